@@ -1,0 +1,155 @@
+/*
+ * NativeUtils.h -- C-ABI of libNativeUtils.so, the MI355X-native drop-in for LiveScan3D's NativeUtils.dll
+ * on the per-tick fusion path (depth -> XYZ unprojection, R(p+t), AABB crop, raster-order merged cloud, ICP).
+ *
+ * Part 1 are the reference's own exports, same names, argument order and meaning, so LiveScanServer's
+ * P/Invoke declarations bind unchanged (LiveScanServer/KinectServer.cs:35-60, MainWindowForm.cs:42-43).
+ * Part 2 is the device-resident API the same code runs on (plain pointers and sizes; no torch / HIP types):
+ * what a host that already keeps frames in HBM (bench.py, the multi-GPU harness) calls.
+ *
+ * Nothing here throws; on failure the exports leave an empty mesh / untouched R,t and lsnGetLastError()
+ * tells why.  There is NO CPU fallback: without a usable HIP device every compute entry point fails loudly.
+ *
+ * Paths in comments are relative to the reference repository root.
+ */
+#ifndef LSN_NATIVEUTILS_H
+#define LSN_NATIVEUTILS_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Part 1 -- the reference's exports
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* include/NativeUtils/depthprocessing.h:29-33 -- 16 bytes, what KinectServer.CopyMeshToVerticesWithColoursArray
+ * copies out (KinectServer.cs:376-389). */
+typedef struct VertexC4ubV3f {
+    unsigned char R, G, B, A;
+    float X, Y, Z;
+} VertexC4ubV3f;
+
+/* include/NativeUtils/depthprocessing.h:42-48 (C# mirror LiveScanServer/Utils.cs:335-342) -- 32 bytes on LP64. */
+typedef struct Mesh {
+    int nVertices;
+    VertexC4ubV3f *vertices;
+    int nTriangles;
+    int *triangles;
+} Mesh;
+
+/* include/NativeUtils/icp.h:15-18 */
+typedef struct Point3f {
+    float X, Y, Z;
+} Point3f;
+
+/* Replaces generateVerticesFromDepthMap, include/NativeUtils/depthprocessing.h:103-105
+ * (src/NativeUtils/depthprocessing.cpp:1631-1657).  depth_maps / depth_colors are the concatenated per-sensor
+ * buffers (u16 LE [h][w] / RGB8 [h][w][3]); intr_params 7 floats per sensor {cx,cy,fx,fy,r2,r4,r6};
+ * wtransform_params 12 floats per sensor {t[3], R[3][3] row-major}, p' = R (p + t).
+ * out_mesh->vertices is host memory owned by the library until deleteMesh; nTriangles = 0. */
+void generateVerticesFromDepthMap(unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+                                  float *intr_params, float *wtransform_params, Mesh *out_mesh,
+                                  float minX, float minY, float minZ, float maxX, float maxY, float maxZ,
+                                  int depth_map_index);
+
+/* Replaces generateMeshFromDepthMaps, include/NativeUtils/depthprocessing.h:108-110
+ * (src/NativeUtils/depthprocessing.cpp:1715-1792).  In scope: the vertices of all sensors, cropped, in sensor
+ * order then raster order (= the reference with both flags false).  Triangulation (always on in the reference,
+ * meshGenerator.cpp) is the first "next" row: until it lands nTriangles = 0 and `triangles` is a valid empty array.
+ * bcolor_transfer / bgenerate_triangles select reference stages that are out of scope (colour transfer, overlay
+ * merge); passing true is reported through lsnGetLastError() and otherwise ignored. */
+void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
+                               int *heights, float *intr_params, float *wtransform_params, Mesh *out_mesh,
+                               bool bcolor_transfer, float minX, float minY, float minZ, float maxX, float maxY,
+                               float maxZ, bool bgenerate_triangles);
+
+/* Replaces createMesh / deleteMesh, src/NativeUtils/depthprocessing.cpp:1818-1835.  deleteMesh releases the two
+ * arrays only (not the struct) and, unlike the reference, also nulls them so a second call is harmless. */
+Mesh *createMesh(void);
+void deleteMesh(Mesh *mesh);
+
+/* Replaces ICP, include/NativeUtils/icp.h:65 (src/NativeUtils/icp.cpp:75-177): point-to-point ICP with exact
+ * nearest neighbours, one-to-one matching, 2.5-sigma rejection on squared distances and an uncentred Kabsch step.
+ * verts1 = target (read only), verts2 = source (moved in place), R (9, row-major) and t (3) in/out.
+ * Returns 1.0f like the reference. */
+float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2, float *R, float *t, int maxIter);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Part 2 -- device-resident API (extension; every pointer named d_* is HIP device memory)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Copies the calling thread's last error message (empty string = none) into buf; returns its length. */
+int lsnGetLastError(char *buf, int len);
+
+/* Number of visible HIP devices (0 when there is none or the runtime cannot initialise). */
+int lsnDeviceCount(void);
+
+/* A fusion plan: fixed rig geometry (n_maps sensors with widths/heights, as in the reference call) replicated
+ * over n_ticks ticks that are fused by ONE launch sequence.  Holds the geometry tables and scan scratch in HBM. */
+typedef struct LsnFusion LsnFusion;
+
+LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const int *widths, const int *heights);
+void lsnFusionDestroy(LsnFusion *plan);
+
+/* Vertices one tick can produce at most (= sum of w*h): the per-tick stride of d_vertices. */
+long long lsnFusionTickCapacity(const LsnFusion *plan);
+
+/* Host arrays exactly like the reference call: intr 7*n_maps, wt 12*n_maps, bounds {minX,minY,minZ,maxX,maxY,maxZ}.
+ * stream is a hipStream_t passed as void* (NULL = the null stream). */
+int lsnFusionSetParams(LsnFusion *plan, const float *intr_params, const float *wtransform_params,
+                       const float *bounds6, void *stream);
+
+/* Selects how the raster-order compaction gets its global offsets: 0 = two-pass (count kernel + write kernel),
+ * 1 = single pass with decoupled look-back.  Results are identical. */
+int lsnFusionSetMode(LsnFusion *plan, int mode);
+
+/* Fuses n_ticks ticks.  d_depth_maps: n_ticks x (concatenated u16 maps of one tick); d_depth_colors likewise RGB8;
+ * d_vertices: n_ticks x lsnFusionTickCapacity() VertexC4ubV3f, tick k's merged cloud starts at k*capacity;
+ * d_offsets: n_ticks x (n_maps+1) ints, [k][i] = index of sensor i's first vertex inside tick k's cloud,
+ * [k][n_maps] = nVertices of tick k.  Asynchronous on `stream`; returns 0 on success. */
+int lsnFusionRun(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_colors, void *d_vertices,
+                 int *d_offsets, void *stream);
+
+/* Name and average duration (ms, HIP events on the plan's stream) of the dominant kernel over the launches
+ * since the last call with reset != 0; used by bench.py's roofline block.  Enable with lsnFusionProfile(plan,1). */
+int lsnFusionProfile(LsnFusion *plan, int enable);
+int lsnFusionKernelStats(LsnFusion *plan, double *avg_ms, long long *launches, char *name, int name_len, int reset);
+
+/* Merged-cloud assembly after an all-gather of per-GPU shards (one block of sensors per GPU, rank order = sensor order):
+ * d_shards [n_shards][n_ticks][shard_cap] vertices and d_shard_offsets [n_shards][n_ticks][maps_per_shard+1] are the
+ * gathered outputs of lsnFusionRun; writes d_merged [n_ticks][merged_cap] (each tick contiguous, formMesh order,
+ * src/NativeUtils/depthprocessing.cpp:1594-1608) and d_merged_offsets [n_ticks][n_shards*maps_per_shard+1]. */
+int lsnMergeShards(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap,
+                   const int *d_shard_offsets, void *d_merged, long long merged_cap, int *d_merged_offsets, void *stream);
+
+/* 1 when the last look-back launch (mode 1) gave up on a bounded spin (outputs invalid), else 0; synchronises. */
+int lsnFusionLookbackFailed(LsnFusion *plan, void *stream);
+
+/* An ICP workspace for clouds of at most max_n1 target / max_n2 source points. */
+typedef struct LsnIcp LsnIcp;
+
+LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2);
+void lsnIcpDestroy(LsnIcp *icp);
+
+/* nn_mode: 0 = LDS-tiled brute force, 1 = voxel grid (exact; falls back to brute force per query when needed).
+ * d_verts1: n1*3 floats (target), d_verts2: n2*3 floats (source, moved in place), d_R 9 floats, d_t 3 floats
+ * (in/out, device).  Asynchronous on `stream`; no host synchronisation inside the iteration loop. */
+int lsnIcpRun(LsnIcp *icp, const float *d_verts1, int n1, float *d_verts2, int n2, float *d_R, float *d_t,
+              int maxIter, int nn_mode, void *stream);
+
+/* The NN step alone (parity tests, ablation): d_idx n2 ints, d_dist2 n2 floats. */
+int lsnIcpNearest(LsnIcp *icp, const float *d_verts1, int n1, const float *d_verts2, int n2, int *d_idx,
+                  float *d_dist2, int nn_mode, void *stream);
+
+/* Per-iteration diagnostics of the last lsnIcpRun (copied to host; synchronises `stream`):
+ * out[iter] = {n_matched, n_kept, mean, stddev, T[3], Rn[9]} as 16 floats (counts stored as floats). */
+int lsnIcpTrace(LsnIcp *icp, float *out16_per_iter, int max_iters, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

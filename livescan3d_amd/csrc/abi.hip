@@ -1,0 +1,323 @@
+// abi.hip -- the reference's C-ABI exports (include/NativeUtils.h part 1) on top of the device-resident API.
+//
+// LiveScanServer hands over host arrays (pinned managed arrays / AllocHGlobal blocks, KinectServer.cs:354-374,
+// MainWindowForm.cs:364-370) and reads host memory back (Marshal.Copy, KinectServer.cs:383), so these entry points
+// add the H2D / D2H hops around the same kernels bench.py drives directly on HBM-resident data.
+// One process-wide context (device from $LSN_DEVICE, default 0) serialises the calls: the reference's exports are
+// re-entrant and LiveScanServer calls them from two BackgroundWorkers (MainWindowForm.cs:238,304).
+#include "lsn_common.hpp"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+namespace lsn {
+
+std::string &last_error()
+{
+    static thread_local std::string s;
+    return s;
+}
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    if (getenv("LSN_VERBOSE")) fprintf(stderr, "[NativeUtils] %s\n", buf);
+}
+
+}  // namespace lsn
+
+extern "C" int lsnGetLastError(char *buf, int len)
+{
+    const std::string &s = lsn::last_error();
+    if (buf && len > 0) snprintf(buf, (size_t)len, "%s", s.c_str());
+    return (int)s.size();
+}
+
+extern "C" int lsnDeviceCount(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+namespace {
+
+struct Ctx {
+    std::mutex mu;
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::vector<int>, LsnFusion *> plans;  // key: n_maps, widths..., heights...
+    lsn::DevBuf d_depth, d_colors, d_out, d_off, d_v1, d_v2, d_Rt;
+    LsnIcp *icp = nullptr;
+    int icp_n1 = 0, icp_n2 = 0;
+    // pinned host blocks handed out as Mesh::vertices, recycled by deleteMesh
+    std::unordered_map<void *, size_t> live;          // ptr -> capacity (bytes)
+    std::multimap<size_t, void *> pool;               // capacity -> ptr
+    std::unordered_map<void *, int> live_tri;         // triangles arrays we own
+};
+
+Ctx &ctx()
+{
+    static Ctx c;
+    return c;
+}
+
+// requires c.mu held
+int ensure_ready(Ctx &c)
+{
+    if (c.ready) return hipSetDevice(c.device) == hipSuccess ? 0 : -1;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        lsn::set_error("NativeUtils: no HIP device is available -- this library has no CPU path");
+        return -1;
+    }
+    const char *env = getenv("LSN_DEVICE");
+    c.device = env ? atoi(env) : 0;
+    if (c.device < 0 || c.device >= n) {
+        lsn::set_error("NativeUtils: LSN_DEVICE=%d but %d device(s) are visible", c.device, n);
+        return -1;
+    }
+    LSN_HIP(hipSetDevice(c.device));
+    LSN_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.ready = true;
+    return 0;
+}
+
+void *pinned_get(Ctx &c, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    auto it = c.pool.lower_bound(bytes);
+    if (it != c.pool.end() && it->first <= bytes * 2 + 4096) {
+        void *p = it->second;
+        c.live[p] = it->first;
+        c.pool.erase(it);
+        return p;
+    }
+    void *p = nullptr;
+    size_t cap = (bytes + 4095) & ~(size_t)4095;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        lsn::set_error("NativeUtils: hipHostMalloc(%zu) failed", cap);
+        return nullptr;
+    }
+    c.live[p] = cap;
+    return p;
+}
+
+void pinned_put(Ctx &c, void *p)
+{
+    auto it = c.live.find(p);
+    if (it == c.live.end()) return;  // not ours: leave it alone
+    size_t cap = it->second;
+    c.live.erase(it);
+    // keep a handful of blocks around, free the rest
+    if (c.pool.size() >= 8) (void)hipHostFree(p);
+    else c.pool.emplace(cap, p);
+}
+
+void empty_mesh(Ctx &c, Mesh *m)
+{
+    m->nVertices = 0;
+    m->vertices = nullptr;
+    m->nTriangles = 0;
+    int *tri = (int *)malloc(sizeof(int));  // "new int[0]": valid, never dereferenced (KinectServer.cs:344-345)
+    m->triangles = tri;
+    if (tri) c.live_tri[tri] = 1;
+}
+
+// Fuses n_maps sensors of one tick from host buffers into out_mesh.  first/count select the sensors
+// (generateVerticesFromDepthMap uses one).  c.mu held.
+int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
+              const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count)
+{
+    std::vector<int> key;
+    key.push_back(count);
+    for (int i = 0; i < count; i++) key.push_back(widths[first + i]);
+    for (int i = 0; i < count; i++) key.push_back(heights[first + i]);
+    LsnFusion *plan = nullptr;
+    auto it = c.plans.find(key);
+    if (it != c.plans.end()) plan = it->second;
+    else {
+        plan = lsnFusionCreate(c.device, 1, count, widths + first, heights + first);
+        if (!plan) return -1;
+        if (c.plans.size() > 64) {  // unbounded variety of geometries: start over
+            for (auto &kv : c.plans) lsnFusionDestroy(kv.second);
+            c.plans.clear();
+        }
+        c.plans[key] = plan;
+    }
+    // sensor `first` starts after the frames before it (depthprocessing.cpp:1646-1650)
+    size_t dskip = 0, cskip = 0, dbytes = 0, cbytes = 0;
+    for (int i = 0; i < first; i++) {
+        dskip += (size_t)widths[i] * heights[i] * 2;
+        cskip += (size_t)widths[i] * heights[i] * 3;
+    }
+    for (int i = 0; i < count; i++) {
+        dbytes += (size_t)widths[first + i] * heights[first + i] * 2;
+        cbytes += (size_t)widths[first + i] * heights[first + i] * 3;
+    }
+    (void)n_maps_total;
+    const long long cap = lsnFusionTickCapacity(plan);
+    if (c.d_depth.reserve(dbytes + 16) || c.d_colors.reserve(cbytes + 16) || c.d_out.reserve((size_t)cap * 16) ||
+        c.d_off.reserve(sizeof(int) * (count + 1)))
+        return -1;
+    LSN_HIP(hipMemcpyAsync(c.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, c.stream));
+    LSN_HIP(hipMemcpyAsync(c.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, c.stream));
+    if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, c.stream)) return -1;
+    if (lsnFusionRun(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.stream)) return -1;
+    std::vector<int> off(count + 1);
+    LSN_HIP(hipMemcpyAsync(off.data(), c.d_off.p, sizeof(int) * (count + 1), hipMemcpyDeviceToHost, c.stream));
+    LSN_HIP(hipStreamSynchronize(c.stream));
+    const int nv = off[count];
+    if (nv < 0 || nv > cap) {
+        lsn::set_error("NativeUtils: device returned an impossible vertex count %d", nv);
+        return -1;
+    }
+    void *host = pinned_get(c, (size_t)nv * sizeof(VertexC4ubV3f));
+    if (!host) return -1;
+    if (nv > 0) {
+        LSN_HIP(hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, c.stream));
+        LSN_HIP(hipStreamSynchronize(c.stream));
+    }
+    out->nVertices = nv;
+    out->vertices = static_cast<VertexC4ubV3f *>(host);
+    out->nTriangles = 0;
+    int *tri = (int *)malloc(sizeof(int));
+    out->triangles = tri;
+    if (tri) c.live_tri[tri] = 1;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" void generateVerticesFromDepthMap(unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+                                             float *intr_params, float *wtransform_params, Mesh *out_mesh, float minX, float minY,
+                                             float minZ, float maxX, float maxY, float maxZ, int depth_map_index)
+{
+    lsn::clear_error();
+    if (!out_mesh) return;
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params || depth_map_index < 0) {
+        lsn::set_error("generateVerticesFromDepthMap: bad arguments");
+        empty_mesh(c, out_mesh);
+        return;
+    }
+    const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
+    if (ensure_ready(c) || fuse_host(c, depth_map_index + 1, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params,
+                                     out_mesh, b, depth_map_index, 1))
+        empty_mesh(c, out_mesh);
+}
+
+extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+                                          float *intr_params, float *wtransform_params, Mesh *out_mesh, bool bcolor_transfer, float minX,
+                                          float minY, float minZ, float maxX, float maxY, float maxZ, bool bgenerate_triangles)
+{
+    lsn::clear_error();
+    if (!out_mesh) return;
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (n_maps <= 0 || !depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params) {
+        if (n_maps != 0) lsn::set_error("generateMeshFromDepthMaps: bad arguments");
+        empty_mesh(c, out_mesh);
+        return;
+    }
+    const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
+    if (ensure_ready(c) ||
+        fuse_host(c, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps)) {
+        empty_mesh(c, out_mesh);
+        return;
+    }
+    if (bcolor_transfer || bgenerate_triangles)
+        lsn::set_error("generateMeshFromDepthMaps: colour transfer / overlay merge are outside this library's scope; "
+                       "returned the cropped vertices of all sensors (flags false,false behaviour)");
+}
+
+extern "C" Mesh *createMesh(void)
+{
+    Mesh *m = (Mesh *)calloc(1, sizeof(Mesh));  // zeroed like depthprocessing.cpp:1820-1825
+    return m;
+}
+
+extern "C" void deleteMesh(Mesh *mesh)
+{
+    if (!mesh) return;
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (mesh->triangles) {
+        auto it = c.live_tri.find(mesh->triangles);
+        if (it != c.live_tri.end()) {
+            c.live_tri.erase(it);
+            free(mesh->triangles);
+        }
+    }
+    if (mesh->vertices) pinned_put(c, mesh->vertices);
+    mesh->triangles = nullptr;
+    mesh->vertices = nullptr;
+}
+
+extern "C" float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2, float *R, float *t, int maxIter)
+{
+    lsn::clear_error();
+    const float error = 1.0f;  // icp.cpp:85,176
+    if (!verts1 || !verts2 || !R || !t || nVerts1 <= 0 || nVerts2 <= 0 || maxIter <= 0) {
+        // the reference would throw out of nanoflann on an empty cloud (include/nanoflann.h:904); callers guard
+        if (nVerts1 <= 0 || nVerts2 <= 0) lsn::set_error("ICP: empty cloud (nVerts1=%d nVerts2=%d)", nVerts1, nVerts2);
+        return error;
+    }
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (ensure_ready(c)) return error;
+    if (!c.icp || nVerts1 > c.icp_n1 || nVerts2 > c.icp_n2) {
+        if (c.icp) lsnIcpDestroy(c.icp);
+        c.icp_n1 = nVerts1 > c.icp_n1 ? nVerts1 : c.icp_n1;
+        c.icp_n2 = nVerts2 > c.icp_n2 ? nVerts2 : c.icp_n2;
+        c.icp = lsnIcpCreate(c.device, c.icp_n1, c.icp_n2);
+        if (!c.icp) {
+            c.icp_n1 = c.icp_n2 = 0;
+            return error;
+        }
+    }
+    if (c.d_v1.reserve(sizeof(float) * 3 * (size_t)nVerts1) || c.d_v2.reserve(sizeof(float) * 3 * (size_t)nVerts2) || c.d_Rt.reserve(64))
+        return error;
+    const char *env = getenv("LSN_NN");
+    const int nn_mode = (env && strcmp(env, "brute") == 0) ? 0 : 1;
+    auto fail = [&]() { return error; };
+    if (hipMemcpyAsync(c.d_v1.p, verts1, sizeof(float) * 3 * (size_t)nVerts1, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
+        hipMemcpyAsync(c.d_v2.p, verts2, sizeof(float) * 3 * (size_t)nVerts2, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
+        hipMemcpyAsync(c.d_Rt.p, R, sizeof(float) * 9, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
+        hipMemcpyAsync(c.d_Rt.as<float>() + 9, t, sizeof(float) * 3, hipMemcpyHostToDevice, c.stream) != hipSuccess) {
+        lsn::set_error("ICP: upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail();
+    }
+    if (lsnIcpRun(c.icp, c.d_v1.as<float>(), nVerts1, c.d_v2.as<float>(), nVerts2, c.d_Rt.as<float>(), c.d_Rt.as<float>() + 9, maxIter,
+                  nn_mode, c.stream))
+        return fail();
+    // results go to a scratch first so that the caller's buffers stay untouched when anything fails
+    std::vector<float> v2((size_t)nVerts2 * 3);
+    float Rt[12];
+    if (hipMemcpyAsync(v2.data(), c.d_v2.p, sizeof(float) * 3 * (size_t)nVerts2, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+        hipMemcpyAsync(Rt, c.d_Rt.p, sizeof(float) * 12, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+        hipStreamSynchronize(c.stream) != hipSuccess) {
+        lsn::set_error("ICP: download failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail();
+    }
+    memcpy(verts2, v2.data(), sizeof(float) * 3 * (size_t)nVerts2);
+    memcpy(R, Rt, sizeof(float) * 9);
+    memcpy(t, Rt + 9, sizeof(float) * 3);
+    return error;
+}

@@ -1,0 +1,656 @@
+// fusion.hip -- fused depth-unproject + R(p+t) + AABB crop + raster-order compaction + AoS pack for gfx950.
+//
+// Replaces, for N sensors x T ticks in one launch sequence, the reference's
+//   createVertices                 src/NativeUtils/depthprocessing.cpp:122-187  (+ RotatePoint :109-120)
+//   generateVerticesFromDepthMaps  :708-733   (std::thread per sensor -> one grid over every pixel of every sensor)
+//   formMesh (vertex part)         :1578-1608 (SoA -> VertexC4ubV3f repack + concatenation in sensor order)
+//
+// Arithmetic contract (bit-exact with the reference, verified against oracle/): every f32 operation is rounded
+// on its own in the reference's order -- this file MUST be compiled with -ffp-contract=off and without any
+// fast-math flag; fp32 '/' is the correctly rounded division.
+//
+// Data layout in HBM (all little-endian, as LiveScanServer packs it, KinectServer.cs:453-498):
+//   depth   [tick][sensor][h][w] u16       -- 2 B / pixel, read with one 16-B load per lane (8 pixels)
+//   colours [tick][sensor][h][w][3] u8     -- 3 B / pixel, read with three 8-B loads per lane (8 pixels)
+//   cloud   [tick][capacity] {u8 R,G,B,A; f32 X,Y,Z} -- 16 B / surviving vertex, written as whole 16-B lanes,
+//                                             sensor-major then raster order (formMesh order)
+// Algorithmic bytes per sensor-frame: 2 P + 19 V  (P pixels, V survivors).  The kernel is HBM-bound; MFMA has no
+// role here (no contraction), the 4x4 pose is wave-uniform and lives in SGPRs (scalar loads), LDS is used for what
+// it is needed for: turning the per-lane compaction into fully coalesced 16-B stores.
+//
+// Compaction: a 256-thread workgroup owns a tile of 2048 consecutive pixels of one sensor-frame (8 per lane, so all
+// global loads are wide and coalesced).  Lanes count their survivors, a wave scan (cross-lane shuffles) and a 4-entry
+// LDS exchange give every survivor its rank inside the tile, survivors are staged in LDS in rank order, and the tile
+// is then copied out with consecutive lanes writing consecutive vertices.  The tile's global offset inside its tick
+// comes either from a preceding count pass (mode 0, two launches) or from a decoupled look-back over per-tile
+// status words in the same launch (mode 1).
+#include "lsn_common.hpp"
+
+#include <mutex>
+#include <vector>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPxPerLane = 8;
+constexpr int kTile = kThreads * kPxPerLane;  // 2048 pixels per workgroup
+
+struct FrameDesc {
+    int w, h, npix, tile_start;  // tile_start: first tile of this frame inside its tick
+    long long depth_off;         // u16 elements from the tick's depth base
+    long long rgb_off;           // bytes from the tick's colour base
+};
+
+struct SensorParams {  // 16 floats, wave-uniform -> scalar loads
+    float cx, cy, fx, fy;
+    float t0, t1, t2;
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+};
+
+struct FuseArgs {
+    const FrameDesc *frames;
+    const unsigned short *tile_frame;  // tile (within tick) -> frame
+    const SensorParams *params;
+    const unsigned short *depth;
+    const unsigned char *rgb;
+    uint4 *out;
+    int *tile_counts;                // mode 0: [n_ticks * tiles_per_tick]
+    unsigned long long *tile_state;  // mode 1: [n_ticks * tiles_per_tick] {flag:2 | value}
+    unsigned int *ticket;            // mode 1: dynamic tile id
+    int *offsets;                    // [n_ticks][n_frames + 1]
+    int *error_flag;                 // mode 1: set when a bounded spin gives up
+    int n_frames;
+    int tiles_per_tick;
+    int n_tiles_total;
+    long long tick_depth_stride;  // u16 elements
+    long long tick_rgb_stride;    // bytes
+    long long tick_vert_stride;   // vertices
+    float minX, minY, minZ, maxX, maxY, maxZ;
+};
+
+// createVertices' per-pixel arithmetic (depthprocessing.cpp:149-163), one rounding per operation.
+// yfac = (cy - float(y)) / fy is shared by the 8 pixels of a lane when they sit in one row.
+__device__ __forceinline__ bool unproject(float d, float xf, float yfac, const SensorParams &P, const FuseArgs &a,
+                                          float &ox, float &oy, float &oz)
+{
+    float Z = d / 1000.0f;
+    float X = (xf - P.cx) / P.fx;
+    float Y = yfac;
+    X = X * Z;
+    Y = Y * Z;
+    X = X + P.t0;
+    Y = Y + P.t1;
+    Z = Z + P.t2;
+    ox = X * P.r00 + Y * P.r01 + Z * P.r02;
+    oy = X * P.r10 + Y * P.r11 + Z * P.r12;
+    oz = X * P.r20 + Y * P.r21 + Z * P.r22;
+    // same comparisons as :162 so a NaN coordinate is kept exactly like the reference keeps it
+    bool rejected = ox < a.minX || ox > a.maxX || oy < a.minY || oy > a.maxY || oz < a.minZ || oz > a.maxZ;
+    return !rejected;
+}
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Look-back status word: bits 63..62 flag (0 = empty, 1 = tile aggregate, 2 = inclusive prefix), low 32 bits value.
+constexpr unsigned long long kFlagAggregate = 1ull << 62;
+constexpr unsigned long long kFlagPrefix = 2ull << 62;
+constexpr int kSpinLimit = 1 << 22;
+
+// MODE 0 = count only (writes tile_counts), 1 = write with offsets from tile_counts, 2 = single pass with look-back.
+// VEC: every frame has w % 8 == 0 and the buffers are 16-B aligned -> 16-B depth loads, 8-B colour loads.
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
+{
+    constexpr bool kWrite = MODE != 0;
+    // rank r lives at slot r + r/8: a lane's 8 consecutive ranks then start 9 slots (144 B) apart, which keeps
+    // the 16-B LDS writes of neighbouring lanes on different bank groups (stride 128 B would be an 8-way conflict).
+    __shared__ uint4 stage[kWrite ? (kTile + kTile / 8) : 1];
+    __shared__ int s_wave_tot[4];
+    __shared__ int s_wave_pre[4];
+    __shared__ int s_tile;
+    __shared__ int s_base;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    int gtile = blockIdx.x;
+    if (MODE == 2) {
+        // tiles are handed out in launch order so that every tile a workgroup looks back at is already running
+        if (threadIdx.x == 0) s_tile = (int)atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        gtile = s_tile;
+    }
+    const int tick = gtile / a.tiles_per_tick;
+    const int tile = gtile - tick * a.tiles_per_tick;
+    const int f = a.tile_frame[tile];
+    const FrameDesc fd = a.frames[f];
+    const SensorParams P = a.params[f];
+
+    const int p0 = (tile - fd.tile_start) * kTile + threadIdx.x * kPxPerLane;
+    const unsigned short *dptr = a.depth + tick * a.tick_depth_stride + fd.depth_off;
+    const unsigned char *cptr = a.rgb + tick * a.tick_rgb_stride + fd.rgb_off;
+
+    // ---- loads ---------------------------------------------------------------------------------------------
+    unsigned int dw[4] = {0, 0, 0, 0};  // 8 x u16
+    unsigned int cw[6] = {0, 0, 0, 0, 0, 0};  // 8 x RGB8
+    if (VEC) {
+        if (p0 < fd.npix) {
+            uint4 dv = *reinterpret_cast<const uint4 *>(dptr + p0);
+            dw[0] = dv.x; dw[1] = dv.y; dw[2] = dv.z; dw[3] = dv.w;
+            if (kWrite) {
+                const uint2 *cp = reinterpret_cast<const uint2 *>(cptr + 3ll * p0);
+                uint2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+                cw[0] = c0.x; cw[1] = c0.y; cw[2] = c1.x; cw[3] = c1.y; cw[4] = c2.x; cw[5] = c2.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            if (p0 + k < fd.npix) {
+                unsigned int d = dptr[p0 + k];
+                dw[k >> 1] |= d << ((k & 1) * 16);
+                if (kWrite) {
+                    const unsigned char *c = cptr + 3ll * (p0 + k);
+                    unsigned int rgb = c[0] | (c[1] << 8) | (c[2] << 16);
+                    // append 3 bytes at byte offset 3k of the 24-byte group
+                    int b = 3 * k;
+                    cw[b >> 2] |= rgb << ((b & 3) * 8);
+                    if ((b & 3) > 1) cw[(b >> 2) + 1] |= rgb >> ((4 - (b & 3)) * 8);
+                }
+            }
+        }
+    }
+
+    // ---- per-pixel arithmetic ------------------------------------------------------------------------------
+    int y = p0 / fd.w;
+    int x = p0 - y * fd.w;
+    float yfac = (P.cy - (float)y) / P.fy;
+    float vx[kPxPerLane], vy[kPxPerLane], vz[kPxPerLane];
+    unsigned int mask = 0;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) {
+        unsigned int d = (dw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+        bool keep = false;
+        if (d != 0) keep = unproject((float)d, (float)x, yfac, P, a, vx[k], vy[k], vz[k]);
+        mask |= (keep ? 1u : 0u) << k;
+        if (!VEC) {
+            // rows may end inside a lane's 8 pixels when w % 8 != 0
+            x++;
+            if (x == fd.w) {
+                x = 0;
+                y++;
+                yfac = (P.cy - (float)y) / P.fy;
+            }
+        } else {
+            x++;
+        }
+    }
+
+    // ---- rank inside the tile --------------------------------------------------------------------------------
+    const int cnt = __popc(mask);
+    const int incl = wave_inclusive_scan(cnt, lane);
+    if (lane == 63) s_wave_tot[wave] = incl;
+
+    int base = 0;
+    if (MODE == 1) {
+        // offset of this tile inside its tick = counts of the tiles before it (<= a few hundred ints, L2 resident)
+        const int *tc = a.tile_counts + (long long)tick * a.tiles_per_tick;
+        int part = 0;
+        for (int i = threadIdx.x; i < tile; i += kThreads) part += tc[i];
+        part = wave_sum(part);
+        if (lane == 0) s_wave_pre[wave] = part;
+    }
+    __syncthreads();
+    int wave_off = 0, tile_tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int v = s_wave_tot[i];
+        if (i < wave) wave_off += v;
+        tile_tot += v;
+    }
+    if (MODE == 1) base = s_wave_pre[0] + s_wave_pre[1] + s_wave_pre[2] + s_wave_pre[3];
+
+    if (MODE == 0) {
+        if (threadIdx.x == 0) a.tile_counts[gtile] = tile_tot;
+        return;
+    }
+
+    // ---- stage survivors in rank order ----------------------------------------------------------------------
+    int r = wave_off + incl - cnt;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) {
+        if (mask & (1u << k)) {
+            const int b = 3 * k;
+            unsigned int lo = cw[b >> 2];
+            unsigned int hi = cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
+            unsigned int rgba = (__funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu) | 0xFF000000u;  // A = 255 (:1601)
+            stage[r + (r >> 3)] = make_uint4(rgba, __float_as_uint(vx[k]), __float_as_uint(vy[k]), __float_as_uint(vz[k]));
+            r++;
+        }
+    }
+
+    if (MODE == 2) {
+        // ---- decoupled look-back over the tiles of this tick (wave 0) ----------------------------------------
+        if (wave == 0) {
+            unsigned long long *st = a.tile_state + (long long)tick * a.tiles_per_tick;
+            if (lane == 0) {
+                unsigned long long w = (tile == 0 ? kFlagPrefix : kFlagAggregate) | (unsigned int)tile_tot;
+                __hip_atomic_store(&st[tile], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int run = 0;
+            int pos = tile - 1 - lane;  // lane 0 looks at the nearest predecessor
+            bool done = tile == 0;
+            int spins = 0;
+            while (!done) {
+                unsigned long long w = 0;
+                if (pos >= 0) w = __hip_atomic_load(&st[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else w = kFlagPrefix;  // before the first tile: prefix 0
+                const unsigned int flag = (unsigned int)(w >> 62);
+                const unsigned long long pref = __ballot(flag == 2);
+                // only the predecessors up to and including the nearest prefix holder matter
+                const int first = pref ? __ffsll((long long)pref) - 1 : 63;
+                const unsigned long long relevant = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+                const unsigned long long empty = __ballot(flag == 0) & relevant;
+                if (empty != 0) {
+                    // one of them has not published yet: poll again (bounded, so the grid always drains)
+                    if (++spins > kSpinLimit) {
+                        if (lane == 0) atomicExch(a.error_flag, 1);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                int v = (lane <= first) ? (int)(unsigned int)w : 0;
+                run += wave_sum(v);
+                if (pref) done = true;
+                else pos -= 64;
+            }
+            if (lane == 0) {
+                if (tile != 0) {
+                    unsigned long long w = kFlagPrefix | (unsigned int)(run + tile_tot);
+                    __hip_atomic_store(&st[tile], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_base = run;
+            }
+        }
+        __syncthreads();
+        base = s_base;
+    } else {
+        __syncthreads();
+    }
+
+    // ---- coalesced copy-out: consecutive lanes write consecutive 16-B vertices ------------------------------
+    uint4 *dst = a.out + tick * a.tick_vert_stride + base;
+    for (int i = threadIdx.x; i < tile_tot; i += kThreads) dst[i] = stage[i + (i >> 3)];
+
+    if (threadIdx.x == 0) {
+        int *off = a.offsets + (long long)tick * (a.n_frames + 1);
+        if (tile == fd.tile_start) off[f] = base;
+        if (tile == a.tiles_per_tick - 1) off[a.n_frames] = base + tile_tot;
+    }
+}
+
+// Merged-cloud assembly after the all-gather (one sensor block per GPU): shard r holds, for every tick, the cloud of
+// its own sensors at [r][tick][0 .. count) of a fixed-capacity slab; the merged cloud of a tick is the concatenation
+// of the shards in rank order = formMesh's sensor order (depthprocessing.cpp:1594-1608).
+struct MergeArgs {
+    const uint4 *shards;     // [n_shards][n_ticks][shard_cap]
+    const int *shard_off;    // [n_shards][n_ticks][maps_per_shard + 1]  (the gathered lsnFusionRun offsets)
+    uint4 *merged;           // [n_ticks][merged_cap]
+    int *merged_off;         // [n_ticks][n_shards * maps_per_shard + 1]
+    long long shard_cap, merged_cap;
+    int n_shards, n_ticks, maps_per_shard;
+};
+
+__global__ __launch_bounds__(kThreads) void merge_shards_kernel(const MergeArgs a)
+{
+    const int tick = blockIdx.y / a.n_shards;
+    const int shard = blockIdx.y - tick * a.n_shards;
+    const int mps1 = a.maps_per_shard + 1;
+    int base = 0;
+    for (int r = 0; r < shard; r++) base += a.shard_off[((long long)r * a.n_ticks + tick) * mps1 + a.maps_per_shard];
+    const int *my_off = a.shard_off + ((long long)shard * a.n_ticks + tick) * mps1;
+    const int count = my_off[a.maps_per_shard];
+    const uint4 *src = a.shards + ((long long)shard * a.n_ticks + tick) * a.shard_cap;
+    uint4 *dst = a.merged + (long long)tick * a.merged_cap + base;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < count; i += gridDim.x * kThreads) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x <= a.maps_per_shard) {
+        int *mo = a.merged_off + (long long)tick * (a.n_shards * a.maps_per_shard + 1);
+        if (threadIdx.x < a.maps_per_shard) mo[shard * a.maps_per_shard + threadIdx.x] = base + my_off[threadIdx.x];
+        else if (shard == a.n_shards - 1) mo[a.n_shards * a.maps_per_shard] = base + count;
+    }
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------------------
+
+struct LsnFusion {
+    int device = 0;
+    int n_ticks = 0, n_maps = 0;
+    std::vector<int> w, h;
+    long long cap = 0;  // vertices per tick
+    long long tick_depth_elems = 0, tick_rgb_bytes = 0;
+    int tiles_per_tick = 0;
+    bool vec_ok = false;
+    bool params_set = false;
+    int mode = 0;
+    float bounds[6] = {0, 0, 0, 0, 0, 0};
+    lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: ticket + error flag
+    // dominant-kernel timing
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t ev_used = 0;
+    double acc_ms = 0;
+    long long launches = 0;
+    std::mutex mu;
+};
+
+extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const int *widths, const int *heights)
+{
+    lsn::clear_error();
+    if (n_ticks <= 0 || n_maps <= 0 || !widths || !heights) {
+        lsn::set_error("lsnFusionCreate: bad arguments (n_ticks=%d n_maps=%d)", n_ticks, n_maps);
+        return nullptr;
+    }
+    if (n_maps > 65535) {
+        lsn::set_error("lsnFusionCreate: at most 65535 sensors");
+        return nullptr;
+    }
+    LSN_HIP_NULL(hipSetDevice(device));
+    LsnFusion *p = new (std::nothrow) LsnFusion();
+    if (!p) return nullptr;
+    p->device = device;
+    p->n_ticks = n_ticks;
+    p->n_maps = n_maps;
+    std::vector<FrameDesc> fr(n_maps);
+    std::vector<unsigned short> tf;
+    long long doff = 0, coff = 0;
+    int tiles = 0;
+    bool vec = true;
+    for (int i = 0; i < n_maps; i++) {
+        if (widths[i] <= 0 || heights[i] <= 0 || (long long)widths[i] * heights[i] > (1ll << 30)) {
+            lsn::set_error("lsnFusionCreate: bad frame size %dx%d", widths[i], heights[i]);
+            delete p;
+            return nullptr;
+        }
+        p->w.push_back(widths[i]);
+        p->h.push_back(heights[i]);
+        const int npix = widths[i] * heights[i];
+        fr[i].w = widths[i];
+        fr[i].h = heights[i];
+        fr[i].npix = npix;
+        fr[i].tile_start = tiles;
+        fr[i].depth_off = doff;
+        fr[i].rgb_off = coff;
+        const int nt = (npix + kTile - 1) / kTile;
+        for (int t = 0; t < nt; t++) tf.push_back((unsigned short)i);
+        tiles += nt;
+        doff += npix;
+        coff += 3ll * npix;
+        // 16-B depth loads / 8-B colour loads need every frame to start 8-pixel aligned and rows not to split a lane
+        if (widths[i] % 8 != 0) vec = false;
+    }
+    p->cap = doff;
+    p->tick_depth_elems = doff;
+    p->tick_rgb_bytes = coff;
+    p->tiles_per_tick = tiles;
+    p->vec_ok = vec;
+    if (doff > 0x7FFFFFFFll) {
+        lsn::set_error("lsnFusionCreate: a tick may not exceed 2^31-1 pixels (Mesh.nVertices is an int)");
+        delete p;
+        return nullptr;
+    }
+    if ((long long)tiles * n_ticks > 0x7FFFFFFFll) {
+        lsn::set_error("lsnFusionCreate: too many tiles");
+        delete p;
+        return nullptr;
+    }
+    const size_t n_tiles_total = (size_t)tiles * n_ticks;
+    if (p->frames.reserve(sizeof(FrameDesc) * n_maps) || p->tile_frame.reserve(sizeof(unsigned short) * tf.size()) ||
+        p->params.reserve(sizeof(SensorParams) * n_maps) || p->tile_counts.reserve(sizeof(int) * n_tiles_total) ||
+        p->tile_state.reserve(sizeof(unsigned long long) * n_tiles_total) || p->misc.reserve(256)) {
+        delete p;
+        return nullptr;
+    }
+    if (hipMemcpy(p->frames.p, fr.data(), sizeof(FrameDesc) * n_maps, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->tile_frame.p, tf.data(), sizeof(unsigned short) * tf.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        lsn::set_error("lsnFusionCreate: geometry upload failed");
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void lsnFusionDestroy(LsnFusion *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (auto &e : p->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete p;
+}
+
+extern "C" long long lsnFusionTickCapacity(const LsnFusion *p) { return p ? p->cap : 0; }
+
+extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *wt, const float *bounds6, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !intr || !wt || !bounds6) {
+        lsn::set_error("lsnFusionSetParams: null argument");
+        return -1;
+    }
+    LSN_HIP(hipSetDevice(p->device));
+    std::vector<SensorParams> sp(p->n_maps);
+    for (int i = 0; i < p->n_maps; i++) {
+        // IntrinsicCameraParameters(float*) / WorldTranformation(float*), include/NativeUtils/depthprocessing.h:56-63,96-97
+        const float *ip = intr + 7 * i, *tp = wt + 12 * i;
+        SensorParams &s = sp[i];
+        s.cx = ip[0]; s.cy = ip[1]; s.fx = ip[2]; s.fy = ip[3];
+        s.t0 = tp[0]; s.t1 = tp[1]; s.t2 = tp[2];
+        s.r00 = tp[3]; s.r01 = tp[4]; s.r02 = tp[5];
+        s.r10 = tp[6]; s.r11 = tp[7]; s.r12 = tp[8];
+        s.r20 = tp[9]; s.r21 = tp[10]; s.r22 = tp[11];
+    }
+    // pageable source: hipMemcpyAsync copies it out before returning, so the local vector may die
+    LSN_HIP(hipMemcpyAsync(p->params.p, sp.data(), sizeof(SensorParams) * p->n_maps, hipMemcpyHostToDevice,
+                           lsn::as_stream(stream)));
+    LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
+    memcpy(p->bounds, bounds6, sizeof(p->bounds));
+    p->params_set = true;
+    return 0;
+}
+
+extern "C" int lsnFusionSetMode(LsnFusion *p, int mode)
+{
+    if (!p || mode < 0 || mode > 1) {
+        lsn::set_error("lsnFusionSetMode: mode must be 0 (two-pass) or 1 (look-back)");
+        return -1;
+    }
+    p->mode = mode;
+    return 0;
+}
+
+extern "C" int lsnFusionProfile(LsnFusion *p, int enable)
+{
+    if (!p) return -1;
+    p->profile = enable != 0;
+    return 0;
+}
+
+static int drain_events(LsnFusion *p)
+{
+    for (size_t i = 0; i < p->ev_used; i++) {
+        float ms = 0;
+        LSN_HIP(hipEventSynchronize(p->events[i].second));
+        LSN_HIP(hipEventElapsedTime(&ms, p->events[i].first, p->events[i].second));
+        p->acc_ms += ms;
+        p->launches++;
+    }
+    p->ev_used = 0;
+    return 0;
+}
+
+extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *launches, char *name, int name_len, int reset)
+{
+    lsn::clear_error();
+    if (!p) return -1;
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    if (drain_events(p)) return -1;
+    if (avg_ms) *avg_ms = p->launches ? p->acc_ms / (double)p->launches : 0.0;
+    if (launches) *launches = p->launches;
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", p->mode == 0 ? "fuse_kernel<1>" : "fuse_kernel<2>");
+    if (reset) {
+        p->acc_ms = 0;
+        p->launches = 0;
+    }
+    return 0;
+}
+
+template <int MODE>
+static void launch(bool vec, int grid, hipStream_t s, const FuseArgs &a)
+{
+    if (vec) hipLaunchKernelGGL((fuse_kernel<MODE, true>), dim3(grid), dim3(kThreads), 0, s, a);
+    else     hipLaunchKernelGGL((fuse_kernel<MODE, false>), dim3(grid), dim3(kThreads), 0, s, a);
+}
+
+extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+                            void *stream)
+{
+    lsn::clear_error();
+    if (!p || !d_depth || !d_colors || !d_vertices || !d_offsets) {
+        lsn::set_error("lsnFusionRun: null argument");
+        return -1;
+    }
+    if (!p->params_set) {
+        lsn::set_error("lsnFusionRun: lsnFusionSetParams has not been called");
+        return -1;
+    }
+    if (((uintptr_t)d_vertices & 15) != 0) {
+        lsn::set_error("lsnFusionRun: d_vertices must be 16-byte aligned");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    hipStream_t s = lsn::as_stream(stream);
+
+    FuseArgs a;
+    a.frames = p->frames.as<FrameDesc>();
+    a.tile_frame = p->tile_frame.as<unsigned short>();
+    a.params = p->params.as<SensorParams>();
+    a.depth = static_cast<const unsigned short *>(d_depth);
+    a.rgb = static_cast<const unsigned char *>(d_colors);
+    a.out = static_cast<uint4 *>(d_vertices);
+    a.tile_counts = p->tile_counts.as<int>();
+    a.tile_state = p->tile_state.as<unsigned long long>();
+    a.ticket = p->misc.as<unsigned int>();
+    a.error_flag = p->misc.as<int>() + 1;
+    a.offsets = d_offsets;
+    a.n_frames = p->n_maps;
+    a.tiles_per_tick = p->tiles_per_tick;
+    a.n_tiles_total = p->tiles_per_tick * p->n_ticks;
+    a.tick_depth_stride = p->tick_depth_elems;
+    a.tick_rgb_stride = p->tick_rgb_bytes;
+    a.tick_vert_stride = p->cap;
+    a.minX = p->bounds[0]; a.minY = p->bounds[1]; a.minZ = p->bounds[2];
+    a.maxX = p->bounds[3]; a.maxY = p->bounds[4]; a.maxZ = p->bounds[5];
+
+    // the wide-load path also needs 16-B aligned buffers and every tick to start 16-B / 8-B aligned
+    const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 &&
+                     (p->tick_depth_elems % 8) == 0;
+    const int grid = a.n_tiles_total;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (p->profile) {
+        if (p->ev_used == p->events.size()) {
+            if (p->events.size() >= 4096) {
+                if (drain_events(p)) return -1;
+            } else {
+                hipEvent_t x, y;
+                LSN_HIP(hipEventCreate(&x));
+                LSN_HIP(hipEventCreate(&y));
+                p->events.emplace_back(x, y);
+            }
+        }
+        e0 = p->events[p->ev_used].first;
+        e1 = p->events[p->ev_used].second;
+        p->ev_used++;
+    }
+
+    if (p->mode == 0) {
+        launch<0>(vec, grid, s, a);
+        if (e0) LSN_HIP(hipEventRecord(e0, s));
+        launch<1>(vec, grid, s, a);
+        if (e1) LSN_HIP(hipEventRecord(e1, s));
+    } else {
+        LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)a.n_tiles_total, s));
+        LSN_HIP(hipMemsetAsync(p->misc.p, 0, 8, s));
+        if (e0) LSN_HIP(hipEventRecord(e0, s));
+        launch<2>(vec, grid, s, a);
+        if (e1) LSN_HIP(hipEventRecord(e1, s));
+    }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+// Reads back the look-back error flag (diagnostics for tests); synchronises the stream.
+extern "C" int lsnFusionLookbackFailed(LsnFusion *p, void *stream)
+{
+    if (!p) return -1;
+    int flag = 0;
+    LSN_HIP(hipSetDevice(p->device));
+    LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
+    LSN_HIP(hipMemcpy(&flag, p->misc.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost));
+    return flag;
+}
+
+extern "C" int lsnMergeShards(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap,
+                              const int *d_shard_offsets, void *d_merged, long long merged_cap, int *d_merged_offsets, void *stream)
+{
+    lsn::clear_error();
+    if (n_shards <= 0 || n_ticks <= 0 || maps_per_shard <= 0 || maps_per_shard >= kThreads || !d_shards || !d_shard_offsets || !d_merged ||
+        !d_merged_offsets || shard_cap <= 0 || merged_cap < shard_cap) {
+        lsn::set_error("lsnMergeShards: bad arguments");
+        return -1;
+    }
+    if ((long long)n_shards * n_ticks > 65535) {
+        lsn::set_error("lsnMergeShards: n_shards * n_ticks must not exceed 65535");
+        return -1;
+    }
+    LSN_HIP(hipSetDevice(device));
+    MergeArgs a;
+    a.shards = static_cast<const uint4 *>(d_shards);
+    a.shard_off = d_shard_offsets;
+    a.merged = static_cast<uint4 *>(d_merged);
+    a.merged_off = d_merged_offsets;
+    a.shard_cap = shard_cap;
+    a.merged_cap = merged_cap;
+    a.n_shards = n_shards;
+    a.n_ticks = n_ticks;
+    a.maps_per_shard = maps_per_shard;
+    long long chunks = (shard_cap + kThreads * 8 - 1) / (kThreads * 8);
+    if (chunks > 256) chunks = 256;
+    hipLaunchKernelGGL(merge_shards_kernel, dim3((unsigned)chunks, (unsigned)(n_shards * n_ticks)), dim3(kThreads), 0, lsn::as_stream(stream), a);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}

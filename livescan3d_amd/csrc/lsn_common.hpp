@@ -1,0 +1,66 @@
+// lsn_common.hpp -- shared host-side plumbing of libNativeUtils.so (error channel, HIP checks, small RAII).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/NativeUtils.h"
+
+namespace lsn {
+
+// Thread-local error text behind lsnGetLastError().  The reference's exports have no error channel at all
+// (void / constant returns, src/NativeUtils/depthprocessing.cpp:1631,1715; icp.cpp:176); nothing may throw
+// across the C-ABI, so failures end up here.
+std::string &last_error();
+void set_error(const char *fmt, ...);
+inline void clear_error() { last_error().clear(); }
+
+#define LSN_HIP(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            lsn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);   \
+            return -1;                                                                                   \
+        }                                                                                                \
+    } while (0)
+
+#define LSN_HIP_NULL(expr)                                                                               \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            lsn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);   \
+            return nullptr;                                                                              \
+        }                                                                                                \
+    } while (0)
+
+// Device buffer that frees itself; not copyable.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // grow-only
+    int reserve(size_t n) {
+        if (n <= bytes) return 0;
+        release();
+        LSN_HIP(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
+
+}  // namespace lsn

@@ -1,0 +1,307 @@
+"""ctypes binding of libNativeUtils.so (include/NativeUtils.h).
+
+Part 1 mirrors LiveScanServer's P/Invoke declarations (LiveScanServer/KinectServer.cs:35-60,
+MainWindowForm.cs:42-43): same entry points, same array conventions.  Part 2 binds the device-resident
+API; device pointers are plain integers (e.g. torch.Tensor.data_ptr()).
+
+The library is loaded from livescan3d_amd/lib/ (built in-tree by __graft_entry__.build()).  If it is missing
+or a call fails, NativeUtilsError is raised -- nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libNativeUtils.so")
+
+VERTEX_DTYPE = np.dtype([("R", "u1"), ("G", "u1"), ("B", "u1"), ("A", "u1"),
+                         ("X", "<f4"), ("Y", "<f4"), ("Z", "<f4")])  # VertexC4ubV3f, 16 bytes
+
+# every symbol include/NativeUtils.h declares
+EXPORTS = [
+    "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "createMesh", "deleteMesh", "ICP",
+    "lsnGetLastError", "lsnDeviceCount",
+    "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
+    "lsnFusionRun", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
+    "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace",
+]
+
+
+class NativeUtilsError(RuntimeError):
+    pass
+
+
+class Mesh(C.Structure):
+    """struct Mesh (include/NativeUtils/depthprocessing.h:42-48; C# mirror Utils.cs:335-342)."""
+    _fields_ = [("nVertices", C.c_int), ("vertices", C.c_void_p), ("nTriangles", C.c_int), ("triangles", C.c_void_p)]
+
+
+assert C.sizeof(Mesh) == 32
+
+_lib = None
+
+
+def lib():
+    """Loads libNativeUtils.so and declares the prototypes.  Raises NativeUtilsError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeUtilsError(f"{LIB_PATH} is missing -- run __graft_entry__.build() (there is no CPU fallback)")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeUtilsError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
+    f = C.c_float
+    L.generateVerticesFromDepthMap.restype = None
+    L.generateVerticesFromDepthMap.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(Mesh), f, f, f, f, f, f, C.c_int]
+    L.generateMeshFromDepthMaps.restype = None
+    L.generateMeshFromDepthMaps.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(Mesh), C.c_bool,
+                                            f, f, f, f, f, f, C.c_bool]
+    L.createMesh.restype = C.POINTER(Mesh)
+    L.createMesh.argtypes = []
+    L.deleteMesh.restype = None
+    L.deleteMesh.argtypes = [C.POINTER(Mesh)]
+    L.ICP.restype = C.c_float
+    L.ICP.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.lsnGetLastError.restype = C.c_int
+    L.lsnGetLastError.argtypes = [C.c_char_p, C.c_int]
+    L.lsnDeviceCount.restype = C.c_int
+    L.lsnDeviceCount.argtypes = []
+    L.lsnFusionCreate.restype = vp
+    L.lsnFusionCreate.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]
+    L.lsnFusionDestroy.restype = None
+    L.lsnFusionDestroy.argtypes = [vp]
+    L.lsnFusionTickCapacity.restype = C.c_longlong
+    L.lsnFusionTickCapacity.argtypes = [vp]
+    L.lsnFusionSetParams.restype = C.c_int
+    L.lsnFusionSetParams.argtypes = [vp, vp, vp, vp, vp]
+    L.lsnFusionSetMode.restype = C.c_int
+    L.lsnFusionSetMode.argtypes = [vp, C.c_int]
+    L.lsnFusionRun.restype = C.c_int
+    L.lsnFusionRun.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.lsnFusionProfile.restype = C.c_int
+    L.lsnFusionProfile.argtypes = [vp, C.c_int]
+    L.lsnFusionKernelStats.restype = C.c_int
+    L.lsnFusionKernelStats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_char_p, C.c_int, C.c_int]
+    L.lsnFusionLookbackFailed.restype = C.c_int
+    L.lsnFusionLookbackFailed.argtypes = [vp, vp]
+    L.lsnMergeShards.restype = C.c_int
+    L.lsnMergeShards.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp]
+    L.lsnIcpCreate.restype = vp
+    L.lsnIcpCreate.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.lsnIcpDestroy.restype = None
+    L.lsnIcpDestroy.argtypes = [vp]
+    L.lsnIcpRun.restype = C.c_int
+    L.lsnIcpRun.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]
+    L.lsnIcpNearest.restype = C.c_int
+    L.lsnIcpNearest.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
+    L.lsnIcpTrace.restype = C.c_int
+    L.lsnIcpTrace.argtypes = [vp, vp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def last_error():
+    buf = C.create_string_buffer(1024)
+    lib().lsnGetLastError(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise NativeUtilsError(f"{what} failed: {last_error()}")
+
+
+def device_count():
+    return int(lib().lsnDeviceCount())
+
+
+def require_gpu():
+    if device_count() <= 0:
+        raise NativeUtilsError("no HIP device visible: libNativeUtils has no CPU path")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _as(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Part 1: the reference's exports (host buffers in, host buffers out)
+# ----------------------------------------------------------------------------------------------------------
+
+def _copy_mesh(mesh):
+    """KinectServer.CopyMeshToVerticesWithColoursArray (KinectServer.cs:376-389) + deleteMesh."""
+    n = mesh.nVertices
+    if n > 0:
+        if not mesh.vertices:
+            raise NativeUtilsError("mesh has nVertices > 0 but a null vertices pointer")
+        raw = C.string_at(mesh.vertices, n * 16)
+        verts = np.frombuffer(raw, dtype=VERTEX_DTYPE).copy()
+    else:
+        verts = np.zeros(0, dtype=VERTEX_DTYPE)
+    ntri = mesh.nTriangles
+    tris = np.zeros(0, dtype=np.int32)
+    if ntri > 0:
+        tris = np.frombuffer(C.string_at(mesh.triangles, ntri * 12), dtype=np.int32).copy()
+    lib().deleteMesh(C.byref(mesh))
+    return verts, tris
+
+
+def generate_mesh_from_depth_maps(depth_maps, depth_colors, widths, heights, intr, wt, bounds,
+                                  color_transfer=False, generate_triangles=False):
+    """KinectServer.GenerateMesh (KinectServer.cs:354-374).  Returns (vertices[VERTEX_DTYPE], triangles int32)."""
+    require_gpu()
+    widths, heights = _as(widths, np.int32), _as(heights, np.int32)
+    n = len(widths)
+    dm = np.ascontiguousarray(depth_maps).view(np.uint8).ravel()
+    dc = _as(depth_colors, np.uint8).ravel()
+    intr, wt, b = _as(intr, np.float32).ravel(), _as(wt, np.float32).ravel(), _as(bounds, np.float32).ravel()
+    assert intr.size == 7 * n and wt.size == 12 * n and b.size == 6
+    mesh = Mesh()
+    lib().generateMeshFromDepthMaps(n, _ptr(dm), _ptr(dc), _ptr(widths), _ptr(heights), _ptr(intr), _ptr(wt),
+                                    C.byref(mesh), bool(color_transfer), *[float(x) for x in b], bool(generate_triangles))
+    err = last_error()
+    if err and mesh.nVertices == 0 and not (color_transfer or generate_triangles):
+        lib().deleteMesh(C.byref(mesh))
+        raise NativeUtilsError(err)
+    return _copy_mesh(mesh)
+
+
+def generate_vertices_from_depth_map(depth_maps, depth_colors, widths, heights, intr, wt, bounds, index):
+    """One sensor's cropped cloud, as KinectServer.GetLatestFrameVerticesOnly calls it (KinectServer.cs:527-554)."""
+    require_gpu()
+    widths, heights = _as(widths, np.int32), _as(heights, np.int32)
+    n = len(widths)
+    dm = np.ascontiguousarray(depth_maps).view(np.uint8).ravel()
+    dc = _as(depth_colors, np.uint8).ravel()
+    intr, wt, b = _as(intr, np.float32).ravel(), _as(wt, np.float32).ravel(), _as(bounds, np.float32).ravel()
+    assert intr.size == 7 * n and wt.size == 12 * n and b.size == 6
+    mesh = Mesh()
+    lib().generateVerticesFromDepthMap(_ptr(dm), _ptr(dc), _ptr(widths), _ptr(heights), _ptr(intr), _ptr(wt),
+                                       C.byref(mesh), *[float(x) for x in b], int(index))
+    err = last_error()
+    if err and mesh.nVertices == 0:
+        lib().deleteMesh(C.byref(mesh))
+        raise NativeUtilsError(err)
+    return _copy_mesh(mesh)[0]
+
+
+def icp(verts1, verts2, R=None, t=None, max_iter=10):
+    """ICP export (MainWindowForm.cs:42-43,370).  Returns (verts2_out, R_out[3,3], t_out[3]); inputs are not modified."""
+    require_gpu()
+    v1 = _as(verts1, np.float32).reshape(-1, 3)
+    v2 = _as(verts2, np.float32).reshape(-1, 3).copy()
+    R = np.eye(3, dtype=np.float32).ravel() if R is None else _as(R, np.float32).ravel().copy()
+    t = np.zeros(3, dtype=np.float32) if t is None else _as(t, np.float32).ravel().copy()
+    lib().ICP(_ptr(v1), _ptr(v2), len(v1), len(v2), _ptr(R), _ptr(t), int(max_iter))
+    err = last_error()
+    if err:
+        raise NativeUtilsError(err)
+    return v2, R.reshape(3, 3), t
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Part 2: device-resident API
+# ----------------------------------------------------------------------------------------------------------
+
+class FusionPlan:
+    """lsnFusion*: T ticks x N sensors fused per call on HBM-resident inputs."""
+
+    def __init__(self, device, n_ticks, widths, heights):
+        require_gpu()
+        self.widths, self.heights = _as(widths, np.int32), _as(heights, np.int32)
+        self.n_maps, self.n_ticks, self.device = len(self.widths), int(n_ticks), int(device)
+        self._h = lib().lsnFusionCreate(self.device, self.n_ticks, self.n_maps, _ptr(self.widths), _ptr(self.heights))
+        if not self._h:
+            raise NativeUtilsError(f"lsnFusionCreate failed: {last_error()}")
+        self.capacity = int(lib().lsnFusionTickCapacity(self._h))
+        self.pixels_per_tick = int(np.sum(self.widths.astype(np.int64) * self.heights))
+
+    def set_params(self, intr, wt, bounds, stream=0):
+        intr, wt, b = _as(intr, np.float32).ravel(), _as(wt, np.float32).ravel(), _as(bounds, np.float32).ravel()
+        assert intr.size == 7 * self.n_maps and wt.size == 12 * self.n_maps and b.size == 6
+        _check(lib().lsnFusionSetParams(self._h, _ptr(intr), _ptr(wt), _ptr(b), stream), "lsnFusionSetParams")
+
+    def set_mode(self, mode):
+        _check(lib().lsnFusionSetMode(self._h, int(mode)), "lsnFusionSetMode")
+
+    def run(self, d_depth, d_colors, d_vertices, d_offsets, stream=0):
+        """All four are device pointers (ints); asynchronous on `stream` (a hipStream_t as int, 0 = null stream)."""
+        _check(lib().lsnFusionRun(self._h, d_depth, d_colors, d_vertices, d_offsets, stream), "lsnFusionRun")
+
+    def lookback_failed(self, stream=0):
+        return int(lib().lsnFusionLookbackFailed(self._h, stream))
+
+    def profile(self, enable=True):
+        _check(lib().lsnFusionProfile(self._h, 1 if enable else 0), "lsnFusionProfile")
+
+    def kernel_stats(self, reset=True):
+        avg, n = C.c_double(0), C.c_longlong(0)
+        name = C.create_string_buffer(128)
+        _check(lib().lsnFusionKernelStats(self._h, C.byref(avg), C.byref(n), name, len(name), 1 if reset else 0),
+               "lsnFusionKernelStats")
+        return {"kernel": name.value.decode(), "avg_ms": avg.value, "launches": n.value}
+
+    def close(self):
+        if self._h:
+            lib().lsnFusionDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_shards(device, n_shards, n_ticks, maps_per_shard, d_shards, shard_cap, d_shard_offsets, d_merged, merged_cap,
+                 d_merged_offsets, stream=0):
+    _check(lib().lsnMergeShards(int(device), int(n_shards), int(n_ticks), int(maps_per_shard), d_shards, int(shard_cap),
+                                d_shard_offsets, d_merged, int(merged_cap), d_merged_offsets, stream), "lsnMergeShards")
+
+
+NN_BRUTE, NN_GRID = 0, 1
+
+
+class IcpWorkspace:
+    """lsnIcp*: device-resident ICP for clouds up to (max_n1, max_n2)."""
+
+    def __init__(self, device, max_n1, max_n2):
+        require_gpu()
+        self.device = int(device)
+        self._h = lib().lsnIcpCreate(self.device, int(max_n1), int(max_n2))
+        if not self._h:
+            raise NativeUtilsError(f"lsnIcpCreate failed: {last_error()}")
+
+    def run(self, d_verts1, n1, d_verts2, n2, d_R, d_t, max_iter=10, nn_mode=NN_GRID, stream=0):
+        _check(lib().lsnIcpRun(self._h, d_verts1, int(n1), d_verts2, int(n2), d_R, d_t, int(max_iter), int(nn_mode), stream),
+               "lsnIcpRun")
+
+    def nearest(self, d_verts1, n1, d_verts2, n2, d_idx, d_dist2, nn_mode=NN_GRID, stream=0):
+        _check(lib().lsnIcpNearest(self._h, d_verts1, int(n1), d_verts2, int(n2), d_idx, d_dist2, int(nn_mode), stream),
+               "lsnIcpNearest")
+
+    def trace(self, max_iters, stream=0):
+        out = np.zeros((max(max_iters, 1), 16), dtype=np.float32)
+        n = lib().lsnIcpTrace(self._h, _ptr(out), int(max_iters), stream)
+        if n < 0:
+            raise NativeUtilsError(f"lsnIcpTrace failed: {last_error()}")
+        return out[:n]
+
+    def close(self):
+        if self._h:
+            lib().lsnIcpDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,101 @@
+/*
+ * lsn_oracle.h -- CPU restatement of LiveScan3D NativeUtils' fusion hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The shipped path (livescan3d_amd/) never links or calls it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - depth -> cloud path (orc_create_vertices / orc_generate_mesh_vertices):
+ *     PARITY UNPINNED.  The reference holds no golden vectors for it (ref.bin and
+ *     frames_info_*.bin are absent, src/NativeUtils/main.cpp:159-252) and
+ *     depthprocessing.cpp cannot be compiled here without stand-ins for
+ *     <windows.h> (include/NativeUtils/simpleimage.h:4) and for pgm/simpleimage.
+ *   - exact nearest neighbour (orc_nn_*): PINNED against the reference's vendored
+ *     nanoflann 1.1.9 + its PointCloud adaptor compiled from /root/reference
+ *     (oracle/_ref/ref_nn, fixtures in tests/golden/nn_*.npz).
+ *   - rest of ICP (matching, rejection, Kabsch): PARITY UNPINNED (needs OpenCV
+ *     3.2.0 core binaries, absent; the only reference ICP test is commented out,
+ *     src/NativeUtils/main.cpp:253-268).
+ *
+ * Every function cites the reference file:line it follows.  Paths are relative
+ * to the reference repository root.
+ */
+#ifndef LSN_ORACLE_H
+#define LSN_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* include/NativeUtils/depthprocessing.h:29-33 */
+typedef struct { unsigned char R, G, B, A; float X, Y, Z; } orc_vertex;
+
+/* createVertices, src/NativeUtils/depthprocessing.cpp:122-187 (+ RotatePoint :109-120)
+ * followed by the AoS repack of formMesh :1594-1608 for one sensor.
+ * intr7 = {cx,cy,fx,fy,r2,r4,r6}; wt12 = {t[3], R[3][3] row-major}; bounds6 = {minX,minY,minZ,maxX,maxY,maxZ}.
+ * out must hold w*h vertices.  vert_to_pix (nullable) receives vertices_to_depth_map,
+ * pix_to_vert (nullable, w*h ints) receives depth_to_vertices_map (-1 = none).
+ * Returns the number of vertices. */
+int orc_create_vertices(const uint16_t *depth, const uint8_t *rgb, int w, int h,
+                        const float *intr7, const float *wt12, const float *bounds6,
+                        orc_vertex *out, int *vert_to_pix, int *pix_to_vert);
+
+/* generateMeshFromDepthMaps with (bcolor_transfer,bgenerate_triangles)=(false,false), vertices only:
+ * src/NativeUtils/depthprocessing.cpp:1715-1792 -> generateVerticesFromDepthMaps :708-733 -> formMesh :1578-1608.
+ * depth_maps / depth_colors are the concatenated per-sensor buffers (:1646-1650 striding).
+ * out must hold sum(w*h) vertices; per_map_counts (nullable) gets n_maps counts.  Returns nVertices.
+ * n_threads > 1 runs one sensor per thread like the reference's std::thread fan-out (P1). */
+long orc_generate_mesh_vertices(int n_maps, const uint8_t *depth_maps, const uint8_t *depth_colors,
+                                const int *widths, const int *heights,
+                                const float *intr, const float *wt, const float *bounds6,
+                                orc_vertex *out, int *per_map_counts, int n_threads);
+
+/* generateVerticesFromDepthMap, src/NativeUtils/depthprocessing.cpp:1631-1657. */
+int orc_generate_vertices_from_depth_map(const uint8_t *depth_maps, const uint8_t *depth_colors,
+                                         const int *widths, const int *heights,
+                                         const float *intr, const float *wt, const float *bounds6,
+                                         int depth_map_index, orc_vertex *out);
+
+/* Exact 1-NN, squared L2 evaluated as (d0*d0 + d1*d1) + d2*d2 in f32
+ * (include/NativeUtils/icp.h:40-47; query loop src/NativeUtils/icp.cpp:18-32).
+ * Ties (equal f32 distance) resolve to the LOWEST target index -- nanoflann's tie
+ * order depends on its traversal; fixtures are tie-free.
+ * targets: n1*3 floats, queries: n2*3 floats. */
+void orc_nn_brute(const float *targets, int n1, const float *queries, int n2,
+                  int64_t *idx, float *dist, int n_threads);
+void orc_nn_kdtree(const float *targets, int n1, const float *queries, int n2,
+                   int64_t *idx, float *dist, int n_threads);
+
+/* Per-iteration trace of orc_icp (all optional, for piecewise tests). */
+typedef struct {
+    int   n_matched;      /* m  : one-to-one matches before rejection (icp.cpp:95-126) */
+    int   n_kept;         /* m' : after RejectOutlierMatches (icp.cpp:56-73)          */
+    float mean, stddev;   /* GetStandardDeviation (icp.cpp:34-54)                      */
+    float T[3];           /* tempT (icp.cpp:141)                                       */
+    float Rn[9];          /* tempR (icp.cpp:155-163), row-major                        */
+} orc_icp_iter;
+
+/* ICP, src/NativeUtils/icp.cpp:75-177.  verts2 is moved in place; R (9, row-major) and t (3)
+ * are in/out.  nn_mode 0 = brute force, 1 = kd-tree (same results).  trace (nullable) must
+ * hold maxIter entries.  Returns 1.0f like the reference (:86,:176). */
+float orc_icp(const float *verts1, float *verts2, int n1, int n2,
+              float *R, float *t, int maxIter, int nn_mode, int n_threads,
+              orc_icp_iter *trace);
+
+/* refineWorker_DoWork, LiveScanServer/MainWindowForm.cs:330-410: Gauss-Seidel ICP over sensors and
+ * the (aliasing) pose composition.  clouds[i] = n[i]*3 floats, moved in place.
+ * world_R (n_sensors*9) / world_t (n_sensors*3) are updated like worldTransforms[i]. */
+void orc_refine(int n_sensors, float **clouds, const int *n, int n_refine_iters, int n_icp_iters,
+                float *world_R, float *world_t, float *Rs_out, float *Ts_out,
+                int nn_mode, int n_threads);
+
+/* 3x3 SVD-based rotation: Rn = U*Vt (last column of U negated if det<0), icp.cpp:152-163. */
+void orc_kabsch_rotation(const float *M9, float *Rn9);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,129 @@
+"""GPU parity of the ICP path (exact NN, one-to-one matching, rejection, Kabsch) against the CPU oracle.
+
+Bars: nearest-neighbour indices and f32 squared distances bit-exact (integer/index work); XYZ after ICP, R and t
+within 1e-4 m / 1e-4 of the oracle (the north-star tolerance; GPU sums are in double, the reference's in f32)."""
+import numpy as np
+import pytest
+
+from livescan3d_amd import native, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # metres, BASELINE.json north_star: "XYZ within 1e-4 m after ICP"
+
+
+def _xyz(v):
+    return np.stack([v["X"], v["Y"], v["Z"]], axis=1).astype(np.float32)
+
+
+def _scene_clouds(orc, n, w, h, seed=4, perturb=True):
+    rig = synth.make_rig("scene", n, w, h, seed=seed, perturb=perturb)
+    v, counts = orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    xyz = _xyz(v)
+    edges = np.concatenate([[0], np.cumsum(counts)])
+    return [xyz[edges[i]:edges[i + 1]].copy() for i in range(n)]
+
+
+def _gpu_nn(targets, queries, mode):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(targets, np.float32)).cuda()
+    q = torch.from_numpy(np.ascontiguousarray(queries, np.float32)).cuda()
+    idx = torch.full((len(queries),), -7, dtype=torch.int32, device="cuda")
+    d2 = torch.zeros(len(queries), dtype=torch.float32, device="cuda")
+    ws = native.IcpWorkspace(0, len(targets), len(queries))
+    ws.nearest(t.data_ptr(), len(targets), q.data_ptr(), len(queries), idx.data_ptr(), d2.data_ptr(), mode,
+               int(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ws.close()
+    return idx.cpu().numpy().astype(np.int64), d2.cpu().numpy()
+
+
+@pytest.mark.parametrize("mode", [native.NN_BRUTE, native.NN_GRID])
+def test_nn_matches_oracle_bitexact(gpu, orc, mode):
+    rng = np.random.default_rng(5)
+    clouds = _scene_clouds(orc, 3, 256, 212)
+    cases = [
+        (clouds[1], clouds[0]),                                           # overlapping surfaces
+        (np.concatenate([clouds[1], clouds[2]]), clouds[0]),              # merged target
+        (rng.normal(size=(3000, 3)).astype(np.float32), rng.normal(size=(2000, 3)).astype(np.float32) * 3 + 1),  # volume + far outliers
+        (rng.uniform(-1, 1, size=(1, 3)).astype(np.float32), rng.uniform(-1, 1, size=(500, 3)).astype(np.float32)),  # single target
+        (np.repeat(rng.uniform(-1, 1, size=(50, 3)).astype(np.float32), 4, axis=0), rng.uniform(-1, 1, size=(300, 3)).astype(np.float32)),  # duplicated targets: ties -> lowest index
+        ((rng.uniform(0, 1, size=(4000, 3)) * [1, 1, 0]).astype(np.float32), rng.uniform(-0.5, 1.5, size=(1500, 3)).astype(np.float32)),  # flat cloud (zero extent in z)
+    ]
+    for k, (t, q) in enumerate(cases):
+        want_i, want_d = orc.nn(t, q, mode="brute", n_threads=8)
+        got_i, got_d = _gpu_nn(t, q, mode)
+        assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)), f"case {k}: squared distances differ"
+        assert np.array_equal(got_i, want_i), f"case {k}: indices differ at {np.flatnonzero(got_i != want_i)[:5]}"
+
+
+def test_nn_full_size(gpu, orc):
+    """config-2 sized clouds (2 x 512x424): grid NN == oracle kd-tree NN, bit-exact."""
+    clouds = _scene_clouds(orc, 2, 512, 424)
+    want_i, want_d = orc.nn(clouds[0], clouds[1], mode="kdtree", n_threads=8)
+    got_i, got_d = _gpu_nn(clouds[0], clouds[1], native.NN_GRID)
+    assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
+    assert np.array_equal(got_i, want_i)
+
+
+@pytest.mark.parametrize("w,h,iters", [(128, 96, 10), (512, 424, 10)])
+def test_icp_export_matches_oracle(gpu, orc, w, h, iters):
+    clouds = _scene_clouds(orc, 2, w, h)
+    got_v, got_R, got_t = native.icp(clouds[0], clouds[1], max_iter=iters)
+    ref_v, ref_R, ref_t = orc.icp(clouds[0], clouds[1], max_iter=iters, n_threads=8)
+    assert np.abs(got_v - ref_v).max() <= TOL
+    assert np.abs(got_R - ref_R).max() <= TOL and np.abs(got_t - ref_t).max() <= TOL
+    # the call moved the cloud and is consistent with its own R, t: v_out = (v_in + t) R   
+    assert np.abs(got_v - clouds[1]).max() > 1e-3
+    recon = (clouds[1].astype(np.float64) + got_t.astype(np.float64)) @ got_R.astype(np.float64)
+    assert np.abs(recon - got_v).max() <= 5e-5
+    assert abs(np.linalg.det(got_R.astype(np.float64)) - 1.0) < 1e-5
+    assert np.abs(got_R.astype(np.float64) @ got_R.astype(np.float64).T - np.eye(3)).max() < 1e-5
+
+
+def test_icp_trace_and_modes_agree(gpu, orc):
+    """Per-iteration match counts / T / Rn against the oracle's trace; brute-force and grid NN give identical runs."""
+    import torch
+    clouds = _scene_clouds(orc, 2, 192, 160)
+    ref_v, ref_R, ref_t, tr = orc.icp(clouds[0], clouds[1], max_iter=6, trace=True, n_threads=8)
+    outs = []
+    for mode in (native.NN_BRUTE, native.NN_GRID):
+        v1 = torch.from_numpy(clouds[0]).cuda()
+        v2 = torch.from_numpy(clouds[1].copy()).cuda()
+        Rt = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device="cuda")
+        ws = native.IcpWorkspace(0, len(clouds[0]), len(clouds[1]))
+        ws.run(v1.data_ptr(), len(clouds[0]), v2.data_ptr(), len(clouds[1]), Rt.data_ptr(), Rt.data_ptr() + 36, 6, mode,
+               int(torch.cuda.current_stream().cuda_stream))
+        g = ws.trace(6, int(torch.cuda.current_stream().cuda_stream))
+        outs.append((v2.cpu().numpy(), Rt.cpu().numpy(), g))
+        ws.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    g = outs[1][2]
+    assert len(g) == 6
+    for it in range(6):
+        assert abs(int(g[it, 0]) - int(tr[it]["n_matched"])) <= 2
+        assert abs(int(g[it, 1]) - int(tr[it]["n_kept"])) <= max(3, int(0.001 * tr[it]["n_kept"]))
+        assert np.abs(g[it, 4:7] - tr[it]["T"]).max() <= 2e-5
+        assert np.abs(g[it, 7:16] - tr[it]["Rn"]).max() <= 2e-5
+    assert np.abs(outs[1][0] - ref_v).max() <= TOL
+
+
+def test_icp_edge_cases(gpu, orc):
+    rng = np.random.default_rng(9)
+    a = rng.uniform(-1, 1, size=(400, 3)).astype(np.float32)
+    # identical clouds: already aligned, stays put
+    v, R, t = native.icp(a, a.copy(), max_iter=3)
+    assert np.abs(v - a).max() <= 1e-6 and np.abs(R - np.eye(3)).max() <= 1e-6 and np.abs(t).max() <= 1e-6
+    # tiny clouds
+    for n1, n2 in [(1, 1), (1, 7), (5, 1), (2, 2)]:
+        t1 = rng.uniform(-1, 1, size=(n1, 3)).astype(np.float32)
+        t2 = rng.uniform(-1, 1, size=(n2, 3)).astype(np.float32)
+        gv, gR, gt = native.icp(t1, t2, max_iter=4)
+        rv, rR, rt = orc.icp(t1, t2, max_iter=4, nn_mode="brute")
+        assert np.allclose(gv, rv, atol=TOL, equal_nan=True) and np.allclose(gR, rR, atol=TOL, equal_nan=True) and np.allclose(gt, rt, atol=TOL, equal_nan=True)
+    # empty clouds: untouched, error reported, returns 1.0 (callers guard with nClientCount >= 2, MainWindowForm.cs:469-473)
+    import ctypes as C
+    L = native.lib()
+    R = np.eye(3, dtype=np.float32).ravel(); tt = np.zeros(3, np.float32)
+    ret = L.ICP(a.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), 0, 10, R.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), 10)
+    assert ret == 1.0 and native.last_error() != "" and np.array_equal(R, np.eye(3, dtype=np.float32).ravel())
