@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- fused frames/s of the LiveScan3D fusion hot path on MI355X (+ ICP iteration ms).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" fuses `--ticks` ticks of `--sensors` synthetic 512x424 Kinect streams (depth u16 + RGB8, resident in HBM
+before the timed region) into `--ticks` merged coloured clouds: unproject + R(p+t) + AABB crop + raster-order
+compaction (+ for N > 1 the RCCL all-gather of the per-GPU sensor shards and the merged-cloud assembly).
+value = merged clouds per second = ticks * K / wall time (max over ranks).  Sensors are sharded in contiguous blocks
+over the ranks (fixed total work: "strong" scaling).  Prints ONE JSON line on rank 0.
+
+Extra objects in the line: "roofline" (dominant kernel: algorithmic bytes 2P + 19V per sensor-frame / HIP-event
+kernel time vs 8 TB/s), "cpu_baseline" (the CPU oracle = port of the reference path, timed on this host's cores on
+a bounded sample, rank 0 at N = 1 only), "icp" (configs[1]: 2 sensors x 512x424, ICP(maxIter=10) ms per iteration).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sensors", type=int, default=8, help="streams per tick (north-star target: 8 x 512x424)")
+    ap.add_argument("--ticks", type=int, default=64, help="ticks fused per step (one launch sequence)")
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--height", type=int, default=424)
+    ap.add_argument("--mode", type=int, default=int(os.environ.get("LSN_FUSE_MODE", "0")), help="0 two-pass, 1 look-back")
+    ap.add_argument("--no-icp", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--icp-reps", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from livescan3d_amd import native, synth
+    from livescan3d_amd.fusion import DeviceFusion
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: libNativeUtils has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    native.require_gpu()
+
+    S, B, w, h = args.sensors, args.ticks, args.width, args.height
+    from livescan3d_amd.sharding import MergedCloudExchange, sensor_block
+    try:
+        s0, s1 = sensor_block(S, world, rank)   # contiguous sensor block: rank order = formMesh sensor order
+    except ValueError as e:
+        raise SystemExit(str(e))
+    S_loc = s1 - s0
+    P = w * h
+    bounds = synth.CROP_BOUNDS
+    intr_all = np.concatenate([synth.kinect_intrinsics(w, h)] * S)
+    wt_all = np.concatenate([synth.pack_pose(*synth.ring_pose(s, S)) for s in range(S)])
+
+    # ---- synthetic inputs, resident in HBM -------------------------------------------------------------------
+    depth, rgb = synth.noise_frames_torch(dev, 1, B, S_loc, w, h, sensor0=s0)
+    depth = depth.view(B, S_loc * P)
+    rgb = rgb.view(B, S_loc * P * 3)
+
+    fus = DeviceFusion(B, [w] * S_loc, [h] * S_loc, device=local_rank, mode=args.mode)
+    fus.set_params(intr_all[7 * s0:7 * (s0 + S_loc)], wt_all[12 * s0:12 * (s0 + S_loc)], bounds)
+    stream = int(torch.cuda.current_stream().cuda_stream)
+
+    xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev) if world > 1 else None
+
+    def step():
+        fus.run(depth, rgb)
+        if xch is not None:
+            # the exchange step: all-gather of the per-GPU sensor shards over xGMI + local packing into one
+            # contiguous cloud per tick, so that every GPU holds the merged cloud (sensor order = rank order)
+            xch.exchange(fus.vertices, fus.offsets)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    fus.plan.profile(True)
+    fus.plan.kernel_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    kstats = fus.plan.kernel_stats(reset=True)
+    fus.plan.profile(False)
+
+    # algorithmic bytes of one launch of the dominant kernel on this rank: sum over its sensor-frames of 2P + 19V
+    off = fus.offsets.cpu().numpy().astype(np.int64)
+    V_local = int(off[:, -1].sum())
+    alg_bytes = 2 * P * S_loc * B + 19 * V_local
+    if world > 1:
+        V_total = int(xch.merged_off[:, -1].sum().item())
+    else:
+        V_total = V_local
+    if args.mode == 1 and fus.plan.lookback_failed(stream):
+        raise SystemExit("look-back compaction gave up on a bounded spin: results invalid")
+
+    result = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        achieved = alg_bytes / (kstats["avg_ms"] * 1e-3) / 1e9 if kstats["avg_ms"] > 0 else 0.0
+        result = {
+            "metric": "fused frames/s (N x 512x424 depth -> merged cloud)",
+            "value": B * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{S} synthetic {w}x{h} Kinect streams per tick (BASELINE configs[2]/[3], the north-star target shape), "
+                            f"{B} ticks fused per step; ICP: configs[1] (2 sensors x 512x424, 10 iterations) reported under 'icp'",
+                "sensors": S, "width": w, "height": h, "ticks_per_step": B,
+                "sensors_per_gpu": S_loc,
+                "survivor_fraction": V_total / float(B * S * P),
+                "compaction": "two-pass" if args.mode == 0 else "look-back",
+                "parallelism": f"sensor-shard{world}" + ("+allgather" if world > 1 else ""),
+                "bounds": [float(x) for x in bounds],
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": kstats["kernel"],
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_avg_ms": kstats["avg_ms"],
+                "kernel_launches": kstats["launches"],
+            },
+        }
+
+    # ---- drop-in export on host buffers (PCIe-inclusive; never `value`) -----------------------------------------
+    if rank == 0 and not args.no_host_path:
+        rig = synth.make_rig("noise", S, w, h, seed=1, bounds=bounds)
+        for _ in range(2):
+            native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 2.0:
+            native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+            n += 1
+        result["host_path_frames_per_s"] = n / (time.perf_counter() - t0)
+
+    # ---- ICP, configs[1] ------------------------------------------------------------------------------------------
+    if rank == 0 and not args.no_icp:
+        result["icp"] = bench_icp(args, torch, native, synth, dev, stream, with_cpu=(world == 1 and not args.no_cpu))
+
+    # ---- CPU baseline (rank 0, N = 1 only) ------------------------------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(args, synth, S, w, h, bounds)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def bench_icp(args, torch, native, synth, dev, stream, with_cpu):
+    """configs[1]: 2 sensors x 512x424 'scene' frames, sensor 1 mis-calibrated; ICP(maxIter=10), device resident."""
+    from livescan3d_amd.fusion import DeviceFusion, upload_rig
+    w, h, iters = 512, 424, 10
+    rig = synth.make_rig("scene", 2, w, h, seed=4, perturb=True)
+    fus = DeviceFusion(1, rig.widths, rig.heights, device=dev.index)
+    fus.set_params(rig.intr, rig.wt, rig.bounds)
+    d, c = upload_rig(rig, 1, dev.index)
+    v, off = fus.run(d, c)
+    torch.cuda.synchronize()
+    off = off[0].cpu().numpy()
+    xyz = v[0, :int(off[2]), 4:16].contiguous().view(torch.float32).view(-1, 3)
+    tgt = xyz[:int(off[1])].contiguous()
+    src0 = xyz[int(off[1]):].contiguous()
+    n1, n2 = tgt.shape[0], src0.shape[0]
+    ws = native.IcpWorkspace(dev.index, n1, n2)
+    out = {"workload": "configs[1]: 2 sensors x 512x424 scene frames, ICP(maxIter=10), device resident", "n1": n1, "n2": n2}
+    for name, mode in (("grid", native.NN_GRID), ("brute", native.NN_BRUTE)):
+        reps = args.icp_reps if mode == native.NN_GRID else 1
+        times = []
+        for r in range(reps + 1):
+            src = src0.clone()
+            Rt = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            ws.run(tgt.data_ptr(), n1, src.data_ptr(), n2, Rt.data_ptr(), Rt.data_ptr() + 36, iters, mode, stream)
+            e1.record()
+            torch.cuda.synchronize()
+            if r > 0 or reps == 1:
+                times.append(e0.elapsed_time(e1))
+        out[f"iter_ms_{name}"] = min(times) / iters
+    out["iter_ms"] = out["iter_ms_grid"]
+    if with_cpu:
+        from oracle import orc
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        orc.icp(tgt.cpu().numpy(), src0.cpu().numpy(), max_iter=2, nn_mode="kdtree", n_threads=cores)
+        out["cpu_iter_ms"] = 1e3 * (time.perf_counter() - t0) / 2
+        out["cpu_cores"] = cores
+        out["cpu_kind"] = "port (oracle kd-tree NN with OpenMP queries like icp.cpp:25-31, 2 iterations timed)"
+    ws.close()
+    return out
+
+
+def cpu_baseline(args, synth, S, w, h, bounds):
+    """The CPU oracle (port of createVertices/formMesh, one thread per sensor like the reference's std::thread fan-out)
+    on the same tick shape, for about --cpu-seconds of wall time."""
+    from oracle import orc
+    cores = os.cpu_count() or 1
+    threads = min(S, cores)
+    rig = synth.make_rig("noise", S, w, h, seed=1, bounds=bounds)
+    orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, n_threads=threads)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, n_threads=threads)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} merge calls of {S} x {w}x{h} (same generator, tick 0) in {dt:.1f} s, {threads} threads (one per sensor), host has {cores} cores"}
+
+
+if __name__ == "__main__":
+    main()

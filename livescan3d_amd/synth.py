@@ -44,9 +44,8 @@ def noise_frame(seed, tick, sensor, w=512, h=424):
     return depth, rgb
 
 
-def noise_frames_torch(device, seed, n_ticks, n_sensors, w=512, h=424):
-    """Same generator as noise_frame, evaluated with torch int64 ops on `device`.
-    Returns (depth int16-viewed-u16 tensor [n_ticks, n_sensors, h, w] as torch.int16 bit pattern... see below).
+def noise_frames_torch(device, seed, n_ticks, n_sensors, w=512, h=424, sensor0=0, tick0=0):
+    """Same generator as noise_frame (ticks tick0.., sensors sensor0..), evaluated with torch int64 ops on `device`.
 
     torch has no uint16/uint64 arithmetic, so the hash runs in wrapping int64 with logical shifts emulated;
     depth is returned as torch.int16 holding the u16 bit pattern (values < 4500 so they are non-negative),
@@ -73,7 +72,7 @@ def noise_frames_torch(device, seed, n_ticks, n_sensors, w=512, h=424):
     yx = (y << 14) ^ x
     for t in range(n_ticks):
         for s in range(n_sensors):
-            key = yx ^ c64((seed << 52) ^ (t << 36) ^ (s << 28))
+            key = yx ^ c64((seed << 52) ^ ((t + tick0) << 36) ^ ((s + sensor0) << 28))
             hsh = sm64(key)
             k = lsr(hsh, 11)
             d = 500 + (k >> 4) % 4000
@@ -205,9 +204,7 @@ def make_rig(kind, n_sensors, w=512, h=424, seed=1, tick=0, bounds=None, perturb
     return Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), bounds)
 
 
-def fnv1a64(data):
-    """FNV-1a 64-bit of a bytes-like (used to pin large fixtures by hash)."""
-    hsh = 0xCBF29CE484222325
-    for chunk in memoryview(np.ascontiguousarray(data).view(np.uint8).ravel()).tobytes():
-        hsh = ((hsh ^ chunk) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
-    return hsh
+def digest(data):
+    """sha256 hex digest of an array's bytes (pins large fixtures by hash)."""
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(data).view(np.uint8).tobytes()).hexdigest()

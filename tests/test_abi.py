@@ -1,0 +1,73 @@
+"""The C-ABI library: it loads without a GPU, exports every symbol include/NativeUtils.h declares, keeps the
+reference's struct layouts, and refuses to compute without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from livescan3d_amd import native, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "NativeUtils.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = native.lib()
+    names = _declared_functions()
+    assert {"generateMeshFromDepthMaps", "generateVerticesFromDepthMap", "createMesh", "deleteMesh", "ICP"} <= set(names)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(native.EXPORTS) == set(names)
+
+
+def test_struct_layouts_match_the_reference():
+    assert native.VERTEX_DTYPE.itemsize == 16                        # Utils.cs: SizeInBytes = 16; depthprocessing.h:29-33
+    assert [native.VERTEX_DTYPE.fields[k][1] for k in "RGBAXYZ"] == [0, 1, 2, 3, 4, 8, 12]
+    assert C.sizeof(native.Mesh) == 32                               # depthprocessing.h:42-48 on LP64
+    assert native.Mesh.vertices.offset == 8 and native.Mesh.nTriangles.offset == 16 and native.Mesh.triangles.offset == 24
+
+
+def test_create_and_delete_mesh_without_gpu():
+    L = native.lib()
+    m = L.createMesh()
+    assert m and m.contents.nVertices == 0 and m.contents.nTriangles == 0 and not m.contents.vertices and not m.contents.triangles
+    L.deleteMesh(m)       # frees nothing, must not crash; the struct itself stays with the caller like in the reference
+    L.deleteMesh(m)
+
+
+@pytest.mark.skipif(native.device_count() > 0, reason="only meaningful on a machine without a GPU")
+def test_compute_fails_loudly_without_gpu():
+    rig = synth.make_rig("noise", 1, 16, 8)
+    with pytest.raises(native.NativeUtilsError):
+        native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    with pytest.raises(native.NativeUtilsError):
+        native.icp(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32))
+    with pytest.raises(native.NativeUtilsError):
+        native.FusionPlan(0, 1, [16], [8])
+    # the raw export leaves an empty mesh and an error message instead of throwing across the ABI
+    L = native.lib()
+    mesh = native.Mesh()
+    w = np.array([16], np.int32); h = np.array([8], np.int32)
+    L.generateMeshFromDepthMaps(1, rig.depth_maps.ctypes.data_as(C.c_void_p), rig.depth_colors.ctypes.data_as(C.c_void_p),
+                                w.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), rig.intr.ctypes.data_as(C.c_void_p),
+                                rig.wt.ctypes.data_as(C.c_void_p), C.byref(mesh), False, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, False)
+    assert mesh.nVertices == 0 and mesh.nTriangles == 0 and mesh.triangles
+    assert "no HIP device" in native.last_error()
+    L.deleteMesh(C.byref(mesh))
+    assert not mesh.triangles and not mesh.vertices
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under livescan3d_amd/ may import, link or call it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "livescan3d_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "lsn_oracle" not in text and "from oracle" not in text and "import oracle" not in text and "orc_" not in text, f
