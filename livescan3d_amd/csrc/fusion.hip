@@ -39,6 +39,8 @@ struct FrameDesc {
     int w, h, npix, tile_start;  // tile_start: first tile of this frame inside its tick
     long long depth_off;         // u16 elements from the tick's depth base
     long long rgb_off;           // bytes from the tick's colour base
+    int xtab_off, ytab_off;      // this sensor's rows of the unprojection tables (floats)
+    int pad0, pad1;
 };
 
 struct SensorParams {  // 16 floats, wave-uniform -> scalar loads
@@ -51,14 +53,16 @@ struct FuseArgs {
     const FrameDesc *frames;
     const unsigned short *tile_frame;  // tile (within tick) -> frame
     const SensorParams *params;
+    const float *xtab;  // [(x - cx) / fx] per sensor column
+    const float *ytab;  // [(cy - y) / fy] per sensor row
     const unsigned short *depth;
     const unsigned char *rgb;
     uint4 *out;
     int *tile_counts;                // mode 0: [n_ticks * tiles_per_tick]
     unsigned long long *tile_state;  // mode 1: [n_ticks * tiles_per_tick] {flag:2 | value}
-    unsigned int *ticket;            // mode 1: dynamic tile id
+    unsigned int *ticket;            // mode 1: per-tick tile tickets, 32 words apart
     int *offsets;                    // [n_ticks][n_frames + 1]
-    int *error_flag;                 // mode 1: set when a bounded spin gives up
+    int *error_flag;                 // mode 1: set when a bounded spin gives up (sticky until read)
     int n_frames;
     int tiles_per_tick;
     int n_tiles_total;
@@ -68,24 +72,53 @@ struct FuseArgs {
     float minX, minY, minZ, maxX, maxY, maxZ;
 };
 
-// createVertices' per-pixel arithmetic (depthprocessing.cpp:149-163), one rounding per operation.
-// yfac = (cy - float(y)) / fy is shared by the 8 pixels of a lane when they sit in one row.
-__device__ __forceinline__ bool unproject(float d, float xf, float yfac, const SensorParams &P, const FuseArgs &a,
-                                          float &ox, float &oy, float &oz)
+// Z = float(d) / 1000.0f (depthprocessing.cpp:149-150) without the ~13-instruction IEEE division: with
+// r = fl32(1/1000), q0 = d*r, e = fma(-q0, 1000, d), q = fma(e, r, q0) is the correctly rounded quotient for EVERY
+// u16 d -- proven exhaustively with exact rational arithmetic in tests/test_fast_division.py (65535 cases).
+__device__ __forceinline__ float depth_to_metres(float d)
 {
-    float Z = d / 1000.0f;
-    float X = (xf - P.cx) / P.fx;
-    float Y = yfac;
-    X = X * Z;
-    Y = Y * Z;
+    const float r = 0x1.0624dep-10f;  // 0x3a83126f = fl32(0.001)
+    const float q0 = d * r;
+    const float e = __builtin_fmaf(-q0, 1000.0f, d);
+    return __builtin_fmaf(e, r, q0);
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Z = float(d) / 1000.0f for two pixels (see depth_to_metres): v_pk_mul_f32 + 2 v_pk_fma_f32.
+__device__ __forceinline__ f2 depth_to_metres2(f2 d)
+{
+    const f2 r = {0x1.0624dep-10f, 0x1.0624dep-10f};
+    const f2 k = {1000.0f, 1000.0f};
+    const f2 q0 = d * r;
+    const f2 e = __builtin_elementwise_fma(-q0, k, d);
+    return __builtin_elementwise_fma(e, r, q0);
+}
+
+// createVertices' per-pixel arithmetic (depthprocessing.cpp:149-163) on TWO pixels at once, one rounding per
+// operation (contraction is off, so a*b+c stays a packed multiply and a packed add: v_pk_mul_f32 / v_pk_add_f32 do two
+// f32 lanes' worth per issue slot, which halves the VALU time of this VALU-heavy kernel).
+// xfac = (float(x) - cx) / fx and yfac = (cy - float(y)) / fy (:151-152) depend on the column / row only; they come
+// from per-sensor tables filled on the device with the same IEEE operations (table_kernel), so the per-pixel work
+// has no division left.
+__device__ __forceinline__ void unproject2(f2 d, f2 xfac, f2 yfac, const SensorParams &P, f2 &ox, f2 &oy, f2 &oz)
+{
+    f2 Z = depth_to_metres2(d);
+    f2 X = xfac * Z;
+    f2 Y = yfac * Z;
     X = X + P.t0;
     Y = Y + P.t1;
     Z = Z + P.t2;
     ox = X * P.r00 + Y * P.r01 + Z * P.r02;
     oy = X * P.r10 + Y * P.r11 + Z * P.r12;
     oz = X * P.r20 + Y * P.r21 + Z * P.r22;
-    // same comparisons as :162 so a NaN coordinate is kept exactly like the reference keeps it
-    bool rejected = ox < a.minX || ox > a.maxX || oy < a.minY || oy > a.maxY || oz < a.minZ || oz > a.maxZ;
+}
+
+// The inclusive AABB test with the reference's own comparisons (:162), so that a NaN coordinate is kept exactly like
+// the reference keeps it (non-short-circuit '|': six compares and lane-mask ORs, no divergent branches).
+__device__ __forceinline__ bool inside_box(float ox, float oy, float oz, const FuseArgs &a)
+{
+    const bool rejected = (ox < a.minX) | (ox > a.maxX) | (oy < a.minY) | (oy > a.maxY) | (oz < a.minZ) | (oz > a.maxZ);
     return !rejected;
 }
 
@@ -121,7 +154,6 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     // the 16-B LDS writes of neighbouring lanes on different bank groups (stride 128 B would be an 8-way conflict).
     __shared__ uint4 stage[kWrite ? (kTile + kTile / 8) : 1];
     __shared__ int s_wave_tot[4];
-    __shared__ int s_wave_pre[4];
     __shared__ int s_tile;
     __shared__ int s_base;
 
@@ -129,14 +161,24 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     const int wave = threadIdx.x >> 6;
 
     int gtile = blockIdx.x;
+    int tick, tile;
     if (MODE == 2) {
-        // tiles are handed out in launch order so that every tile a workgroup looks back at is already running
-        if (threadIdx.x == 0) s_tile = (int)atomicAdd(a.ticket, 1u);
+        // Every tick is its own compaction domain with its own ticket counter (128 B apart: one returning atomic
+        // on a single word saturates near 88 tickets/us, far below the tile rate).  Workgroup b serves tick
+        // b % n_ticks and draws that tick's next tile: the tiles it will look back at were drawn earlier, so they
+        // are already running -- no deadlock whatever the dispatch order -- and because neighbouring workgroups
+        // serve different ticks, a tile's predecessors are n_ticks workgroups older each: long enough to have
+        // published their prefix, so a look-back usually ends inside its first 64-wide window.
+        const int n_ticks = a.n_tiles_total / a.tiles_per_tick;
+        tick = blockIdx.x % n_ticks;
+        if (threadIdx.x == 0) s_tile = (int)atomicAdd(a.ticket + 32 * tick, 1u);
         __syncthreads();
-        gtile = s_tile;
+        tile = s_tile;
+        gtile = tick * a.tiles_per_tick + tile;
+    } else {
+        tick = gtile / a.tiles_per_tick;
+        tile = gtile - tick * a.tiles_per_tick;
     }
-    const int tick = gtile / a.tiles_per_tick;
-    const int tile = gtile - tick * a.tiles_per_tick;
     const int f = a.tile_frame[tile];
     const FrameDesc fd = a.frames[f];
     const SensorParams P = a.params[f];
@@ -177,44 +219,68 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     }
 
     // ---- per-pixel arithmetic ------------------------------------------------------------------------------
-    int y = p0 / fd.w;
-    int x = p0 - y * fd.w;
-    float yfac = (P.cy - (float)y) / P.fy;
-    float vx[kPxPerLane], vy[kPxPerLane], vz[kPxPerLane];
-    unsigned int mask = 0;
+    const bool in_frame = p0 < fd.npix;
+    int y = in_frame ? p0 / fd.w : 0;
+    int x = in_frame ? p0 - y * fd.w : 0;
+    const float *xt = a.xtab + fd.xtab_off;
+    const float *yt = a.ytab + fd.ytab_off;
+    float yfac = yt[y];
+    float xf[kPxPerLane], yf[kPxPerLane];
+    if (VEC) {
+        // w % 8 == 0: the lane's 8 pixels share a row and their columns are 8 consecutive, 32-B aligned table entries
+        const float4 x0 = *reinterpret_cast<const float4 *>(xt + x);
+        const float4 x1 = *reinterpret_cast<const float4 *>(xt + x + 4);
+        xf[0] = x0.x; xf[1] = x0.y; xf[2] = x0.z; xf[3] = x0.w;
+        xf[4] = x1.x; xf[5] = x1.y; xf[6] = x1.z; xf[7] = x1.w;
 #pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) {
-        unsigned int d = (dw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-        bool keep = false;
-        if (d != 0) keep = unproject((float)d, (float)x, yfac, P, a, vx[k], vy[k], vz[k]);
-        mask |= (keep ? 1u : 0u) << k;
-        if (!VEC) {
+        for (int k = 0; k < kPxPerLane; k++) yf[k] = yfac;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            xf[k] = xt[x];
+            yf[k] = yfac;
             // rows may end inside a lane's 8 pixels when w % 8 != 0
             x++;
             if (x == fd.w) {
                 x = 0;
-                y++;
-                yfac = (P.cy - (float)y) / P.fy;
+                y = y + 1 < fd.h ? y + 1 : y;
+                yfac = yt[y];
             }
-        } else {
-            x++;
         }
+    }
+    uint4 vert[kPxPerLane];  // {RGBA, X, Y, Z} assembled in place so the 16-B LDS store needs no register shuffling
+    bool keep[kPxPerLane];   // wave-wide predicates (SGPR pairs); no per-lane bit mask is materialised
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k += 2) {
+        const unsigned int d0 = dw[k >> 1] & 0xFFFFu, d1 = dw[k >> 1] >> 16;
+        // branch-free: a zero depth (invalid pixel, :144, or a lane past the frame end) is computed and then dropped
+        f2 ox, oy, oz;
+        unproject2(f2{(float)d0, (float)d1}, f2{xf[k], xf[k + 1]}, f2{yf[k], yf[k + 1]}, P, ox, oy, oz);
+        keep[k] = inside_box(ox.x, oy.x, oz.x, a) && d0 != 0;
+        keep[k + 1] = inside_box(ox.y, oy.y, oz.y, a) && d1 != 0;
+        if (kWrite) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int b = 3 * (k + j);
+                const unsigned int lo = cw[b >> 2];
+                const unsigned int hi = cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
+                vert[k + j].x = (__funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu) | 0xFF000000u;  // A = 255 (:1601)
+                vert[k + j].y = __float_as_uint(j ? ox.y : ox.x);
+                vert[k + j].z = __float_as_uint(j ? oy.y : oy.x);
+                vert[k + j].w = __float_as_uint(j ? oz.y : oz.x);
+            }
+        }
+        cnt += (keep[k] ? 1 : 0) + (keep[k + 1] ? 1 : 0);
     }
 
     // ---- rank inside the tile --------------------------------------------------------------------------------
-    const int cnt = __popc(mask);
     const int incl = wave_inclusive_scan(cnt, lane);
     if (lane == 63) s_wave_tot[wave] = incl;
 
     int base = 0;
-    if (MODE == 1) {
-        // offset of this tile inside its tick = counts of the tiles before it (<= a few hundred ints, L2 resident)
-        const int *tc = a.tile_counts + (long long)tick * a.tiles_per_tick;
-        int part = 0;
-        for (int i = threadIdx.x; i < tile; i += kThreads) part += tc[i];
-        part = wave_sum(part);
-        if (lane == 0) s_wave_pre[wave] = part;
-    }
+    // mode 1: scan_kernel has turned the tile counts into exclusive prefixes inside each tick (one scalar load)
+    if (MODE == 1) base = a.tile_counts[(long long)tick * a.tiles_per_tick + tile];
     __syncthreads();
     int wave_off = 0, tile_tot = 0;
 #pragma unroll
@@ -223,10 +289,9 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
         if (i < wave) wave_off += v;
         tile_tot += v;
     }
-    if (MODE == 1) base = s_wave_pre[0] + s_wave_pre[1] + s_wave_pre[2] + s_wave_pre[3];
 
     if (MODE == 0) {
-        if (threadIdx.x == 0) a.tile_counts[gtile] = tile_tot;
+        if (threadIdx.x == 0) a.tile_counts[(long long)tick * a.tiles_per_tick + tile] = tile_tot;
         return;
     }
 
@@ -234,12 +299,8 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     int r = wave_off + incl - cnt;
 #pragma unroll
     for (int k = 0; k < kPxPerLane; k++) {
-        if (mask & (1u << k)) {
-            const int b = 3 * k;
-            unsigned int lo = cw[b >> 2];
-            unsigned int hi = cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
-            unsigned int rgba = (__funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu) | 0xFF000000u;  // A = 255 (:1601)
-            stage[r + (r >> 3)] = make_uint4(rgba, __float_as_uint(vx[k]), __float_as_uint(vy[k]), __float_as_uint(vz[k]));
+        if (keep[k]) {
+            stage[r + (r >> 3)] = vert[k];
             r++;
         }
     }
@@ -298,10 +359,55 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     uint4 *dst = a.out + tick * a.tick_vert_stride + base;
     for (int i = threadIdx.x; i < tile_tot; i += kThreads) dst[i] = stage[i + (i >> 3)];
 
-    if (threadIdx.x == 0) {
+    if (MODE == 2 && threadIdx.x == 0) {
         int *off = a.offsets + (long long)tick * (a.n_frames + 1);
         if (tile == fd.tile_start) off[f] = base;
         if (tile == a.tiles_per_tick - 1) off[a.n_frames] = base + tile_tot;
+    }
+}
+
+// Mode 0, between the count and the write launch: one workgroup per tick turns that tick's tile counts into exclusive
+// prefixes in place and fills the per-sensor offset table (offsets[tick][f] = first vertex of sensor f, [n_frames] = total).
+__global__ __launch_bounds__(kThreads) void scan_kernel(int *tile_counts, int tiles_per_tick, const FrameDesc *frames, int n_frames,
+                                                        int *offsets)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_carry;
+    const int tick = blockIdx.x;
+    int *tc = tile_counts + (long long)tick * tiles_per_tick;
+    int *off = offsets + (long long)tick * (n_frames + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < tiles_per_tick; c0 += kThreads) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < tiles_per_tick ? tc[i] : 0;
+        const int incl = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int pre = s_carry;
+        for (int w = 0; w < wave; w++) pre += s_wave[w];
+        if (i < tiles_per_tick) tc[i] = pre + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kThreads - 1) s_carry = pre + incl;
+        __syncthreads();
+    }
+    // frames are few: thread f looks up the prefix at its first tile (written above by this workgroup)
+    for (int f = threadIdx.x; f <= n_frames; f += kThreads) off[f] = f < n_frames ? tc[frames[f].tile_start] : s_carry;
+}
+
+// Fills a sensor's unprojection tables with the reference's own operations (depthprocessing.cpp:151-152):
+// xtab[x] = (float(x) - cx) / fx, ytab[y] = (cy - float(y)) / fy -- IEEE subtraction and correctly rounded division.
+__global__ __launch_bounds__(kThreads) void table_kernel(const FrameDesc *frames, const SensorParams *params, int n_frames, float *xtab,
+                                                         float *ytab)
+{
+    const int f = blockIdx.y;
+    if (f >= n_frames) return;
+    const FrameDesc fd = frames[f];
+    const SensorParams P = params[f];
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < fd.w + fd.h; i += gridDim.x * kThreads) {
+        if (i < fd.w) xtab[fd.xtab_off + i] = ((float)i - P.cx) / P.fx;
+        else ytab[fd.ytab_off + (i - fd.w)] = (P.cy - (float)(i - fd.w)) / P.fy;
     }
 }
 
@@ -353,7 +459,8 @@ struct LsnFusion {
     bool params_set = false;
     int mode = 0;
     float bounds[6] = {0, 0, 0, 0, 0, 0};
-    lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: ticket + error flag
+    lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: error flag (word 0) + tickets
+    lsn::DevBuf xtab, ytab;
     // dominant-kernel timing
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -383,7 +490,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
     std::vector<FrameDesc> fr(n_maps);
     std::vector<unsigned short> tf;
     long long doff = 0, coff = 0;
-    int tiles = 0;
+    int tiles = 0, xoff = 0, yoff = 0;
     bool vec = true;
     for (int i = 0; i < n_maps; i++) {
         if (widths[i] <= 0 || heights[i] <= 0 || (long long)widths[i] * heights[i] > (1ll << 30)) {
@@ -400,6 +507,11 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
         fr[i].tile_start = tiles;
         fr[i].depth_off = doff;
         fr[i].rgb_off = coff;
+        fr[i].xtab_off = xoff;
+        fr[i].ytab_off = yoff;
+        fr[i].pad0 = fr[i].pad1 = 0;
+        xoff += (widths[i] + 7) & ~7;  // keeps every sensor's row 32-B aligned for the float4 loads
+        yoff += heights[i];
         const int nt = (npix + kTile - 1) / kTile;
         for (int t = 0; t < nt; t++) tf.push_back((unsigned short)i);
         tiles += nt;
@@ -426,7 +538,13 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
     const size_t n_tiles_total = (size_t)tiles * n_ticks;
     if (p->frames.reserve(sizeof(FrameDesc) * n_maps) || p->tile_frame.reserve(sizeof(unsigned short) * tf.size()) ||
         p->params.reserve(sizeof(SensorParams) * n_maps) || p->tile_counts.reserve(sizeof(int) * n_tiles_total) ||
-        p->tile_state.reserve(sizeof(unsigned long long) * n_tiles_total) || p->misc.reserve(256)) {
+        p->tile_state.reserve(sizeof(unsigned long long) * n_tiles_total) || p->misc.reserve(128 * ((size_t)n_ticks + 1)) ||
+        p->xtab.reserve(sizeof(float) * (size_t)(xoff + 8)) || p->ytab.reserve(sizeof(float) * (size_t)(yoff + 8))) {
+        delete p;
+        return nullptr;
+    }
+    if (hipMemset(p->misc.p, 0, 128 * ((size_t)n_ticks + 1)) != hipSuccess) {
+        lsn::set_error("lsnFusionCreate: scratch initialisation failed");
         delete p;
         return nullptr;
     }
@@ -474,6 +592,9 @@ extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *
     // pageable source: hipMemcpyAsync copies it out before returning, so the local vector may die
     LSN_HIP(hipMemcpyAsync(p->params.p, sp.data(), sizeof(SensorParams) * p->n_maps, hipMemcpyHostToDevice,
                            lsn::as_stream(stream)));
+    hipLaunchKernelGGL(table_kernel, dim3(8, (unsigned)p->n_maps), dim3(kThreads), 0, lsn::as_stream(stream), p->frames.as<FrameDesc>(),
+                       p->params.as<SensorParams>(), p->n_maps, p->xtab.as<float>(), p->ytab.as<float>());
+    LSN_HIP(hipGetLastError());
     LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
     memcpy(p->bounds, bounds6, sizeof(p->bounds));
     p->params_set = true;
@@ -558,13 +679,15 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
     a.frames = p->frames.as<FrameDesc>();
     a.tile_frame = p->tile_frame.as<unsigned short>();
     a.params = p->params.as<SensorParams>();
+    a.xtab = p->xtab.as<float>();
+    a.ytab = p->ytab.as<float>();
     a.depth = static_cast<const unsigned short *>(d_depth);
     a.rgb = static_cast<const unsigned char *>(d_colors);
     a.out = static_cast<uint4 *>(d_vertices);
     a.tile_counts = p->tile_counts.as<int>();
     a.tile_state = p->tile_state.as<unsigned long long>();
-    a.ticket = p->misc.as<unsigned int>();
-    a.error_flag = p->misc.as<int>() + 1;
+    a.error_flag = p->misc.as<int>();
+    a.ticket = p->misc.as<unsigned int>() + 32;
     a.offsets = d_offsets;
     a.n_frames = p->n_maps;
     a.tiles_per_tick = p->tiles_per_tick;
@@ -599,12 +722,14 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
 
     if (p->mode == 0) {
         launch<0>(vec, grid, s, a);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
+                           a.offsets);
         if (e0) LSN_HIP(hipEventRecord(e0, s));
         launch<1>(vec, grid, s, a);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
     } else {
         LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)a.n_tiles_total, s));
-        LSN_HIP(hipMemsetAsync(p->misc.p, 0, 8, s));
+        LSN_HIP(hipMemsetAsync(p->misc.as<char>() + 128, 0, 128 * (size_t)p->n_ticks, s));  // tickets; the error flag is sticky
         if (e0) LSN_HIP(hipEventRecord(e0, s));
         launch<2>(vec, grid, s, a);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
@@ -620,7 +745,8 @@ extern "C" int lsnFusionLookbackFailed(LsnFusion *p, void *stream)
     int flag = 0;
     LSN_HIP(hipSetDevice(p->device));
     LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
-    LSN_HIP(hipMemcpy(&flag, p->misc.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost));
+    LSN_HIP(hipMemcpy(&flag, p->misc.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) LSN_HIP(hipMemset(p->misc.p, 0, sizeof(int)));
     return flag;
 }
 

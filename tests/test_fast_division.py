@@ -1,0 +1,34 @@
+"""Exhaustive proof of the division-free depth conversion used by the HIP kernel (csrc/fusion.hip, depth_to_metres):
+for EVERY u16 depth d the sequence  q0 = d*r ; e = fma(-q0, 1000, d) ; q = fma(e, r, q0)  with r = fl32(1/1000)
+is bit-identical to the reference's  float(d) / 1000.0f  (src/NativeUtils/depthprocessing.cpp:149-150).
+Exact rational arithmetic, no floating-point shortcuts."""
+from fractions import Fraction
+
+import numpy as np
+
+
+def rn32(F):
+    """Correct rounding of a Fraction to float32 (nearest, ties to even)."""
+    if F == 0:
+        return np.float32(0)
+    c = np.float32(float(F))
+    best = None
+    for x in (np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))):
+        err = abs(Fraction(float(x)) - F)
+        if best is None or err < best[0] or (err == best[0] and (int(x.view(np.uint32)) & 1) == 0):
+            best = (err, x)
+    return best[1]
+
+
+def test_three_instruction_quotient_is_exact_for_every_u16_depth():
+    r = np.float32(1.0) / np.float32(1000.0)
+    assert int(r.view(np.uint32)) == 0x3A83126F            # the literal in fusion.hip
+    R = Fraction(float(r))
+    for d in range(1, 65536):
+        D = Fraction(d)
+        want = np.float32(d) / np.float32(1000.0)           # IEEE-754 division
+        assert want == rn32(D / 1000)
+        q0 = rn32(D * R)
+        e = rn32(D - Fraction(float(q0)) * 1000)
+        q = rn32(Fraction(float(q0)) + Fraction(float(e)) * R)
+        assert q == want, d
