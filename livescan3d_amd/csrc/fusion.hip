@@ -7,23 +7,31 @@
 //
 // Arithmetic contract (bit-exact with the reference, verified against oracle/): every f32 operation is rounded
 // on its own in the reference's order -- this file MUST be compiled with -ffp-contract=off and without any
-// fast-math flag; fp32 '/' is the correctly rounded division.
+// fast-math flag.  The only fused operations are the two explicit FMAs of the exact d/1000 sequence.
 //
 // Data layout in HBM (all little-endian, as LiveScanServer packs it, KinectServer.cs:453-498):
 //   depth   [tick][sensor][h][w] u16       -- 2 B / pixel, read with one 16-B load per lane (8 pixels)
-//   colours [tick][sensor][h][w][3] u8     -- 3 B / pixel, read with three 8-B loads per lane (8 pixels)
+//   colours [tick][sensor][h][w][3] u8     -- 3 B / pixel, read with 24 B per lane (8 pixels)
 //   cloud   [tick][capacity] {u8 R,G,B,A; f32 X,Y,Z} -- 16 B / surviving vertex, written as whole 16-B lanes,
 //                                             sensor-major then raster order (formMesh order)
-// Algorithmic bytes per sensor-frame: 2 P + 19 V  (P pixels, V survivors).  The kernel is HBM-bound; MFMA has no
-// role here (no contraction), the 4x4 pose is wave-uniform and lives in SGPRs (scalar loads), LDS is used for what
-// it is needed for: turning the per-lane compaction into fully coalesced 16-B stores.
+// Algorithmic bytes per sensor-frame: 2 P + 19 V  (P pixels, V survivors).  MFMA has no role here (no contraction;
+// it would also change the rounding); the per-sensor pose/intrinsics are wave-uniform and live in SGPRs (scalar
+// loads), LDS is used for what it is needed for: turning the per-lane compaction into fully coalesced 16-B stores.
 //
-// Compaction: a 256-thread workgroup owns a tile of 2048 consecutive pixels of one sensor-frame (8 per lane, so all
+// Measured character on MI355X (profiles/): the per-pixel arithmetic is NOT free -- ~35-45 VALU instructions per
+// pixel at ~4 cycles per wave instruction make the count pass VALU-bound and the write pass ~50 % VALU-busy -- so the
+// kernels are built to (1) spend as few VALU issue slots as possible (no divisions, packed f32 pairs, SALU lane-mask
+// logic) and (2) keep VALU-heavy and HBM-heavy work resident on a CU at the same time.
+//
+// Compaction: a 256-thread workgroup owns tiles of 2048 consecutive pixels of one sensor-frame (8 per lane, so all
 // global loads are wide and coalesced).  Lanes count their survivors, a wave scan (cross-lane shuffles) and a 4-entry
 // LDS exchange give every survivor its rank inside the tile, survivors are staged in LDS in rank order, and the tile
-// is then copied out with consecutive lanes writing consecutive vertices.  The tile's global offset inside its tick
-// comes either from a preceding count pass (mode 0, two launches) or from a decoupled look-back over per-tile
-// status words in the same launch (mode 1).
+// is copied out with consecutive lanes writing consecutive vertices.  Two ways to get a tile's offset in its tick:
+//   mode 0  count kernel -> scan kernel (one workgroup per tick) -> write kernel            (three launches)
+//   mode 1  ONE launch: a workgroup owns a RUN of consecutive tiles of one tick; it first counts the run (depth only),
+//           publishes the run's aggregate, resolves its base with a decoupled look-back over the runs of its tick,
+//           then recomputes and writes the run.  Counting (VALU) and writing (HBM) phases of different workgroups
+//           overlap on every CU, the second depth read comes from cache, and there is one look-back per run, not per tile.
 #include "lsn_common.hpp"
 
 #include <mutex>
@@ -33,7 +41,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kPxPerLane = 8;
-constexpr int kTile = kThreads * kPxPerLane;  // 2048 pixels per workgroup
+constexpr int kTile = kThreads * kPxPerLane;  // 2048 pixels per workgroup step
+constexpr int kWin = 1152;                    // survivors staged per LDS round (9/16 of a tile)
 
 struct FrameDesc {
     int w, h, npix, tile_start;  // tile_start: first tile of this frame inside its tick
@@ -58,34 +67,27 @@ struct FuseArgs {
     const unsigned short *depth;
     const unsigned char *rgb;
     uint4 *out;
-    int *tile_counts;                // mode 0: [n_ticks * tiles_per_tick]
-    unsigned long long *tile_state;  // mode 1: [n_ticks * tiles_per_tick] {flag:2 | value}
-    unsigned int *ticket;            // mode 1: per-tick tile tickets, 32 words apart
+    int *tile_counts;                // mode 0: [n_ticks * tiles_per_tick] counts, then exclusive prefixes
+    unsigned long long *run_state;   // mode 1: [n_ticks * tiles_per_tick] {flag:2 | value}, indexed by run
+    unsigned int *ticket;            // mode 1: per-tick run tickets, 32 words apart
     int *offsets;                    // [n_ticks][n_frames + 1]
     int *error_flag;                 // mode 1: set when a bounded spin gives up (sticky until read)
     int n_frames;
     int tiles_per_tick;
-    int n_tiles_total;
+    int n_ticks;
+    int tiles_per_run;               // mode 1
+    int runs_per_tick;               // mode 1
     long long tick_depth_stride;  // u16 elements
     long long tick_rgb_stride;    // bytes
     long long tick_vert_stride;   // vertices
     float minX, minY, minZ, maxX, maxY, maxZ;
 };
 
-// Z = float(d) / 1000.0f (depthprocessing.cpp:149-150) without the ~13-instruction IEEE division: with
-// r = fl32(1/1000), q0 = d*r, e = fma(-q0, 1000, d), q = fma(e, r, q0) is the correctly rounded quotient for EVERY
-// u16 d -- proven exhaustively with exact rational arithmetic in tests/test_fast_division.py (65535 cases).
-__device__ __forceinline__ float depth_to_metres(float d)
-{
-    const float r = 0x1.0624dep-10f;  // 0x3a83126f = fl32(0.001)
-    const float q0 = d * r;
-    const float e = __builtin_fmaf(-q0, 1000.0f, d);
-    return __builtin_fmaf(e, r, q0);
-}
-
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Z = float(d) / 1000.0f for two pixels (see depth_to_metres): v_pk_mul_f32 + 2 v_pk_fma_f32.
+// Z = float(d) / 1000.0f (depthprocessing.cpp:149-150) for two pixels without the ~13-instruction IEEE division:
+// with r = fl32(1/1000) = 0x3a83126f, q0 = d*r, e = fma(-q0, 1000, d), q = fma(e, r, q0) is the correctly rounded
+// quotient for EVERY u16 d -- proven exhaustively with exact rational arithmetic in tests/test_fast_division.py.
 __device__ __forceinline__ f2 depth_to_metres2(f2 d)
 {
     const f2 r = {0x1.0624dep-10f, 0x1.0624dep-10f};
@@ -139,97 +141,92 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
-// Look-back status word: bits 63..62 flag (0 = empty, 1 = tile aggregate, 2 = inclusive prefix), low 32 bits value.
-constexpr unsigned long long kFlagAggregate = 1ull << 62;
-constexpr unsigned long long kFlagPrefix = 2ull << 62;
-constexpr int kSpinLimit = 1 << 22;
+// ---- one tile: where it is, its inputs, its arithmetic --------------------------------------------------------
 
-// MODE 0 = count only (writes tile_counts), 1 = write with offsets from tile_counts, 2 = single pass with look-back.
-// VEC: every frame has w % 8 == 0 and the buffers are 16-B aligned -> 16-B depth loads, 8-B colour loads.
-template <int MODE, bool VEC>
-__global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
+struct Tile {  // wave-uniform (SGPRs)
+    int f, w, h, npix, px0;  // frame, its size, first pixel of the tile inside the frame
+    bool frame_start;
+    const unsigned short *dptr;
+    const unsigned char *cptr;
+    const float *xt, *yt;
+};
+
+__device__ __forceinline__ Tile locate(const FuseArgs &a, int tick, int tile)
 {
-    constexpr bool kWrite = MODE != 0;
-    // rank r lives at slot r + r/8: a lane's 8 consecutive ranks then start 9 slots (144 B) apart, which keeps
-    // the 16-B LDS writes of neighbouring lanes on different bank groups (stride 128 B would be an 8-way conflict).
-    __shared__ uint4 stage[kWrite ? (kTile + kTile / 8) : 1];
-    __shared__ int s_wave_tot[4];
-    __shared__ int s_tile;
-    __shared__ int s_base;
+    Tile t;
+    t.f = a.tile_frame[tile];
+    const FrameDesc fd = a.frames[t.f];
+    t.w = fd.w;
+    t.h = fd.h;
+    t.npix = fd.npix;
+    t.px0 = (tile - fd.tile_start) * kTile;
+    t.frame_start = tile == fd.tile_start;
+    t.dptr = a.depth + tick * a.tick_depth_stride + fd.depth_off;
+    t.cptr = a.rgb + tick * a.tick_rgb_stride + fd.rgb_off;
+    t.xt = a.xtab + fd.xtab_off;
+    t.yt = a.ytab + fd.ytab_off;
+    return t;
+}
 
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+struct Inputs {  // one lane's 8 pixels
+    unsigned int dw[4];  // 8 x u16 depth
+    unsigned int cw[6];  // 8 x RGB8
+};
 
-    int gtile = blockIdx.x;
-    int tick, tile;
-    if (MODE == 2) {
-        // Every tick is its own compaction domain with its own ticket counter (128 B apart: one returning atomic
-        // on a single word saturates near 88 tickets/us, far below the tile rate).  Workgroup b serves tick
-        // b % n_ticks and draws that tick's next tile: the tiles it will look back at were drawn earlier, so they
-        // are already running -- no deadlock whatever the dispatch order -- and because neighbouring workgroups
-        // serve different ticks, a tile's predecessors are n_ticks workgroups older each: long enough to have
-        // published their prefix, so a look-back usually ends inside its first 64-wide window.
-        const int n_ticks = a.n_tiles_total / a.tiles_per_tick;
-        tick = blockIdx.x % n_ticks;
-        if (threadIdx.x == 0) s_tile = (int)atomicAdd(a.ticket + 32 * tick, 1u);
-        __syncthreads();
-        tile = s_tile;
-        gtile = tick * a.tiles_per_tick + tile;
-    } else {
-        tick = gtile / a.tiles_per_tick;
-        tile = gtile - tick * a.tiles_per_tick;
-    }
-    const int f = a.tile_frame[tile];
-    const FrameDesc fd = a.frames[f];
-    const SensorParams P = a.params[f];
-
-    const int p0 = (tile - fd.tile_start) * kTile + threadIdx.x * kPxPerLane;
-    const unsigned short *dptr = a.depth + tick * a.tick_depth_stride + fd.depth_off;
-    const unsigned char *cptr = a.rgb + tick * a.tick_rgb_stride + fd.rgb_off;
-
-    // ---- loads ---------------------------------------------------------------------------------------------
-    unsigned int dw[4] = {0, 0, 0, 0};  // 8 x u16
-    unsigned int cw[6] = {0, 0, 0, 0, 0, 0};  // 8 x RGB8
+// VEC: every frame has w % 8 == 0 and the buffers are 16-B aligned -> one 16-B depth load, 24 B of colour per lane.
+template <bool VEC, bool RGB>
+__device__ __forceinline__ void load_inputs(const Tile &t, Inputs &in)
+{
+    const int p0 = t.px0 + threadIdx.x * kPxPerLane;
+#pragma unroll
+    for (int i = 0; i < 4; i++) in.dw[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.cw[i] = 0;
     if (VEC) {
-        if (p0 < fd.npix) {
-            uint4 dv = *reinterpret_cast<const uint4 *>(dptr + p0);
-            dw[0] = dv.x; dw[1] = dv.y; dw[2] = dv.z; dw[3] = dv.w;
-            if (kWrite) {
-                const uint2 *cp = reinterpret_cast<const uint2 *>(cptr + 3ll * p0);
-                uint2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
-                cw[0] = c0.x; cw[1] = c0.y; cw[2] = c1.x; cw[3] = c1.y; cw[4] = c2.x; cw[5] = c2.y;
+        if (p0 < t.npix) {
+            const uint4 dv = *reinterpret_cast<const uint4 *>(t.dptr + p0);
+            in.dw[0] = dv.x; in.dw[1] = dv.y; in.dw[2] = dv.z; in.dw[3] = dv.w;
+            if (RGB) {
+                const uint2 *cp = reinterpret_cast<const uint2 *>(t.cptr + 3ll * p0);
+                const uint2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+                in.cw[0] = c0.x; in.cw[1] = c0.y; in.cw[2] = c1.x; in.cw[3] = c1.y; in.cw[4] = c2.x; in.cw[5] = c2.y;
             }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < kPxPerLane; k++) {
-            if (p0 + k < fd.npix) {
-                unsigned int d = dptr[p0 + k];
-                dw[k >> 1] |= d << ((k & 1) * 16);
-                if (kWrite) {
-                    const unsigned char *c = cptr + 3ll * (p0 + k);
-                    unsigned int rgb = c[0] | (c[1] << 8) | (c[2] << 16);
-                    // append 3 bytes at byte offset 3k of the 24-byte group
-                    int b = 3 * k;
-                    cw[b >> 2] |= rgb << ((b & 3) * 8);
-                    if ((b & 3) > 1) cw[(b >> 2) + 1] |= rgb >> ((4 - (b & 3)) * 8);
+            if (p0 + k < t.npix) {
+                const unsigned int d = t.dptr[p0 + k];
+                in.dw[k >> 1] |= d << ((k & 1) * 16);
+                if (RGB) {
+                    const unsigned char *c = t.cptr + 3ll * (p0 + k);
+                    const unsigned int rgb = c[0] | (c[1] << 8) | (c[2] << 16);
+                    const int b = 3 * k;  // the pixel's 3 bytes start at byte 3k of the lane's 24-byte group
+                    in.cw[b >> 2] |= rgb << ((b & 3) * 8);
+                    if ((b & 3) > 1) in.cw[(b >> 2) + 1] |= rgb >> ((4 - (b & 3)) * 8);
                 }
             }
         }
     }
+}
 
-    // ---- per-pixel arithmetic ------------------------------------------------------------------------------
-    const bool in_frame = p0 < fd.npix;
-    int y = in_frame ? p0 / fd.w : 0;
-    int x = in_frame ? p0 - y * fd.w : 0;
-    const float *xt = a.xtab + fd.xtab_off;
-    const float *yt = a.ytab + fd.ytab_off;
-    float yfac = yt[y];
+// Keep predicates (wave-wide lane masks in SGPR pairs) and, when WRITE, the assembled vertices of a lane's 8 pixels.
+// Branch-free: a zero depth (invalid pixel, :144, or a lane past the frame end) is computed and then dropped.
+template <bool VEC, bool WRITE>
+__device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, const Inputs &in, bool (&keep)[kPxPerLane],
+                                             uint4 (&vert)[kPxPerLane])
+{
+    const SensorParams P = a.params[t.f];
+    const int p0 = t.px0 + threadIdx.x * kPxPerLane;
+    const bool in_frame = p0 < t.npix;
+    int y = in_frame ? p0 / t.w : 0;
+    int x = in_frame ? p0 - y * t.w : 0;
+    float yfac = t.yt[y];
     float xf[kPxPerLane], yf[kPxPerLane];
     if (VEC) {
         // w % 8 == 0: the lane's 8 pixels share a row and their columns are 8 consecutive, 32-B aligned table entries
-        const float4 x0 = *reinterpret_cast<const float4 *>(xt + x);
-        const float4 x1 = *reinterpret_cast<const float4 *>(xt + x + 4);
+        const float4 x0 = *reinterpret_cast<const float4 *>(t.xt + x);
+        const float4 x1 = *reinterpret_cast<const float4 *>(t.xt + x + 4);
         xf[0] = x0.x; xf[1] = x0.y; xf[2] = x0.z; xf[3] = x0.w;
         xf[4] = x1.x; xf[5] = x1.y; xf[6] = x1.z; xf[7] = x1.w;
 #pragma unroll
@@ -237,133 +234,105 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     } else {
 #pragma unroll
         for (int k = 0; k < kPxPerLane; k++) {
-            xf[k] = xt[x];
+            xf[k] = t.xt[x];
             yf[k] = yfac;
             // rows may end inside a lane's 8 pixels when w % 8 != 0
             x++;
-            if (x == fd.w) {
+            if (x == t.w) {
                 x = 0;
-                y = y + 1 < fd.h ? y + 1 : y;
-                yfac = yt[y];
+                y = y + 1 < t.h ? y + 1 : y;
+                yfac = t.yt[y];
             }
         }
     }
-    uint4 vert[kPxPerLane];  // {RGBA, X, Y, Z} assembled in place so the 16-B LDS store needs no register shuffling
-    bool keep[kPxPerLane];   // wave-wide predicates (SGPR pairs); no per-lane bit mask is materialised
-    int cnt = 0;
 #pragma unroll
     for (int k = 0; k < kPxPerLane; k += 2) {
-        const unsigned int d0 = dw[k >> 1] & 0xFFFFu, d1 = dw[k >> 1] >> 16;
-        // branch-free: a zero depth (invalid pixel, :144, or a lane past the frame end) is computed and then dropped
+        const unsigned int d0 = in.dw[k >> 1] & 0xFFFFu, d1 = in.dw[k >> 1] >> 16;
         f2 ox, oy, oz;
         unproject2(f2{(float)d0, (float)d1}, f2{xf[k], xf[k + 1]}, f2{yf[k], yf[k + 1]}, P, ox, oy, oz);
         keep[k] = inside_box(ox.x, oy.x, oz.x, a) && d0 != 0;
         keep[k + 1] = inside_box(ox.y, oy.y, oz.y, a) && d1 != 0;
-        if (kWrite) {
+        if (WRITE) {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int b = 3 * (k + j);
-                const unsigned int lo = cw[b >> 2];
-                const unsigned int hi = cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
+                const unsigned int lo = in.cw[b >> 2];
+                const unsigned int hi = in.cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
                 vert[k + j].x = (__funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu) | 0xFF000000u;  // A = 255 (:1601)
                 vert[k + j].y = __float_as_uint(j ? ox.y : ox.x);
                 vert[k + j].z = __float_as_uint(j ? oy.y : oy.x);
                 vert[k + j].w = __float_as_uint(j ? oz.y : oz.x);
             }
         }
-        cnt += (keep[k] ? 1 : 0) + (keep[k + 1] ? 1 : 0);
     }
+}
 
-    // ---- rank inside the tile --------------------------------------------------------------------------------
+// Stages a tile's survivors in LDS in rank order, window by window, and copies them out with consecutive lanes writing
+// consecutive 16-B vertices.  Rank q of a window lives at slot q + q/8: a lane's 8 consecutive ranks then start 9 slots
+// (144 B) apart, which keeps the 16-B LDS writes of neighbouring lanes on different bank groups (stride 128 B is an
+// 8-way conflict).  A typical tile (crop + invalid pixels) fits in one window of kWin; the 20.7 KB footprint (instead of
+// 36.9 KB for a whole tile) lets 7 workgroups share a CU.  Every thread must call this (barriers inside); rank0 is the
+// lane's first rank inside the tile, tile_tot is uniform.  On return the LDS window is free again.
+__device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)[kPxPerLane], const uint4 (&vert)[kPxPerLane], int rank0,
+                                                int tile_tot, uint4 *dst)
+{
+    for (int w0 = 0; w0 < tile_tot; w0 += kWin) {
+        int r = rank0 - w0;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            if (keep[k]) {
+                if ((unsigned int)r < (unsigned int)kWin) stage[r + (r >> 3)] = vert[k];
+                r++;
+            }
+        }
+        __syncthreads();
+        const int n = min(kWin, tile_tot - w0);
+        for (int i = threadIdx.x; i < n; i += kThreads) dst[w0 + i] = stage[i + (i >> 3)];
+        __syncthreads();
+    }
+}
+
+// ---- mode 0: count kernel, scan kernel, write kernel ------------------------------------------------------------
+
+// MODE 0 = count only (writes tile_counts), 1 = write with offsets from tile_counts (exclusive prefixes by then).
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
+{
+    constexpr bool kWrite = MODE != 0;
+    __shared__ uint4 stage[kWrite ? (kWin + kWin / 8) : 1];
+    __shared__ int s_wave_tot[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tick = blockIdx.x / a.tiles_per_tick;
+    const int tile = blockIdx.x - tick * a.tiles_per_tick;
+
+    const Tile t = locate(a, tick, tile);
+    Inputs in;
+    load_inputs<VEC, kWrite>(t, in);
+    bool keep[kPxPerLane];
+    uint4 vert[kPxPerLane];
+    compute_tile<VEC, kWrite>(a, t, in, keep, vert);
+
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) cnt += keep[k] ? 1 : 0;
     const int incl = wave_inclusive_scan(cnt, lane);
     if (lane == 63) s_wave_tot[wave] = incl;
-
     int base = 0;
-    // mode 1: scan_kernel has turned the tile counts into exclusive prefixes inside each tick (one scalar load)
-    if (MODE == 1) base = a.tile_counts[(long long)tick * a.tiles_per_tick + tile];
+    if (MODE == 1) base = a.tile_counts[blockIdx.x];  // scan_kernel left the exclusive prefix inside the tick here
     __syncthreads();
     int wave_off = 0, tile_tot = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        int v = s_wave_tot[i];
+        const int v = s_wave_tot[i];
         if (i < wave) wave_off += v;
         tile_tot += v;
     }
-
     if (MODE == 0) {
-        if (threadIdx.x == 0) a.tile_counts[(long long)tick * a.tiles_per_tick + tile] = tile_tot;
+        if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = tile_tot;
         return;
     }
-
-    // ---- stage survivors in rank order ----------------------------------------------------------------------
-    int r = wave_off + incl - cnt;
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) {
-        if (keep[k]) {
-            stage[r + (r >> 3)] = vert[k];
-            r++;
-        }
-    }
-
-    if (MODE == 2) {
-        // ---- decoupled look-back over the tiles of this tick (wave 0) ----------------------------------------
-        if (wave == 0) {
-            unsigned long long *st = a.tile_state + (long long)tick * a.tiles_per_tick;
-            if (lane == 0) {
-                unsigned long long w = (tile == 0 ? kFlagPrefix : kFlagAggregate) | (unsigned int)tile_tot;
-                __hip_atomic_store(&st[tile], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            int run = 0;
-            int pos = tile - 1 - lane;  // lane 0 looks at the nearest predecessor
-            bool done = tile == 0;
-            int spins = 0;
-            while (!done) {
-                unsigned long long w = 0;
-                if (pos >= 0) w = __hip_atomic_load(&st[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else w = kFlagPrefix;  // before the first tile: prefix 0
-                const unsigned int flag = (unsigned int)(w >> 62);
-                const unsigned long long pref = __ballot(flag == 2);
-                // only the predecessors up to and including the nearest prefix holder matter
-                const int first = pref ? __ffsll((long long)pref) - 1 : 63;
-                const unsigned long long relevant = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
-                const unsigned long long empty = __ballot(flag == 0) & relevant;
-                if (empty != 0) {
-                    // one of them has not published yet: poll again (bounded, so the grid always drains)
-                    if (++spins > kSpinLimit) {
-                        if (lane == 0) atomicExch(a.error_flag, 1);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                int v = (lane <= first) ? (int)(unsigned int)w : 0;
-                run += wave_sum(v);
-                if (pref) done = true;
-                else pos -= 64;
-            }
-            if (lane == 0) {
-                if (tile != 0) {
-                    unsigned long long w = kFlagPrefix | (unsigned int)(run + tile_tot);
-                    __hip_atomic_store(&st[tile], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                s_base = run;
-            }
-        }
-        __syncthreads();
-        base = s_base;
-    } else {
-        __syncthreads();
-    }
-
-    // ---- coalesced copy-out: consecutive lanes write consecutive 16-B vertices ------------------------------
-    uint4 *dst = a.out + tick * a.tick_vert_stride + base;
-    for (int i = threadIdx.x; i < tile_tot; i += kThreads) dst[i] = stage[i + (i >> 3)];
-
-    if (MODE == 2 && threadIdx.x == 0) {
-        int *off = a.offsets + (long long)tick * (a.n_frames + 1);
-        if (tile == fd.tile_start) off[f] = base;
-        if (tile == a.tiles_per_tick - 1) off[a.n_frames] = base + tile_tot;
-    }
+    stage_and_store(stage, keep, vert, wave_off + incl - cnt, tile_tot, a.out + tick * a.tick_vert_stride + base);
 }
 
 // Mode 0, between the count and the write launch: one workgroup per tick turns that tick's tile counts into exclusive
@@ -394,6 +363,153 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(int *tile_counts, int ti
     }
     // frames are few: thread f looks up the prefix at its first tile (written above by this workgroup)
     for (int f = threadIdx.x; f <= n_frames; f += kThreads) off[f] = f < n_frames ? tc[frames[f].tile_start] : s_carry;
+}
+
+
+// ---- mode 1: one launch, runs of tiles with a decoupled look-back per run ---------------------------------------
+
+// Look-back status word: bits 63..62 flag (0 = empty, 1 = run aggregate, 2 = inclusive prefix), low 32 bits value.
+// One naturally aligned 8-byte word carries flag AND value, written by one agent-scope (sc1, write-through) store and
+// polled with agent-scope loads: nothing else is handed off, so no fence is needed and the result cannot depend on
+// where the producing workgroup ran.
+constexpr unsigned long long kFlagAggregate = 1ull << 62;
+constexpr unsigned long long kFlagPrefix = 2ull << 62;
+constexpr int kSpinLimit = 1 << 20;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void run_kernel(const FuseArgs a)
+{
+    __shared__ uint4 stage[kWin + kWin / 8];
+    __shared__ int s_wave_tot[4];
+    __shared__ int s_run;
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    // Every tick is its own compaction domain with its own ticket counter (128 B apart: one returning atomic on a
+    // single word saturates near 88 tickets/us).  Workgroup b serves tick b % n_ticks and draws that tick's next run:
+    // the runs it will look back at were drawn earlier, so they are running or done, and none of them waits for
+    // anything before publishing its aggregate -- no deadlock whatever the dispatch order.
+    const int tick = blockIdx.x % a.n_ticks;
+    if (threadIdx.x == 0) s_run = (int)atomicAdd(a.ticket + 32 * tick, 1u);
+    __syncthreads();
+    const int run = s_run;
+    if (run >= a.runs_per_tick) return;  // cannot happen with grid = n_ticks * runs_per_tick; keeps a bad launch harmless
+    const int t0 = run * a.tiles_per_run;
+    const int t1 = min(t0 + a.tiles_per_run, a.tiles_per_tick);
+
+    // ---- phase 1: count the run (depth only; the next tile's depth is in flight while this one is evaluated) -------
+    int wave_total = 0;
+    {
+        Tile t = locate(a, tick, t0);
+        Inputs in;
+        load_inputs<VEC, false>(t, in);
+        for (int tile = t0; tile < t1; tile++) {
+            Tile tn = t;
+            Inputs nx = in;
+            if (tile + 1 < t1) {
+                tn = locate(a, tick, tile + 1);
+                load_inputs<VEC, false>(tn, nx);
+            }
+            bool keep[kPxPerLane];
+            uint4 unused[kPxPerLane];
+            compute_tile<VEC, false>(a, t, in, keep, unused);
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) wave_total += __popcll(__ballot(keep[k]));  // SALU: lane mask popcount
+            t = tn;
+            in = nx;
+        }
+    }
+    if (lane == 0) s_wave_tot[wave] = wave_total;
+    __syncthreads();
+    const int run_tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+
+    // inputs of the first tile of phase 2 fly while the look-back polls
+    Tile t = locate(a, tick, t0);
+    Inputs in;
+    load_inputs<VEC, true>(t, in);
+
+    // ---- decoupled look-back over the runs of this tick (wave 0) ---------------------------------------------------
+    if (wave == 0) {
+        unsigned long long *st = a.run_state + (long long)tick * a.tiles_per_tick;
+        if (lane == 0) {
+            const unsigned long long w = (run == 0 ? kFlagPrefix : kFlagAggregate) | (unsigned int)run_tot;
+            __hip_atomic_store(&st[run], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int acc = 0;
+        int pos = run - 1 - lane;  // lane 0 looks at the nearest predecessor
+        bool done = run == 0;
+        int spins = 0;
+        while (!done) {
+            unsigned long long w = kFlagPrefix;  // before the first run: prefix 0
+            if (pos >= 0) w = __hip_atomic_load(&st[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int flag = (unsigned int)(w >> 62);
+            const unsigned long long pref = __ballot(flag == 2);
+            // only the predecessors up to and including the nearest prefix holder matter
+            const int first = pref ? __ffsll((long long)pref) - 1 : 63;
+            const unsigned long long relevant = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+            const unsigned long long empty = __ballot(flag == 0) & relevant;
+            if (empty != 0) {
+                // one of them has not published yet: poll again (bounded, so the grid always drains)
+                if (++spins > kSpinLimit) {
+                    if (lane == 0) atomicExch(a.error_flag, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            const int v = (lane <= first) ? (int)(unsigned int)w : 0;
+            acc += wave_sum(v);
+            if (pref) done = true;
+            else pos -= 64;
+        }
+        if (lane == 0) {
+            if (run != 0) {
+                const unsigned long long w = kFlagPrefix | (unsigned int)(acc + run_tot);
+                __hip_atomic_store(&st[run], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_base = acc;
+        }
+    }
+    __syncthreads();
+    int running = s_base;
+
+    // ---- phase 2: recompute and write the run (depth now comes from cache; next tile's inputs in flight) ------------
+    int *off = a.offsets + (long long)tick * (a.n_frames + 1);
+    for (int tile = t0; tile < t1; tile++) {
+        Tile tn = t;
+        Inputs nx = in;
+        if (tile + 1 < t1) {
+            tn = locate(a, tick, tile + 1);
+            load_inputs<VEC, true>(tn, nx);
+        }
+        bool keep[kPxPerLane];
+        uint4 vert[kPxPerLane];
+        compute_tile<VEC, true>(a, t, in, keep, vert);
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) cnt += keep[k] ? 1 : 0;
+        const int incl = wave_inclusive_scan(cnt, lane);
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_off = 0, tile_tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int v = s_wave_tot[i];
+            if (i < wave) wave_off += v;
+            tile_tot += v;
+        }
+        if (threadIdx.x == 0 && t.frame_start) off[t.f] = running;
+        if (tile_tot > 0) {
+            stage_and_store(stage, keep, vert, wave_off + incl - cnt, tile_tot, a.out + tick * a.tick_vert_stride + running);
+        } else {
+            __syncthreads();  // s_wave_tot is rewritten by the next tile
+        }
+        running += tile_tot;
+        t = tn;
+        in = nx;
+    }
+    if (threadIdx.x == 0 && t1 == a.tiles_per_tick) off[a.n_frames] = running;
 }
 
 // Fills a sensor's unprojection tables with the reference's own operations (depthprocessing.cpp:151-152):
@@ -458,6 +574,7 @@ struct LsnFusion {
     bool vec_ok = false;
     bool params_set = false;
     int mode = 0;
+    int tiles_per_run_override = 0;  // $LSN_TILES_PER_RUN (tuning / tests)
     float bounds[6] = {0, 0, 0, 0, 0, 0};
     lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: error flag (word 0) + tickets
     lsn::DevBuf xtab, ytab;
@@ -485,6 +602,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
     LsnFusion *p = new (std::nothrow) LsnFusion();
     if (!p) return nullptr;
     p->device = device;
+    if (const char *env = getenv("LSN_TILES_PER_RUN")) p->tiles_per_run_override = atoi(env);
     p->n_ticks = n_ticks;
     p->n_maps = n_maps;
     std::vector<FrameDesc> fr(n_maps);
@@ -604,7 +722,7 @@ extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *
 extern "C" int lsnFusionSetMode(LsnFusion *p, int mode)
 {
     if (!p || mode < 0 || mode > 1) {
-        lsn::set_error("lsnFusionSetMode: mode must be 0 (two-pass) or 1 (look-back)");
+        lsn::set_error("lsnFusionSetMode: mode must be 0 (count/scan/write launches) or 1 (single launch, runs + look-back)");
         return -1;
     }
     p->mode = mode;
@@ -640,7 +758,7 @@ extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *lau
     if (drain_events(p)) return -1;
     if (avg_ms) *avg_ms = p->launches ? p->acc_ms / (double)p->launches : 0.0;
     if (launches) *launches = p->launches;
-    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", p->mode == 0 ? "fuse_kernel<1>" : "fuse_kernel<2>");
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", p->mode == 0 ? "fuse_kernel<1>" : "run_kernel");
     if (reset) {
         p->acc_ms = 0;
         p->launches = 0;
@@ -685,13 +803,25 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
     a.rgb = static_cast<const unsigned char *>(d_colors);
     a.out = static_cast<uint4 *>(d_vertices);
     a.tile_counts = p->tile_counts.as<int>();
-    a.tile_state = p->tile_state.as<unsigned long long>();
+    a.run_state = p->tile_state.as<unsigned long long>();
     a.error_flag = p->misc.as<int>();
     a.ticket = p->misc.as<unsigned int>() + 32;
     a.offsets = d_offsets;
     a.n_frames = p->n_maps;
     a.tiles_per_tick = p->tiles_per_tick;
-    a.n_tiles_total = p->tiles_per_tick * p->n_ticks;
+    a.n_ticks = p->n_ticks;
+    // mode 1: runs of consecutive tiles.  Long runs amortise the look-back and the second (cached) depth read, short
+    // runs balance the load: aim at >= ~6 runs per workgroup slot (7 per CU x 256 CUs), at most 8 tiles per run.
+    {
+        const long long total = (long long)p->tiles_per_tick * p->n_ticks;
+        long long tpr = total / (6ll * 7 * 256);
+        if (p->tiles_per_run_override > 0) tpr = p->tiles_per_run_override;
+        if (tpr < 1) tpr = 1;
+        if (tpr > 8 && p->tiles_per_run_override <= 0) tpr = 8;
+        if (tpr > p->tiles_per_tick) tpr = p->tiles_per_tick;
+        a.tiles_per_run = (int)tpr;
+        a.runs_per_tick = (p->tiles_per_tick + a.tiles_per_run - 1) / a.tiles_per_run;
+    }
     a.tick_depth_stride = p->tick_depth_elems;
     a.tick_rgb_stride = p->tick_rgb_bytes;
     a.tick_vert_stride = p->cap;
@@ -701,7 +831,7 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
     // the wide-load path also needs 16-B aligned buffers and every tick to start 16-B / 8-B aligned
     const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 &&
                      (p->tick_depth_elems % 8) == 0;
-    const int grid = a.n_tiles_total;
+    const int grid = p->tiles_per_tick * p->n_ticks;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (p->profile) {
@@ -728,10 +858,12 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         launch<1>(vec, grid, s, a);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
     } else {
-        LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)a.n_tiles_total, s));
+        LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)grid, s));
         LSN_HIP(hipMemsetAsync(p->misc.as<char>() + 128, 0, 128 * (size_t)p->n_ticks, s));  // tickets; the error flag is sticky
         if (e0) LSN_HIP(hipEventRecord(e0, s));
-        launch<2>(vec, grid, s, a);
+        const int rgrid = a.runs_per_tick * p->n_ticks;
+        if (vec) hipLaunchKernelGGL((run_kernel<true>), dim3(rgrid), dim3(kThreads), 0, s, a);
+        else     hipLaunchKernelGGL((run_kernel<false>), dim3(rgrid), dim3(kThreads), 0, s, a);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
     }
     LSN_HIP(hipGetLastError());

@@ -5,10 +5,14 @@
 // (:34-73,:128), and an uncentred Kabsch step through OpenCV (mean difference, 3x3 SVD, apply; :138-168).
 //
 // Here (everything stays in HBM, no host synchronisation inside the iteration loop):
-//   * exact nearest neighbour -- either an LDS-tiled brute force (nn_mode 0) or a uniform voxel grid over the
-//     target built ONCE per call (the target never moves): counting sort by cell, then per query an expanding
-//     shell search that stops only when the best f32 distance is provably minimal; queries that stay unresolved
-//     after kMaxRing shells fall back to the brute-force kernel.  Distances are evaluated exactly like
+//   * exact nearest neighbour -- either an LDS-tiled brute force (nn_mode 0) or a voxel grid over the target built
+//     ONCE per call (the target never moves): counting sort by cell, cells ordered super-block (16^3 cells) ->
+//     block (4^3 cells) -> cell so that every block and super-block is one contiguous range of the sorted points,
+//     tight AABBs per block and super-block.  A query first scans the 27 cells around it; that answer is final when
+//     the best f32 distance is provably inside the scanned neighbourhood.  The remaining ("far") queries are
+//     compacted and resolved by a second kernel that walks the two-level AABB hierarchy with exact f32 lower bounds
+//     (a box is skipped only when its minimum distance exceeds the best so far), so the result is the exact NN at
+//     any distance without ever falling back to O(n1) work per query.  Distances are evaluated exactly like
 //     PointCloud::kdtree_distance (include/NativeUtils/icp.h:40-47): (d0*d0 + d1*d1) + d2*d2, no FMA.
 //     Equal distances resolve to the lowest target index (nanoflann's tie order is traversal dependent).
 //   * one-to-one matching -- a 64-bit atomicMin per target on (dist_bits << 32 | ~i): minimum distance wins, the
@@ -32,16 +36,23 @@ constexpr int kMaxBlocks = 1024;      // partial-sum slots
 constexpr int kMaxCells = 1 << 22;    // dense grid capacity (16 MiB of cell starts)
 constexpr int kScanItems = 16;        // cells per thread in the scan kernels
 constexpr int kScanBlock = kThreads * kScanItems;  // 4096
-constexpr int kMaxRing = 3;           // shells searched in the grid before a query goes to the brute-force list
+constexpr int kSuper = 16;            // cells per super-block edge
+constexpr int kMaxSupers = kMaxCells / (kSuper * kSuper * kSuper);  // 1024
+constexpr int kMaxBlocks3 = kMaxCells / 64;                          // 4^3-cell blocks
 constexpr float kBoundSlack = 0.999f; // shrinks the geometric bound: covers the rounding of the cell arithmetic
 constexpr int kBfTile = 1024;         // targets per LDS tile in the brute-force kernel
 
 struct GridParams {
     float ox, oy, oz;   // origin (bbox min)
     float h, inv_h;
-    int nx, ny, nz;
-    int ncells;
+    int nx, ny, nz;     // cells per axis (multiples of 16)
+    int nsx, nsy, nsz;  // super-blocks per axis
+    int ncells;         // nx * ny * nz
     int n_points;
+};
+
+struct Box {  // tight AABB of a block / super-block; empty: lo = +inf, hi = -inf
+    float lx, ly, lz, hx, hy, hz, pad0, pad1;
 };
 
 // per-iteration device state
@@ -119,6 +130,36 @@ __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int n)
     return c;
 }
 
+// Cell order: super-block (16^3 cells) major, then block (4^3 cells), then cell -- every block / super-block is a
+// contiguous range of cell indices, hence of the cell-sorted point array.
+__device__ __forceinline__ int cell_index(int cx, int cy, int cz, const GridParams &g)
+{
+    const int s = ((cz >> 4) * g.nsy + (cy >> 4)) * g.nsx + (cx >> 4);
+    const int b = ((((cz >> 2) & 3) * 4) + ((cy >> 2) & 3)) * 4 + ((cx >> 2) & 3);
+    const int l = (((cz & 3) * 4) + (cy & 3)) * 4 + (cx & 3);
+    return (s << 12) | (b << 6) | l;
+}
+
+// Exact f32 lower bound of dist2(q, p) over every p inside the box: component-wise |q - p| >= the clamped gap, and
+// rounding is monotone, so the same operation order as dist2 keeps the inequality in floating point.
+__device__ __forceinline__ float box_min_dist2(float qx, float qy, float qz, const Box &b)
+{
+    const float dx = fmaxf(0.0f, fmaxf(b.lx - qx, qx - b.hx));
+    const float dy = fmaxf(0.0f, fmaxf(b.ly - qy, qy - b.hy));
+    const float dz = fmaxf(0.0f, fmaxf(b.lz - qz, qz - b.hz));
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// Upper bound of the NN distance offered by a non-empty box: its farthest corner (every box holds >= 1 point).
+__device__ __forceinline__ float box_max_dist2(float qx, float qy, float qz, const Box &b)
+{
+    const float dx = fmaxf(fabsf(qx - b.lx), fabsf(qx - b.hx));
+    const float dy = fmaxf(fabsf(qy - b.ly), fabsf(qy - b.hy));
+    const float dz = fmaxf(fabsf(qz - b.lz), fabsf(qz - b.hz));
+    const float d = dx * dx + dy * dy + dz * dz;
+    return b.lx <= b.hx ? d * 1.0001f : INFINITY;  // slack: the bound is only used to prune, never reported
+}
+
 // ---- grid build -----------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(kThreads) void bbox_partial_kernel(const float *pts, int n, float *part /* [blocks][6] */)
@@ -150,15 +191,19 @@ __global__ __launch_bounds__(kThreads) void bbox_partial_kernel(const float *pts
     }
 }
 
-__global__ void grid_setup_kernel(const float *part, int n_parts, int n_points, float cell_override, GridParams *gp)
+__global__ __launch_bounds__(64) void grid_setup_kernel(const float *part, int n_parts, int n_points, float cell_override, GridParams *gp)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int b = 0; b < n_parts; b++)
+    for (int b = threadIdx.x; b < n_parts; b += 64)
         for (int c = 0; c < 3; c++) {
             mn[c] = fminf(mn[c], part[b * 6 + c]);
             mx[c] = fmaxf(mx[c], part[b * 6 + 3 + c]);
         }
+    for (int c = 0; c < 3; c++) {
+        mn[c] = wave_min_f(mn[c]);
+        mx[c] = wave_max_f(mx[c]);
+    }
+    if (threadIdx.x != 0) return;
     float ext[3];
     for (int c = 0; c < 3; c++) {
         if (!(mn[c] <= mx[c])) { mn[c] = 0; mx[c] = 0; }  // all-NaN axis
@@ -171,20 +216,25 @@ __global__ void grid_setup_kernel(const float *part, int n_parts, int n_points, 
     float h = 2.0f * sqrtf(fmaxf(area, 1e-12f) / (float)(n_points > 0 ? n_points : 1));
     h = fminf(fmaxf(h, L / 512.0f), L / 4.0f);
     if (cell_override > 0.0f) h = cell_override;
-    int nx = 1, ny = 1, nz = 1;
+    int nsx = 1, nsy = 1, nsz = 1;
     for (int guard = 0; guard < 2000; guard++) {
-        nx = (int)fminf(floorf(ext[0] / h) + 1.0f, 4096.0f);
-        ny = (int)fminf(floorf(ext[1] / h) + 1.0f, 4096.0f);
-        nz = (int)fminf(floorf(ext[2] / h) + 1.0f, 4096.0f);
-        if ((long long)nx * ny * nz <= kMaxCells && (float)nx * h > ext[0] * 0.999f && (float)ny * h > ext[1] * 0.999f &&
-            (float)nz * h > ext[2] * 0.999f)
+        // cells needed per axis, rounded up to whole super-blocks
+        nsx = (int)fminf(floorf(ext[0] / h / kSuper) + 1.0f, 4096.0f);
+        nsy = (int)fminf(floorf(ext[1] / h / kSuper) + 1.0f, 4096.0f);
+        nsz = (int)fminf(floorf(ext[2] / h / kSuper) + 1.0f, 4096.0f);
+        if ((long long)nsx * nsy * nsz <= kMaxSupers && (float)(nsx * kSuper) * h > ext[0] * 1.001f &&
+            (float)(nsy * kSuper) * h > ext[1] * 1.001f && (float)(nsz * kSuper) * h > ext[2] * 1.001f)
             break;
         h *= 1.26f;
+        nsx = nsy = nsz = 1;
     }
+    if ((long long)nsx * nsy * nsz > kMaxSupers) nsx = nsy = nsz = 1;
+    const int nx = nsx * kSuper, ny = nsy * kSuper, nz = nsz * kSuper;
     gp->ox = mn[0]; gp->oy = mn[1]; gp->oz = mn[2];
     gp->h = h;
     gp->inv_h = 1.0f / h;
     gp->nx = nx; gp->ny = ny; gp->nz = nz;
+    gp->nsx = nsx; gp->nsy = nsy; gp->nsz = nsz;
     gp->ncells = nx * ny * nz;
     gp->n_points = n_points;
 }
@@ -197,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void cell_count_kernel(const float *pts, 
         int cx = cell_coord(pts[3 * (size_t)i], g.ox, g.inv_h, g.nx);
         int cy = cell_coord(pts[3 * (size_t)i + 1], g.oy, g.inv_h, g.ny);
         int cz = cell_coord(pts[3 * (size_t)i + 2], g.oz, g.inv_h, g.nz);
-        int c = (cz * g.ny + cy) * g.nx + cx;
+        int c = cell_index(cx, cy, cz, g);
         cell_of[i] = c;
         atomicAdd(&cell_cnt[c], 1);
     }
@@ -303,11 +353,46 @@ __device__ __forceinline__ void scan_range(const float4 *sorted, int s, int e, f
     }
 }
 
-// One thread per query.  Shell r covers the cells at Chebyshev distance r from the (clamped) query cell; after
-// shells 0..r every unsearched target is at least r*h away, so the search stops once best <= (r*h*slack)^2.
+// Tight AABB of every 4^3-cell block (one wave per block; its points are one contiguous range).
+__global__ __launch_bounds__(kThreads) void block_box_kernel(const GridParams *gp, const int *cell_start, const float4 *sorted, Box *boxes)
+{
+    const int lane = threadIdx.x & 63;
+    const int n_blocks = gp->ncells / 64;
+    for (int b = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); b < n_blocks; b += gridDim.x * (kThreads / 64)) {
+        Box bx = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, 0, 0};
+        const int s = cell_start[b * 64], e = cell_start[b * 64 + 64];
+        if (s < e) {  // wave-uniform
+            for (int j = s + lane; j < e; j += 64) {
+                const float4 p = sorted[j];
+                bx.lx = fminf(bx.lx, p.x); bx.ly = fminf(bx.ly, p.y); bx.lz = fminf(bx.lz, p.z);
+                bx.hx = fmaxf(bx.hx, p.x); bx.hy = fmaxf(bx.hy, p.y); bx.hz = fmaxf(bx.hz, p.z);
+            }
+            bx.lx = wave_min_f(bx.lx); bx.ly = wave_min_f(bx.ly); bx.lz = wave_min_f(bx.lz);
+            bx.hx = wave_max_f(bx.hx); bx.hy = wave_max_f(bx.hy); bx.hz = wave_max_f(bx.hz);
+        }
+        if (lane == 0) boxes[b] = bx;
+    }
+}
+
+// AABB of every super-block = union of its 64 block boxes (one wave per super-block).
+__global__ __launch_bounds__(64) void super_box_kernel(const GridParams *gp, const Box *boxes, Box *supers)
+{
+    const int s = blockIdx.x;
+    if (s >= gp->ncells / 4096) return;
+    const Box b = boxes[s * 64 + threadIdx.x];
+    Box r;
+    r.lx = wave_min_f(b.lx); r.ly = wave_min_f(b.ly); r.lz = wave_min_f(b.lz);
+    r.hx = wave_max_f(b.hx); r.hy = wave_max_f(b.hy); r.hz = wave_max_f(b.hz);
+    r.pad0 = r.pad1 = 0;
+    if (threadIdx.x == 0) supers[s] = r;
+}
+
+// One thread per query: scan the 27 cells around the (clamped) query cell.  Every unscanned target sits in a cell at
+// Chebyshev distance >= 2, i.e. at least one cell edge h away, so the answer is final once best <= (h * slack)^2
+// (slack covers the rounding of the cell arithmetic).  Otherwise the query joins the far list, carrying what it found.
 __global__ __launch_bounds__(kThreads) void nn_grid_kernel(const float *queries, int n2, const GridParams *gp, const int *cell_start,
                                                            const float4 *sorted, int *idx, float *dist, unsigned long long *keys,
-                                                           int *unresolved, int *n_unresolved)
+                                                           int *far_list, int *n_far)
 {
     const GridParams g = *gp;
     const int i = blockIdx.x * kThreads + threadIdx.x;
@@ -318,40 +403,124 @@ __global__ __launch_bounds__(kThreads) void nn_grid_kernel(const float *queries,
     const int cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
     float best = INFINITY;
     int best_i = 0x7FFFFFFF;
-    bool resolved = false;
-    // largest shell that still adds cells
-    const int rmax = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
-    for (int r = 0; r <= kMaxRing; r++) {
-        const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1);
-        const int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
-        const int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
-        for (int z = z0; z <= z1; z++) {
-            const bool zface = (z == cz - r) || (z == cz + r);
-            for (int y = y0; y <= y1; y++) {
-                const int row = (z * g.ny + y) * g.nx;
-                if (zface || y == cy - r || y == cy + r) {
-                    // the whole x-run of this row is new: one contiguous range of the sorted array
-                    scan_range(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, best, best_i);
-                } else {
-                    // only the two end cells are new
-                    if (cx - r >= 0) scan_range(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, best, best_i);
-                    if (cx + r < g.nx && r > 0) scan_range(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, best, best_i);
-                }
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); z++)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); y++)
+            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.nx - 1); x++) {
+                const int c = cell_index(x, y, z, g);
+                scan_range(sorted, cell_start[c], cell_start[c + 1], qx, qy, qz, best, best_i);
             }
-        }
-        const float bound = (float)r * g.h * kBoundSlack;
-        if (best <= bound * bound || r >= rmax) {
-            resolved = true;
-            break;
-        }
-    }
-    if (resolved) {
-        if (best_i == 0x7FFFFFFF) best_i = 0;  // every distance was NaN / the grid was empty: keep the index in range
+    const float bound = g.h * kBoundSlack;
+    if (best <= bound * bound) {
         idx[i] = best_i;
         dist[i] = best;
         if (keys) claim_target(keys, best_i, best, i);
     } else {
-        unresolved[atomicAdd(n_unresolved, 1)] = i;
+        idx[i] = best_i;  // what the neighbourhood offered (0x7FFFFFFF / inf when it was empty): the far pass starts there
+        dist[i] = best;
+        far_list[atomicAdd(n_far, 1)] = i;
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Far queries (compacted list): exact NN through the two-level AABB hierarchy, ONE WAVE PER QUERY -- the hierarchy is
+// 64-ary on purpose: the 64 lanes test 64 super-block boxes at a time, then the 64 block boxes of a super-block in one
+// step, then scan a block's points 64 at a time; (distance, index) pairs are reduced lexicographically with wave
+// shuffles.  Super-blocks are visited nearest-first, so the bound (min of: what the 27-cell scan found, the smallest
+// farthest-corner distance of any box seen, the best point so far) tightens after the first visit and almost every
+// other box is skipped.  A box is skipped only when its exact f32 minimum distance EXCEEDS the bound, so equal-distance
+// candidates are still seen and the lowest index wins, like everywhere else.
+__global__ __launch_bounds__(kThreads) void nn_far_kernel(const float *queries, const GridParams *gp, const int *cell_start,
+                                                          const float4 *sorted, const Box *boxes, const Box *supers, const int *far_list,
+                                                          const int *n_far, int *idx, float *dist, unsigned long long *keys)
+{
+    constexpr int kChunks = kMaxSupers / 64;  // 16
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);  // one query per wave
+    if (slot >= *n_far) return;                                          // wave-uniform
+    const int i = far_list[slot];
+    const int n_supers = gp->ncells / 4096;
+    const float qx = queries[3 * (size_t)i], qy = queries[3 * (size_t)i + 1], qz = queries[3 * (size_t)i + 2];
+    float best = dist[i];  // uniform across the wave from here on
+    int best_i = idx[i];
+
+    // every super-block's minimum distance (lane l holds supers l, 64 + l, ...) and the farthest-corner upper bound
+    float md[kChunks];
+    float ub = INFINITY;
+#pragma unroll
+    for (int c = 0; c < kChunks; c++) {
+        md[c] = INFINITY;
+        const int s = c * 64 + lane;
+        if (c * 64 < n_supers && s < n_supers) {
+            const Box b = supers[s];
+            md[c] = box_min_dist2(qx, qy, qz, b);
+            ub = fminf(ub, box_max_dist2(qx, qy, qz, b));
+        }
+    }
+    float bound = fminf(best, wave_min_f(ub));
+
+    for (int visits = 0; visits <= kMaxSupers; visits++) {
+        // nearest unvisited super-block
+        float m = INFINITY;
+        int mc = 0;
+#pragma unroll
+        for (int c = 0; c < kChunks; c++)
+            if (md[c] < m) {
+                m = md[c];
+                mc = c;
+            }
+        const float wm = wave_min_f(m);
+        if (!(wm <= bound)) break;  // nothing left that could hold a point at distance <= bound (also ends on NaN)
+        const int src = __ffsll((long long)__ballot(m == wm)) - 1;
+        const int s = __shfl(mc, src, 64) * 64 + src;
+#pragma unroll
+        for (int c = 0; c < kChunks; c++)
+            if (lane == src && c == mc) md[c] = INFINITY;  // visited (static indices keep md[] in registers)
+
+        // its 64 blocks, one per lane
+        const Box bb = boxes[s * 64 + lane];
+        const float mb = box_min_dist2(qx, qy, qz, bb);
+        bound = fminf(bound, wave_min_f(box_max_dist2(qx, qy, qz, bb)));
+        unsigned long long cand = __ballot(mb <= bound);
+        float lbest = best;
+        int lbi = best_i;
+        while (cand) {
+            const int b = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const int c0 = (s * 64 + b) * 64;
+            const int e = cell_start[c0 + 64];
+            for (int j = cell_start[c0] + lane; j < e; j += 64) {
+                const float4 p = sorted[j];
+                const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
+                const int k = __float_as_int(p.w);
+                if (d < lbest || (d == lbest && k < lbi)) {
+                    lbest = d;
+                    lbi = k;
+                }
+            }
+        }
+        // lexicographic (distance, index) minimum over the wave; non-negative floats order like their bit patterns
+        const unsigned long long key = wave_min_u64(((unsigned long long)__float_as_uint(lbest) << 32) | (unsigned int)lbi);
+        const float kd = __uint_as_float((unsigned int)(key >> 32));
+        if (kd < best || (kd == best && (int)(unsigned int)key < best_i)) {
+            best = kd;
+            best_i = (int)(unsigned int)key;
+        }
+        bound = fminf(bound, best);
+    }
+    if (lane == 0) {
+        if (best_i == 0x7FFFFFFF) best_i = 0;  // every distance was NaN: keep the index in range
+        idx[i] = best_i;
+        dist[i] = best;
+        if (keys) claim_target(keys, best_i, best, i);
     }
 }
 
@@ -502,7 +671,7 @@ __device__ void svd3(const double A[9], double U[9], double w[3], double V[9])
     double B[9];
     for (int i = 0; i < 9; i++) { B[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
     for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0;
+        int rotations = 0;
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
                 double a = 0, b = 0, c = 0;
@@ -511,8 +680,8 @@ __device__ void svd3(const double A[9], double U[9], double w[3], double V[9])
                     b += B[3 * k + q] * B[3 * k + q];
                     c += B[3 * k + p] * B[3 * k + q];
                 }
-                off += fabs(c);
-                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                if (fabs(c) <= 1e-300 || c * c <= 1e-32 * (a * b)) continue;  // columns already orthogonal to ~1e-16
+                rotations++;
                 const double zeta = (b - a) / (2.0 * c);
                 const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
@@ -525,7 +694,7 @@ __device__ void svd3(const double A[9], double U[9], double w[3], double V[9])
                     V[3 * k + q] = sn * vp + cs * vq;
                 }
             }
-        if (off == 0) break;
+        if (rotations == 0) break;
     }
     for (int j = 0; j < 3; j++) {
         double s = 0;
@@ -656,7 +825,7 @@ struct LsnIcp {
     int device = 0;
     int max_n1 = 0, max_n2 = 0;
     float cell_override = 0.0f;
-    lsn::DevBuf gp, bbox_part, cell_of, cell_cnt, cell_start, block_sums, sorted;
+    lsn::DevBuf gp, bbox_part, cell_of, cell_cnt, cell_start, block_sums, sorted, boxes, supers;
     lsn::DevBuf idx, dist, keys, unresolved, counters, part1, part2, part3, state, trace;
     int trace_iters = 0;
     std::mutex mu;
@@ -687,6 +856,8 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
     bad |= w->cell_start.reserve(sizeof(int) * ((size_t)kMaxCells + kScanBlock)) != 0;
     bad |= w->block_sums.reserve(sizeof(int) * 2048) != 0;
     bad |= w->sorted.reserve(sizeof(float4) * (size_t)max_n1) != 0;
+    bad |= w->boxes.reserve(sizeof(Box) * (size_t)kMaxBlocks3) != 0;
+    bad |= w->supers.reserve(sizeof(Box) * (size_t)kMaxSupers) != 0;
     bad |= w->idx.reserve(sizeof(int) * (size_t)max_n2) != 0;
     bad |= w->dist.reserve(sizeof(float) * (size_t)max_n2) != 0;
     bad |= w->keys.reserve(sizeof(unsigned long long) * (size_t)max_n1) != 0;
@@ -732,6 +903,10 @@ static int build_grid(LsnIcp *w, const float *d_verts1, int n1, hipStream_t s)
                        w->block_sums.as<int>(), w->cell_start.as<int>());
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(kThreads), 0, s, d_verts1, n1, w->cell_of.as<int>(), w->cell_start.as<int>(),
                        w->cell_cnt.as<int>(), w->sorted.as<float4>());
+    hipLaunchKernelGGL(block_box_kernel, dim3(2048), dim3(kThreads), 0, s, (const GridParams *)w->gp.as<GridParams>(),
+                       (const int *)w->cell_start.as<int>(), (const float4 *)w->sorted.as<float4>(), w->boxes.as<Box>());
+    hipLaunchKernelGGL(super_box_kernel, dim3(kMaxSupers), dim3(64), 0, s, (const GridParams *)w->gp.as<GridParams>(),
+                       (const Box *)w->boxes.as<Box>(), w->supers.as<Box>());
     LSN_HIP(hipGetLastError());
     return 0;
 }
@@ -747,9 +922,10 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, const float *d_verts
         LSN_HIP(hipMemsetAsync(n_unres, 0, sizeof(int), s));
         hipLaunchKernelGGL(nn_grid_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts2, n2, w->gp.as<GridParams>(),
                            w->cell_start.as<int>(), w->sorted.as<float4>(), d_idx, d_dist, keys, w->unresolved.as<int>(), n_unres);
-        // fallback for the queries the grid could not prove; workgroups beyond the list length exit at once
-        hipLaunchKernelGGL(nn_brute_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts1, n1, d_verts2, n2,
-                           (const int *)w->unresolved.as<int>(), (const int *)n_unres, d_idx, d_dist, keys);
+        // the queries the neighbourhood scan could not prove; workgroups beyond the list length exit at once
+        hipLaunchKernelGGL(nn_far_kernel, dim3((n2 + 3) / 4), dim3(kThreads), 0, s, d_verts2, (const GridParams *)w->gp.as<GridParams>(),
+                           (const int *)w->cell_start.as<int>(), (const float4 *)w->sorted.as<float4>(), (const Box *)w->boxes.as<Box>(),
+                           (const Box *)w->supers.as<Box>(), (const int *)w->unresolved.as<int>(), (const int *)n_unres, d_idx, d_dist, keys);
     }
     LSN_HIP(hipGetLastError());
     return 0;

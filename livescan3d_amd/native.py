@@ -49,6 +49,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise NativeUtilsError(f"{LIB_PATH} is missing -- run __graft_entry__.build() (there is no CPU fallback)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under the same SONAME as /opt/rocm's.  A
+    # process must run ONE HIP runtime (device pointers handed over by torch have to belong to the runtime that launches
+    # our kernels), and the dynamic loader keeps whichever copy is loaded first -- so when torch is installed it is
+    # imported before the library.  Hosts without torch (LiveScanServer, C/C++ callers) simply get /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

@@ -295,7 +295,7 @@ static void svd3(const double A[9], double U[9], double w[3], double V[9])
     memcpy(B, A, sizeof(B));
     for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0;
+        int rotations = 0;
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
                 double a = 0, b = 0, c = 0;
@@ -304,8 +304,8 @@ static void svd3(const double A[9], double U[9], double w[3], double V[9])
                     b += B[3 * k + q] * B[3 * k + q];
                     c += B[3 * k + p] * B[3 * k + q];
                 }
-                off += fabs(c);
-                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                if (fabs(c) <= 1e-300 || c * c <= 1e-32 * (a * b)) continue;  /* columns orthogonal to ~1e-16 */
+                rotations++;
                 double zeta = (b - a) / (2.0 * c);
                 double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
@@ -318,7 +318,7 @@ static void svd3(const double A[9], double U[9], double w[3], double V[9])
                     V[3 * k + q] = sn * vp + cs * vq;
                 }
             }
-        if (off == 0) break;
+        if (rotations == 0) break;
     }
     for (int j = 0; j < 3; j++) {
         double s = 0;
