@@ -154,3 +154,40 @@ def test_full_size_properties(gpu, mode):
         for k in range(T):
             n = int(off_h[k, -1])
             assert torch.equal(v2[k, :n], first[k, :n])
+
+
+def test_merge_shards_kernel_matches_single_plan(gpu, orc):
+    """The multi-GPU assembly step on one GPU: two sensor blocks fused separately (as two ranks would), their slabs laid
+    out like an all-gather result, packed by lsnMergeShards -> identical to fusing all sensors in one plan (formMesh order)."""
+    import torch
+    from livescan3d_amd.fusion import DeviceFusion
+    T, S, w, h, G = 3, 4, 512, 424, 2
+    mpr = S // G
+    rigs = [synth.make_rig("noise" if k % 2 else "scene", S, w, h, seed=17, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+    P = w * h
+    shard_cap = mpr * P
+    g_verts = torch.zeros((G, T, shard_cap, 16), dtype=torch.uint8, device="cuda")
+    g_off = torch.zeros((G, T, mpr + 1), dtype=torch.int32, device="cuda")
+    for r in range(G):
+        s0, s1 = r * mpr, (r + 1) * mpr
+        fus = DeviceFusion(T, [w] * mpr, [h] * mpr)
+        fus.set_params(rigs[0].intr[7 * s0:7 * s1], rigs[0].wt[12 * s0:12 * s1], rigs[0].bounds)
+        depth = torch.from_numpy(np.stack([rk.depth_maps.view(np.int16)[P * s0:P * s1] for rk in rigs])).cuda()
+        rgb = torch.from_numpy(np.stack([rk.depth_colors[3 * P * s0:3 * P * s1] for rk in rigs])).cuda()
+        v, o = fus.run(depth, rgb)
+        torch.cuda.synchronize()
+        g_verts[r].copy_(v)
+        g_off[r].copy_(o)
+    merged = torch.zeros((T, shard_cap * G, 16), dtype=torch.uint8, device="cuda")
+    merged_off = torch.zeros((T, S + 1), dtype=torch.int32, device="cuda")
+    native.merge_shards(0, G, T, mpr, g_verts.data_ptr(), shard_cap, g_off.data_ptr(), merged.data_ptr(), shard_cap * G,
+                        merged_off.data_ptr(), int(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    mo = merged_off.cpu().numpy()
+    for k in range(T):
+        want, counts = orc.generate_mesh_vertices(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights,
+                                                  rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+        n = int(mo[k, -1])
+        assert n == len(want) and list(np.diff(mo[k])) == list(counts)
+        got = merged[k, :n].cpu().numpy().view(native.VERTEX_DTYPE).reshape(-1)
+        _assert_same(got, want, f"merged tick {k}")

@@ -22,3 +22,22 @@ for d in sorted(glob.glob("$out/*/")):
             print(k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
 PY
 grep -h "algorithmic_bytes" $out/*.log | head -1
+python3 - <<PY
+import csv, glob, json, os
+def avg(counter, kernel):
+    vals = []
+    for f in glob.glob("$out/" + counter + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter: vals.append(float(r["Counter_Value"]))
+    return sum(vals) / len(vals) if vals else None
+kernel = "fuse_kernel<1" if "$mode" == "0" else "run_kernel"
+fetch, write = avg("FETCH_SIZE", kernel), avg("WRITE_SIZE", kernel)
+if fetch is not None and write is not None:
+    path = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_traffic.json")
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    T = int(os.environ.get("PMC_TICKS", "64"))
+    d[f"mode$mode-8x512x424-ticks{T}"] = {"kernel": kernel, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+        "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "note": "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read); WRITE_SIZE as read"}
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+    print("traffic", d)
+PY
