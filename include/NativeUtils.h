@@ -58,8 +58,8 @@ void generateVerticesFromDepthMap(unsigned char *depth_maps, unsigned char *dept
 
 /* Replaces generateMeshFromDepthMaps, include/NativeUtils/depthprocessing.h:108-110
  * (src/NativeUtils/depthprocessing.cpp:1715-1792).  In scope: the vertices of all sensors, cropped, in sensor
- * order then raster order (= the reference with both flags false).  Triangulation (always on in the reference,
- * meshGenerator.cpp) is the first "next" row: until it lands nTriangles = 0 and `triangles` is a valid empty array.
+ * order then raster order, and the triangles of the reference's always-on triangulation (meshGenerator.cpp; indices
+ * into `vertices`, reference order) -- i.e. the reference with both flags false.
  * bcolor_transfer / bgenerate_triangles select reference stages that are out of scope (colour transfer, overlay
  * merge); passing true is reported through lsnGetLastError() and otherwise ignored. */
 void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
@@ -113,6 +113,15 @@ int lsnFusionSetMode(LsnFusion *plan, int mode);
  * [k][n_maps] = nVertices of tick k.  Asynchronous on `stream`; returns 0 on success. */
 int lsnFusionRun(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_colors, void *d_vertices,
                  int *d_offsets, void *stream);
+
+/* The complete merge call: vertices as lsnFusionRun plus the reference's always-on triangulation
+ * (MeshGenerator::generateTrianglesGradients, src/NativeUtils/meshGenerator.cpp:14-181; index rebasing of formMesh,
+ * src/NativeUtils/depthprocessing.cpp:1611-1627).  d_triangles: n_ticks x lsnFusionTickTriangleCapacity() x 3 ints
+ * (vertex indices into the tick's merged cloud, reference order); d_tri_offsets: n_ticks x (n_maps+1) ints like d_offsets
+ * ([k][n_maps] = nTriangles of tick k). */
+long long lsnFusionTickTriangleCapacity(const LsnFusion *plan);
+int lsnFusionRunMesh(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_colors, void *d_vertices, int *d_offsets,
+                     void *d_triangles, int *d_tri_offsets, void *stream);
 
 /* Name and average duration (ms, HIP events on the plan's stream) of the dominant kernel over the launches
  * since the last call with reset != 0; used by bench.py's roofline block.  Enable with lsnFusionProfile(plan,1). */

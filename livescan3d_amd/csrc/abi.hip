@@ -60,7 +60,7 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::map<std::vector<int>, LsnFusion *> plans;  // key: n_maps, widths..., heights...
-    lsn::DevBuf d_depth, d_colors, d_out, d_off, d_v1, d_v2, d_Rt;
+    lsn::DevBuf d_depth, d_colors, d_out, d_off, d_tri, d_tri_off, d_v1, d_v2, d_Rt;
     LsnIcp *icp = nullptr;
     int icp_n1 = 0, icp_n2 = 0;
     // pinned host blocks handed out as Mesh::vertices, recycled by deleteMesh
@@ -142,7 +142,8 @@ void empty_mesh(Ctx &c, Mesh *m)
 // Fuses n_maps sensors of one tick from host buffers into out_mesh.  first/count select the sensors
 // (generateVerticesFromDepthMap uses one).  c.mu held.
 int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
-              const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count)
+              const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count,
+              bool with_triangles)
 {
     std::vector<int> key;
     key.push_back(count);
@@ -178,8 +179,16 @@ int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const u
     LSN_HIP(hipMemcpyAsync(c.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, c.stream));
     LSN_HIP(hipMemcpyAsync(c.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, c.stream));
     if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, c.stream)) return -1;
-    if (lsnFusionRun(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.stream)) return -1;
-    std::vector<int> off(count + 1);
+    std::vector<int> off(count + 1), toff(count + 1, 0);
+    if (with_triangles) {
+        const long long tcap = lsnFusionTickTriangleCapacity(plan);
+        if (c.d_tri.reserve((size_t)tcap * 12) || c.d_tri_off.reserve(sizeof(int) * (count + 1))) return -1;
+        if (lsnFusionRunMesh(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.d_tri.p, c.d_tri_off.as<int>(), c.stream))
+            return -1;
+        LSN_HIP(hipMemcpyAsync(toff.data(), c.d_tri_off.p, sizeof(int) * (count + 1), hipMemcpyDeviceToHost, c.stream));
+    } else {
+        if (lsnFusionRun(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.stream)) return -1;
+    }
     LSN_HIP(hipMemcpyAsync(off.data(), c.d_off.p, sizeof(int) * (count + 1), hipMemcpyDeviceToHost, c.stream));
     LSN_HIP(hipStreamSynchronize(c.stream));
     const int nv = off[count];
@@ -187,18 +196,34 @@ int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const u
         lsn::set_error("NativeUtils: device returned an impossible vertex count %d", nv);
         return -1;
     }
+    const int nt = toff[count];
+    if (nt < 0 || nt > 2 * cap) {
+        lsn::set_error("NativeUtils: device returned an impossible triangle count %d", nt);
+        return -1;
+    }
     void *host = pinned_get(c, (size_t)nv * sizeof(VertexC4ubV3f));
     if (!host) return -1;
-    if (nv > 0) {
-        LSN_HIP(hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, c.stream));
-        LSN_HIP(hipStreamSynchronize(c.stream));
+    void *host_tri = nullptr;
+    if (nt > 0) {
+        host_tri = pinned_get(c, (size_t)nt * 12);
+        if (!host_tri) {
+            pinned_put(c, host);
+            return -1;
+        }
     }
+    if (nv > 0) LSN_HIP(hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, c.stream));
+    if (nt > 0) LSN_HIP(hipMemcpyAsync(host_tri, c.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, c.stream));
+    if (nv > 0 || nt > 0) LSN_HIP(hipStreamSynchronize(c.stream));
     out->nVertices = nv;
     out->vertices = static_cast<VertexC4ubV3f *>(host);
-    out->nTriangles = 0;
-    int *tri = (int *)malloc(sizeof(int));
-    out->triangles = tri;
-    if (tri) c.live_tri[tri] = 1;
+    out->nTriangles = nt;
+    if (nt > 0) {
+        out->triangles = static_cast<int *>(host_tri);
+    } else {
+        int *tri = (int *)malloc(sizeof(int));  // "new int[0]": valid, never dereferenced (KinectServer.cs:344-345)
+        out->triangles = tri;
+        if (tri) c.live_tri[tri] = 1;
+    }
     return 0;
 }
 
@@ -219,7 +244,7 @@ extern "C" void generateVerticesFromDepthMap(unsigned char *depth_maps, unsigned
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
     if (ensure_ready(c) || fuse_host(c, depth_map_index + 1, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params,
-                                     out_mesh, b, depth_map_index, 1))
+                                     out_mesh, b, depth_map_index, 1, false))
         empty_mesh(c, out_mesh);
 }
 
@@ -238,7 +263,7 @@ extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps,
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
     if (ensure_ready(c) ||
-        fuse_host(c, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps)) {
+        fuse_host(c, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps, true)) {
         empty_mesh(c, out_mesh);
         return;
     }
@@ -263,6 +288,8 @@ extern "C" void deleteMesh(Mesh *mesh)
         if (it != c.live_tri.end()) {
             c.live_tri.erase(it);
             free(mesh->triangles);
+        } else {
+            pinned_put(c, mesh->triangles);  // a pinned block of ours, or not ours at all (then left alone)
         }
     }
     if (mesh->vertices) pinned_put(c, mesh->vertices);

@@ -49,7 +49,14 @@ struct FrameDesc {
     long long depth_off;         // u16 elements from the tick's depth base
     long long rgb_off;           // bytes from the tick's colour base
     int xtab_off, ytab_off;      // this sensor's rows of the unprojection tables (floats)
-    int pad0, pad1;
+    float inv_w;                 // 1 / w, for the (corrected, exact) float division of small pixel offsets
+    int pad1;
+};
+
+struct TileDesc {  // one per tile of a tick
+    int frame;     // sensor-frame the tile belongs to
+    int x0, y0;    // column / row of the tile's first pixel (host-computed: no integer division on the device)
+    int pad;
 };
 
 struct SensorParams {  // 16 floats, wave-uniform -> scalar loads
@@ -60,7 +67,7 @@ struct SensorParams {  // 16 floats, wave-uniform -> scalar loads
 
 struct FuseArgs {
     const FrameDesc *frames;
-    const unsigned short *tile_frame;  // tile (within tick) -> frame
+    const TileDesc *tiles;             // tile (within tick) -> frame and first-pixel coordinates
     const SensorParams *params;
     const float *xtab;  // [(x - cx) / fx] per sensor column
     const float *ytab;  // [(cy - y) / fy] per sensor row
@@ -71,6 +78,7 @@ struct FuseArgs {
     unsigned long long *run_state;   // mode 1: [n_ticks * tiles_per_tick] {flag:2 | value}, indexed by run
     unsigned int *ticket;            // mode 1: per-tick run tickets, 32 words apart
     int *offsets;                    // [n_ticks][n_frames + 1]
+    int *pixmap;                     // optional [n_ticks][pixels per tick]: vertex index inside the tick's cloud, -1 = none
     int *error_flag;                 // mode 1: set when a bounded spin gives up (sticky until read)
     int n_frames;
     int tiles_per_tick;
@@ -134,6 +142,20 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
     return v;
 }
 
+// Number of survivors among the lower lanes of the wave, and in the whole wave, straight from the keep predicates'
+// lane masks: v_mbcnt per mask for the lanes below, s_bcnt1 (SALU) for the total -- no shuffles, no per-lane counters.
+__device__ __forceinline__ void rank_from_masks(const bool (&keep)[kPxPerLane], int &below, int &wave_total)
+{
+    below = 0;
+    wave_total = 0;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) {
+        const unsigned long long m = __ballot(keep[k]);
+        below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, below));
+        wave_total += __popcll(m);
+    }
+}
+
 __device__ __forceinline__ int wave_sum(int v)
 {
 #pragma unroll
@@ -144,7 +166,10 @@ __device__ __forceinline__ int wave_sum(int v)
 // ---- one tile: where it is, its inputs, its arithmetic --------------------------------------------------------
 
 struct Tile {  // wave-uniform (SGPRs)
+    long long pix_base;      // index of the frame's first pixel inside its tick (= depth_off)
     int f, w, h, npix, px0;  // frame, its size, first pixel of the tile inside the frame
+    int x0, y0;              // that pixel's column / row
+    float inv_w;
     bool frame_start;
     const unsigned short *dptr;
     const unsigned char *cptr;
@@ -154,8 +179,13 @@ struct Tile {  // wave-uniform (SGPRs)
 __device__ __forceinline__ Tile locate(const FuseArgs &a, int tick, int tile)
 {
     Tile t;
-    t.f = a.tile_frame[tile];
+    const TileDesc td = a.tiles[tile];
+    t.f = td.frame;
+    t.x0 = td.x0;
+    t.y0 = td.y0;
     const FrameDesc fd = a.frames[t.f];
+    t.inv_w = fd.inv_w;
+    t.pix_base = fd.depth_off;
     t.w = fd.w;
     t.h = fd.h;
     t.npix = fd.npix;
@@ -219,8 +249,15 @@ __device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, c
     const SensorParams P = a.params[t.f];
     const int p0 = t.px0 + threadIdx.x * kPxPerLane;
     const bool in_frame = p0 < t.npix;
-    int y = in_frame ? p0 / t.w : 0;
-    int x = in_frame ? p0 - y * t.w : 0;
+    // (x, y) of the lane's first pixel: the tile starts at (x0, y0) and the lane is v = x0 + 8*tid < w + 2048 columns
+    // further; v / w by a float multiply and an exact +-1 correction (v < 2^23, so the estimate is off by at most one).
+    const int v = t.x0 + (int)threadIdx.x * kPxPerLane;
+    int q = (int)((float)v * t.inv_w);
+    int x = v - q * t.w;
+    if (x < 0) { q--; x += t.w; }
+    if (x >= t.w) { q++; x -= t.w; }
+    int y = t.y0 + q;
+    if (!in_frame) { x = 0; y = 0; }
     float yfac = t.yt[y];
     float xf[kPxPerLane], yf[kPxPerLane];
     if (VEC) {
@@ -313,11 +350,9 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     uint4 vert[kPxPerLane];
     compute_tile<VEC, kWrite>(a, t, in, keep, vert);
 
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) cnt += keep[k] ? 1 : 0;
-    const int incl = wave_inclusive_scan(cnt, lane);
-    if (lane == 63) s_wave_tot[wave] = incl;
+    int below, wave_total;
+    rank_from_masks(keep, below, wave_total);
+    if (lane == 0) s_wave_tot[wave] = wave_total;
     int base = 0;
     if (MODE == 1) base = a.tile_counts[blockIdx.x];  // scan_kernel left the exclusive prefix inside the tick here
     __syncthreads();
@@ -332,7 +367,30 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
         if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = tile_tot;
         return;
     }
-    stage_and_store(stage, keep, vert, wave_off + incl - cnt, tile_tot, a.out + tick * a.tick_vert_stride + base);
+    if (a.pixmap) {
+        // depth_to_vertices_map (depthprocessing.cpp:166), already rebased to the tick's merged cloud like formMesh
+        // rebases triangle indices (:1614-1626): what the triangulation pass reads
+        const int p0 = t.px0 + threadIdx.x * kPxPerLane;
+        if (p0 < t.npix) {
+            int *pm = a.pixmap + tick * a.tick_depth_stride + t.pix_base + p0;
+            int r = base + wave_off + below;
+            int v[kPxPerLane];
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) {
+                v[k] = keep[k] ? r : -1;
+                r += keep[k] ? 1 : 0;
+            }
+            if (VEC) {
+                reinterpret_cast<int4 *>(pm)[0] = make_int4(v[0], v[1], v[2], v[3]);
+                reinterpret_cast<int4 *>(pm)[1] = make_int4(v[4], v[5], v[6], v[7]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kPxPerLane; k++)
+                    if (p0 + k < t.npix) pm[k] = v[k];
+            }
+        }
+    }
+    stage_and_store(stage, keep, vert, wave_off + below, tile_tot, a.out + tick * a.tick_vert_stride + base);
 }
 
 // Mode 0, between the count and the write launch: one workgroup per tick turns that tick's tile counts into exclusive
@@ -486,11 +544,9 @@ __global__ __launch_bounds__(kThreads) void run_kernel(const FuseArgs a)
         bool keep[kPxPerLane];
         uint4 vert[kPxPerLane];
         compute_tile<VEC, true>(a, t, in, keep, vert);
-        int cnt = 0;
-#pragma unroll
-        for (int k = 0; k < kPxPerLane; k++) cnt += keep[k] ? 1 : 0;
-        const int incl = wave_inclusive_scan(cnt, lane);
-        if (lane == 63) s_wave_tot[wave] = incl;
+        int below, wave_tot2;
+        rank_from_masks(keep, below, wave_tot2);
+        if (lane == 0) s_wave_tot[wave] = wave_tot2;
         __syncthreads();
         int wave_off = 0, tile_tot = 0;
 #pragma unroll
@@ -501,7 +557,7 @@ __global__ __launch_bounds__(kThreads) void run_kernel(const FuseArgs a)
         }
         if (threadIdx.x == 0 && t.frame_start) off[t.f] = running;
         if (tile_tot > 0) {
-            stage_and_store(stage, keep, vert, wave_off + incl - cnt, tile_tot, a.out + tick * a.tick_vert_stride + running);
+            stage_and_store(stage, keep, vert, wave_off + below, tile_tot, a.out + tick * a.tick_vert_stride + running);
         } else {
             __syncthreads();  // s_wave_tot is rewritten by the next tile
         }
@@ -510,6 +566,235 @@ __global__ __launch_bounds__(kThreads) void run_kernel(const FuseArgs a)
         in = nx;
     }
     if (threadIdx.x == 0 && t1 == a.tiles_per_tick) off[a.n_frames] = running;
+}
+
+
+// ---- triangulation (the "next" row after the vertex path) --------------------------------------------------------
+//
+// Replaces MeshGenerator::generateTrianglesGradients (src/NativeUtils/meshGenerator.cpp:14-181, driver
+// depthprocessing.cpp:1659-1691) and formMesh's triangle part (:1611-1627).  Per pixel with a vertex, a 2x2 stencil
+// (P, U = up, UR = up-right, R = right) yields up to two triangles after depth-continuity tests that also look one
+// step further along every edge; the reference's 4 row-band threads concatenated in order are plain raster order over
+// y in [2, h-2), x in [1, w-2).  Same structure as the vertex path: count -> scan_kernel -> write, 8 pixels per lane,
+// the 4 x 11 depth window and the 2 x 9 index window of a lane live in registers.  All integer arithmetic.
+
+struct TriArgs {
+    const FrameDesc *frames;
+    const TileDesc *tiles;
+    const unsigned short *depth;
+    const int *pixmap;   // [n_ticks][pixels per tick]
+    int *tri;            // [n_ticks][tri_cap][3]
+    int *tile_counts;    // [n_ticks * tiles_per_tick] counts, then exclusive prefixes (scan_kernel)
+    int tiles_per_tick;
+    long long tick_pix_stride;  // pixels per tick
+    long long tick_tri_stride;  // triangles per tick (capacity)
+};
+
+constexpr int kTriWin = 1536;  // triangles staged per LDS round (18 KB)
+
+// MeshGenerator::checkTriangleConstraints (meshGenerator.cpp:14-61) on a pixel's 4 x 4 depth window W[dy + 2][dx + 1],
+// dx in [-1, 2], dy in [-2, 1]; the three corners are compile-time offsets, so are the forward / backward probes.
+// depth_thr = (int)((v0 + v1 + v2) / 3.0 * 0.00272 + 7.273) (:26, double) equals (272 s + 2181900) / 300000 in integers
+// for EVERY possible sum s of three u16 -- proven exhaustively in tests/test_fast_division.py.
+template <int X1, int Y1, int X2, int Y2>
+__device__ __forceinline__ bool edge_ok(const int (&W)[4][4], int thr)
+{
+    const int val1 = W[Y1 + 2][X1 + 1], val2 = W[Y2 + 2][X2 + 1];
+    if (abs(val1 - val2) < thr) return true;                                  // :35-36
+    constexpr int SX = X2 - X1, SY = Y2 - Y1;
+    const int val_forward = W[Y2 + SY + 2][X2 + SX + 1];                      // :39-40
+    if (val_forward != 0 && abs(val2 - val1 - (val_forward - val2)) < thr) return true;    // :42-47
+    const int val_backward = W[Y1 - SY + 2][X1 - SX + 1];                     // :50
+    if (val_backward != 0 && abs(val2 - val1 - (val1 - val_backward)) < thr) return true;  // :51-56
+    return false;
+}
+
+template <int X1, int Y1, int X2, int Y2, int X3, int Y3>
+__device__ __forceinline__ bool tri_ok(const int (&W)[4][4])
+{
+    const int v0 = W[Y1 + 2][X1 + 1], v1 = W[Y2 + 2][X2 + 1], v2 = W[Y3 + 2][X3 + 1];
+    if (v0 == 0 || v1 == 0 || v2 == 0) return false;                          // :22-23
+    const int thr = (272 * (v0 + v1 + v2) + 2181900) / 300000;
+    return edge_ok<X1, Y1, X2, Y2>(W, thr) && edge_ok<X2, Y2, X3, Y3>(W, thr) && edge_ok<X3, Y3, X1, Y1>(W, thr);
+}
+
+// Which of the four candidate triangles of a pixel are emitted: bit i = triangle i of meshGenerator.cpp:101-104
+// (0: R,U,P  1: R,UR,U  2: P,UR,U  3: P,R,UR), after the vertex-index checks of :133-134.
+__device__ __forceinline__ unsigned int pixel_triangles(const int (&W)[4][4], int mP, int mU, int mUR, int mR)
+{
+    if (mP == -1) return 0;                                                   // :113-114
+    const bool t0 = tri_ok<0, 0, 0, -1, 1, 0>(W);                             // :117
+    const bool t1 = tri_ok<1, 0, 0, -1, 1, -1>(W);                            // :118
+    bool t2 = false, t3 = false;
+    if (!t0 && !t1) {
+        t2 = tri_ok<0, 0, 0, -1, 1, -1>(W);                                   // :122
+        t3 = tri_ok<0, 0, 1, -1, 1, 0>(W);                                    // :123
+    }
+    unsigned int m = 0;
+    if (t0 && mR != -1 && mU != -1) m |= 1u;
+    if (t1 && mR != -1 && mUR != -1 && mU != -1) m |= 2u;
+    if (t2 && mUR != -1 && mU != -1) m |= 4u;
+    if (t3 && mR != -1 && mUR != -1) m |= 8u;
+    return m;
+}
+
+// MODE 0 = count triangles per tile, 1 = write them at the scanned offsets.
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(kThreads) void tri_kernel(const TriArgs a)
+{
+    __shared__ int stage[MODE == 1 ? 3 * kTriWin : 1];
+    __shared__ int s_wave_tot[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tick = blockIdx.x / a.tiles_per_tick;
+    const int tile = blockIdx.x - tick * a.tiles_per_tick;
+    const TileDesc td = a.tiles[tile];
+    const FrameDesc fd = a.frames[td.frame];
+    const int w = fd.w, h = fd.h;
+    const unsigned short *dep = a.depth + tick * a.tick_pix_stride + fd.depth_off;
+    const int *map = a.pixmap + tick * a.tick_pix_stride + fd.depth_off;
+    const int p0 = (tile - fd.tile_start) * kTile + threadIdx.x * kPxPerLane;
+    const bool in_frame = p0 < fd.npix;
+
+    // (x, y) of the lane's first pixel, as in compute_tile
+    const int v = td.x0 + (int)threadIdx.x * kPxPerLane;
+    int q = (int)((float)v * fd.inv_w);
+    int x0 = v - q * w;
+    if (x0 < 0) { q--; x0 += w; }
+    if (x0 >= w) { q++; x0 -= w; }
+    int y0 = td.y0 + q;
+    if (!in_frame) { x0 = 0; y0 = 0; }
+
+    unsigned int code = 0;      // 4 bits per pixel: which triangles it emits
+    int M[2][kPxPerLane + 1];   // vertex indices: row y-1 (U, UR) and row y (P, R), columns x0 .. x0+8
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c <= kPxPerLane; c++) M[r][c] = -1;
+
+    if (VEC) {
+        // w % 8 == 0: the 8 pixels share row y0; window rows y0-2 .. y0+1, columns x0-1 .. x0+9
+        const bool row_ok = in_frame && y0 >= 2 && y0 < h - 2;   // :87-90 (bands clamp to [2, h-2))
+        if (row_ok) {
+            int D[4][kPxPerLane + 3];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned short *row = dep + (long long)(y0 - 2 + r) * w;
+                const uint4 c = *reinterpret_cast<const uint4 *>(row + x0);
+                const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
+                D[r][0] = x0 > 0 ? row[x0 - 1] : 0;
+#pragma unroll
+                for (int k = 0; k < kPxPerLane; k++) D[r][1 + k] = (cw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                unsigned int right = 0;
+                if (x0 + 8 < w) right = *reinterpret_cast<const unsigned int *>(row + x0 + 8);
+                D[r][9] = right & 0xFFFFu;
+                D[r][10] = right >> 16;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int *mrow = map + (long long)(y0 - 1 + r) * w + x0;
+                const int4 m0 = reinterpret_cast<const int4 *>(mrow)[0], m1 = reinterpret_cast<const int4 *>(mrow)[1];
+                M[r][0] = m0.x; M[r][1] = m0.y; M[r][2] = m0.z; M[r][3] = m0.w;
+                M[r][4] = m1.x; M[r][5] = m1.y; M[r][6] = m1.z; M[r][7] = m1.w;
+                M[r][8] = x0 + 8 < w ? mrow[8] : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) {
+                const int x = x0 + k;
+                if (x >= 1 && x < w - 2) {                                     // :87-90
+                    int W[4][4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) W[r][c] = D[r][k + c];
+                    code |= pixel_triangles(W, M[1][k], M[0][k], M[0][k + 1], M[1][k + 1]) << (4 * k);
+                }
+            }
+        }
+    } else {
+        // general widths: a lane's pixels may span rows; every pixel fetches its own 4 x 4 window
+        int x = x0, y = y0;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            if (p0 + k < fd.npix && y >= 2 && y < h - 2 && x >= 1 && x < w - 2) {
+                int W[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) W[r][c] = dep[(long long)(y - 2 + r) * w + (x - 1 + c)];
+                const long long p = (long long)y * w + x;
+                M[1][k] = map[p];            // P
+                M[0][k] = map[p - w];        // U
+                // UR / R of this pixel are kept in the slots the VEC path would use only when they do not collide:
+                // the general path re-reads them at emission time instead (see below), the code word is what counts
+                code |= pixel_triangles(W, map[p], map[p - w], map[p - w + 1], map[p + 1]) << (4 * k);
+            }
+            x++;
+            if (x == w) { x = 0; y++; }
+        }
+    }
+
+    // ---- ranks ---------------------------------------------------------------------------------------------------
+    const int cnt = __popc(code);
+    const int incl = wave_inclusive_scan(cnt, lane);
+    if (lane == 63) s_wave_tot[wave] = incl;
+    int base = 0;
+    if (MODE == 1) base = a.tile_counts[blockIdx.x];
+    __syncthreads();
+    int wave_off = 0, tile_tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int t = s_wave_tot[i];
+        if (i < wave) wave_off += t;
+        tile_tot += t;
+    }
+    if (MODE == 0) {
+        if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = tile_tot;
+        return;
+    }
+
+    // ---- stage in rank order, copy out coalesced (triangles_shifts order, meshGenerator.cpp:101-104) ------------------
+    int *dst = a.tri + 3 * (tick * a.tick_tri_stride + base);
+    const int rank0 = wave_off + incl - cnt;
+    for (int w0 = 0; w0 < tile_tot; w0 += kTriWin) {
+        int r = rank0 - w0;
+        int x = x0, y = y0;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            const unsigned int m = (code >> (4 * k)) & 15u;
+            if (m) {
+                int mP, mU, mUR, mR;
+                if (VEC) {
+                    mP = M[1][k]; mU = M[0][k]; mUR = M[0][k + 1]; mR = M[1][k + 1];
+                } else {
+                    const long long p = (long long)y * w + x;
+                    mP = map[p]; mU = map[p - w]; mUR = map[p - w + 1]; mR = map[p + 1];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (m & (1u << i)) {
+                        if ((unsigned int)r < (unsigned int)kTriWin) {
+                            const int i0 = i == 0 ? mR : (i == 1 ? mR : mP);
+                            const int i1 = i == 0 ? mU : (i == 1 ? mUR : (i == 2 ? mUR : mR));
+                            const int i2 = i == 0 ? mP : (i == 1 ? mU : (i == 2 ? mU : mUR));
+                            stage[3 * r] = i0;
+                            stage[3 * r + 1] = i1;
+                            stage[3 * r + 2] = i2;
+                        }
+                        r++;
+                    }
+                }
+            }
+            if (!VEC) {
+                x++;
+                if (x == w) { x = 0; y++; }
+            }
+        }
+        __syncthreads();
+        const int n = 3 * min(kTriWin, tile_tot - w0);
+        for (int i = threadIdx.x; i < n; i += kThreads) dst[3 * w0 + i] = stage[i];
+        __syncthreads();
+    }
 }
 
 // Fills a sensor's unprojection tables with the reference's own operations (depthprocessing.cpp:151-152):
@@ -575,9 +860,11 @@ struct LsnFusion {
     bool params_set = false;
     int mode = 0;
     int tiles_per_run_override = 0;  // $LSN_TILES_PER_RUN (tuning / tests)
+    bool want_pixmap = false;        // set by lsnFusionRunMesh around its vertex pass
     float bounds[6] = {0, 0, 0, 0, 0, 0};
     lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: error flag (word 0) + tickets
     lsn::DevBuf xtab, ytab;
+    lsn::DevBuf pixmap, tri_counts;  // triangulation scratch, allocated on first use
     // dominant-kernel timing
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -594,10 +881,6 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
         lsn::set_error("lsnFusionCreate: bad arguments (n_ticks=%d n_maps=%d)", n_ticks, n_maps);
         return nullptr;
     }
-    if (n_maps > 65535) {
-        lsn::set_error("lsnFusionCreate: at most 65535 sensors");
-        return nullptr;
-    }
     LSN_HIP_NULL(hipSetDevice(device));
     LsnFusion *p = new (std::nothrow) LsnFusion();
     if (!p) return nullptr;
@@ -606,7 +889,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
     p->n_ticks = n_ticks;
     p->n_maps = n_maps;
     std::vector<FrameDesc> fr(n_maps);
-    std::vector<unsigned short> tf;
+    std::vector<TileDesc> tf;
     long long doff = 0, coff = 0;
     int tiles = 0, xoff = 0, yoff = 0;
     bool vec = true;
@@ -627,11 +910,20 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
         fr[i].rgb_off = coff;
         fr[i].xtab_off = xoff;
         fr[i].ytab_off = yoff;
-        fr[i].pad0 = fr[i].pad1 = 0;
+        fr[i].pad1 = 0;
         xoff += (widths[i] + 7) & ~7;  // keeps every sensor's row 32-B aligned for the float4 loads
         yoff += heights[i];
         const int nt = (npix + kTile - 1) / kTile;
-        for (int t = 0; t < nt; t++) tf.push_back((unsigned short)i);
+        fr[i].inv_w = 1.0f / (float)widths[i];
+        for (int t = 0; t < nt; t++) {
+            const long long px = (long long)t * kTile;
+            TileDesc td;
+            td.frame = i;
+            td.y0 = (int)(px / widths[i]);
+            td.x0 = (int)(px % widths[i]);
+            td.pad = 0;
+            tf.push_back(td);
+        }
         tiles += nt;
         doff += npix;
         coff += 3ll * npix;
@@ -654,7 +946,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
         return nullptr;
     }
     const size_t n_tiles_total = (size_t)tiles * n_ticks;
-    if (p->frames.reserve(sizeof(FrameDesc) * n_maps) || p->tile_frame.reserve(sizeof(unsigned short) * tf.size()) ||
+    if (p->frames.reserve(sizeof(FrameDesc) * n_maps) || p->tile_frame.reserve(sizeof(TileDesc) * tf.size()) ||
         p->params.reserve(sizeof(SensorParams) * n_maps) || p->tile_counts.reserve(sizeof(int) * n_tiles_total) ||
         p->tile_state.reserve(sizeof(unsigned long long) * n_tiles_total) || p->misc.reserve(128 * ((size_t)n_ticks + 1)) ||
         p->xtab.reserve(sizeof(float) * (size_t)(xoff + 8)) || p->ytab.reserve(sizeof(float) * (size_t)(yoff + 8))) {
@@ -667,7 +959,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
         return nullptr;
     }
     if (hipMemcpy(p->frames.p, fr.data(), sizeof(FrameDesc) * n_maps, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(p->tile_frame.p, tf.data(), sizeof(unsigned short) * tf.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(p->tile_frame.p, tf.data(), sizeof(TileDesc) * tf.size(), hipMemcpyHostToDevice) != hipSuccess) {
         lsn::set_error("lsnFusionCreate: geometry upload failed");
         delete p;
         return nullptr;
@@ -795,7 +1087,7 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
 
     FuseArgs a;
     a.frames = p->frames.as<FrameDesc>();
-    a.tile_frame = p->tile_frame.as<unsigned short>();
+    a.tiles = p->tile_frame.as<TileDesc>();
     a.params = p->params.as<SensorParams>();
     a.xtab = p->xtab.as<float>();
     a.ytab = p->ytab.as<float>();
@@ -807,6 +1099,7 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
     a.error_flag = p->misc.as<int>();
     a.ticket = p->misc.as<unsigned int>() + 32;
     a.offsets = d_offsets;
+    a.pixmap = p->want_pixmap ? p->pixmap.as<int>() : nullptr;
     a.n_frames = p->n_maps;
     a.tiles_per_tick = p->tiles_per_tick;
     a.n_ticks = p->n_ticks;
@@ -850,7 +1143,7 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         p->ev_used++;
     }
 
-    if (p->mode == 0) {
+    if (p->mode == 0 || p->want_pixmap) {
         launch<0>(vec, grid, s, a);
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
                            a.offsets);
@@ -866,6 +1159,52 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         else     hipLaunchKernelGGL((run_kernel<false>), dim3(rgrid), dim3(kThreads), 0, s, a);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
     }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" long long lsnFusionTickTriangleCapacity(const LsnFusion *p) { return p ? 2 * p->cap : 0; }
+
+extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+                                void *d_triangles, int *d_tri_offsets, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !d_triangles || !d_tri_offsets) {
+        lsn::set_error("lsnFusionRunMesh: null argument");
+        return -1;
+    }
+    {
+        std::lock_guard<std::mutex> g(p->mu);
+        LSN_HIP(hipSetDevice(p->device));
+        if (p->pixmap.reserve(sizeof(int) * (size_t)p->cap * p->n_ticks) ||
+            p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks))
+            return -1;
+        p->want_pixmap = true;
+    }
+    // vertices + depth_to_vertices_map (count / scan / write launches)
+    const int rc = lsnFusionRun(p, d_depth, d_colors, d_vertices, d_offsets, stream);
+    std::lock_guard<std::mutex> g(p->mu);
+    p->want_pixmap = false;
+    if (rc) return rc;
+    hipStream_t s = lsn::as_stream(stream);
+    TriArgs t;
+    t.frames = p->frames.as<FrameDesc>();
+    t.tiles = p->tile_frame.as<TileDesc>();
+    t.depth = static_cast<const unsigned short *>(d_depth);
+    t.pixmap = p->pixmap.as<int>();
+    t.tri = static_cast<int *>(d_triangles);
+    t.tile_counts = p->tri_counts.as<int>();
+    t.tiles_per_tick = p->tiles_per_tick;
+    t.tick_pix_stride = p->cap;
+    t.tick_tri_stride = 2 * p->cap;
+    const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && (p->tick_depth_elems % 8) == 0;
+    const int grid = p->tiles_per_tick * p->n_ticks;
+    if (vec) hipLaunchKernelGGL((tri_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, t);
+    else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, t.tile_counts, t.tiles_per_tick, t.frames, p->n_maps,
+                       d_tri_offsets);
+    if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), 0, s, t);
+    else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), 0, s, t);
     LSN_HIP(hipGetLastError());
     return 0;
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
-    "lsnFusionRun", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
+    "lsnFusionRun", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace",
 ]
 
@@ -90,6 +90,10 @@ def lib():
     L.lsnFusionSetMode.argtypes = [vp, C.c_int]
     L.lsnFusionRun.restype = C.c_int
     L.lsnFusionRun.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.lsnFusionRunMesh.restype = C.c_int
+    L.lsnFusionRunMesh.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.lsnFusionTickTriangleCapacity.restype = C.c_longlong
+    L.lsnFusionTickTriangleCapacity.argtypes = [vp]
     L.lsnFusionProfile.restype = C.c_int
     L.lsnFusionProfile.argtypes = [vp, C.c_int]
     L.lsnFusionKernelStats.restype = C.c_int
@@ -155,9 +159,9 @@ def _copy_mesh(mesh):
     else:
         verts = np.zeros(0, dtype=VERTEX_DTYPE)
     ntri = mesh.nTriangles
-    tris = np.zeros(0, dtype=np.int32)
+    tris = np.zeros((0, 3), dtype=np.int32)
     if ntri > 0:
-        tris = np.frombuffer(C.string_at(mesh.triangles, ntri * 12), dtype=np.int32).copy()
+        tris = np.frombuffer(C.string_at(mesh.triangles, ntri * 12), dtype=np.int32).reshape(-1, 3).copy()
     lib().deleteMesh(C.byref(mesh))
     return verts, tris
 
@@ -243,6 +247,11 @@ class FusionPlan:
     def run(self, d_depth, d_colors, d_vertices, d_offsets, stream=0):
         """All four are device pointers (ints); asynchronous on `stream` (a hipStream_t as int, 0 = null stream)."""
         _check(lib().lsnFusionRun(self._h, d_depth, d_colors, d_vertices, d_offsets, stream), "lsnFusionRun")
+
+    def run_mesh(self, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream=0):
+        """Vertices + triangles (the reference's complete merge call); d_triangles: n_ticks x 2*capacity x 3 int32."""
+        _check(lib().lsnFusionRunMesh(self._h, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream),
+               "lsnFusionRunMesh")
 
     def lookback_failed(self, stream=0):
         return int(lib().lsnFusionLookbackFailed(self._h, stream))

@@ -132,6 +132,101 @@ int orc_generate_vertices_from_depth_map(const uint8_t *depth_maps, const uint8_
 }
 
 /* ------------------------------------------------------------------------------------------
+ * triangulation
+ * ---------------------------------------------------------------------------------------- */
+
+/* MeshGenerator::checkTriangleConstraints, src/NativeUtils/meshGenerator.cpp:14-61.
+ * p1,p2,p3 are linear pixel positions inside `depth`. */
+static int tri_ok(const uint16_t *depth, long p1, long p2, long p3)
+{
+    const int vals[3] = {depth[p1], depth[p2], depth[p3]};
+    const long ptrs[3] = {p1, p2, p3};
+    static const int pairs_1[3] = {0, 1, 2};
+    static const int pairs_2[3] = {1, 2, 0};
+    if (vals[0] == 0 || vals[1] == 0 || vals[2] == 0) return 0;                         /* :22-23 */
+    /* :26  (int)((v0+v1+v2) / 3.0 * 0.00272 + 7.273), evaluated in double */
+    const int depth_thr = (int)((vals[0] + vals[1] + vals[2]) / 3.0 * 0.00272 + 7.273);
+    for (int tr = 0; tr < 3; tr++) {
+        const int ind1 = pairs_1[tr], ind2 = pairs_2[tr];
+        const int val1 = vals[ind1], val2 = vals[ind2];
+        if (abs(val1 - val2) < depth_thr) continue;                                      /* :35-36 */
+        const long shift = ptrs[ind2] - ptrs[ind1];                                      /* :39 */
+        const int val_forward = depth[ptrs[ind2] + shift];                               /* :40 */
+        if (val_forward != 0) {
+            const int gradient_forward = val_forward - val2;
+            if (abs(val2 - val1 - gradient_forward) < depth_thr) continue;               /* :44-46 */
+        }
+        const int val_backward = depth[ptrs[ind1] - shift];                              /* :50 */
+        if (val_backward != 0) {
+            const int gradient_backward = val1 - val_backward;
+            if (abs(val2 - val1 - gradient_backward) < depth_thr) continue;              /* :53-55 */
+        }
+        return 0;                                                                        /* :57 */
+    }
+    return 1;
+}
+
+long orc_generate_triangles(const uint16_t *depth, const int *pix_to_vert, int w, int h, int index_base, int *out)
+{
+    /* generateTrianglesGradientsRegion, meshGenerator.cpp:77-144, with the 4 row bands of :147-181 run back to back:
+     * every band clamps to y in [max(.,2), min(.,h-2)) and x in [1, w-2), bands tile [0,h) in order. */
+    long n = 0;
+    const int sh_up = -w, sh_upright = -w + 1, sh_right = 1;                              /* :93 pixel_shifts */
+    const int tshift[12] = {sh_right, sh_up, 0,   sh_right, sh_upright, sh_up,           /* :101-104 triangles_shifts */
+                            0, sh_upright, sh_up, 0, sh_right, sh_upright};
+    for (int y = 2; y < h - 2; y++) {
+        for (int x = 1; x < w - 2; x++) {
+            const long p = (long)y * w + x;
+            if (pix_to_vert[p] == -1) continue;                                           /* :113-114 */
+            int tr[4] = {0, 0, 0, 0};
+            tr[0] = tri_ok(depth, p, p + sh_up, p + sh_right);                            /* :117 */
+            tr[1] = tri_ok(depth, p + sh_right, p + sh_up, p + sh_upright);               /* :118 */
+            if (!tr[0] && !tr[1]) {
+                tr[2] = tri_ok(depth, p, p + sh_up, p + sh_upright);                      /* :122 */
+                tr[3] = tri_ok(depth, p, p + sh_upright, p + sh_right);                   /* :123 */
+            }
+            for (int i = 0; i < 4; i++) {
+                if (!tr[i]) continue;
+                const int m1 = pix_to_vert[p + tshift[i * 3]];
+                const int m2 = pix_to_vert[p + tshift[i * 3 + 1]];
+                const int m3 = pix_to_vert[p + tshift[i * 3 + 2]];
+                if (m1 == -1 || m2 == -1 || m3 == -1) continue;                           /* :133-134 */
+                out[3 * n] = m1 + index_base;
+                out[3 * n + 1] = m2 + index_base;
+                out[3 * n + 2] = m3 + index_base;
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+long orc_generate_mesh(int n_maps, const uint8_t *depth_maps, const uint8_t *depth_colors,
+                       const int *widths, const int *heights, const float *intr, const float *wt,
+                       const float *bounds6, orc_vertex *out, int *per_map_counts, int *out_tri, long *n_triangles)
+{
+    long dpos = 0, cpos = 0, nv = 0, nt = 0;
+    long maxpix = 1;
+    for (int i = 0; i < n_maps; i++) if ((long)widths[i] * heights[i] > maxpix) maxpix = (long)widths[i] * heights[i];
+    int *p2v = (int *)malloc(sizeof(int) * (size_t)maxpix);
+    for (int i = 0; i < n_maps; i++) {
+        const long np = (long)widths[i] * heights[i];
+        const uint16_t *d = (const uint16_t *)(depth_maps + dpos);
+        const int c = orc_create_vertices(d, depth_colors + cpos, widths[i], heights[i], intr + 7 * i, wt + 12 * i, bounds6,
+                                          out + nv, NULL, p2v);
+        /* generateTriangles :1659-1691 on this sensor, then formMesh's index rebase :1614-1626 (act_vertices = nv) */
+        nt += orc_generate_triangles(d, p2v, widths[i], heights[i], (int)nv, out_tri + 3 * nt);
+        if (per_map_counts) per_map_counts[i] = c;
+        nv += c;
+        dpos += np * 2;
+        cpos += np * 3;
+    }
+    free(p2v);
+    if (n_triangles) *n_triangles = nt;
+    return nv;
+}
+
+/* ------------------------------------------------------------------------------------------
  * exact nearest neighbour
  * ---------------------------------------------------------------------------------------- */
 

@@ -59,6 +59,24 @@ int orc_generate_vertices_from_depth_map(const uint8_t *depth_maps, const uint8_
                                          const float *intr, const float *wt, const float *bounds6,
                                          int depth_map_index, orc_vertex *out);
 
+/* MeshGenerator::generateTrianglesGradients, src/NativeUtils/meshGenerator.cpp:14-181 (driver
+ * generateTriangles, src/NativeUtils/depthprocessing.cpp:1659-1691): 2x2-stencil triangulation of ONE sensor.
+ * depth = the sensor's depth map (VerticesWithDepthColorMaps::depth_map, a copy of the input, depthprocessing.cpp:180),
+ * pix_to_vert = depth_to_vertices_map (-1 = no vertex).  The reference splits the rows over 4 threads and concatenates
+ * the bands in order, which is plain raster order over y in [2,h-2), x in [1,w-2).  index_base is added to every
+ * index (formMesh rebases by the cumulative vertex count, depthprocessing.cpp:1611-1627).
+ * out must hold 2*w*h triangles (3 ints each).  Returns the number of triangles.
+ * PARITY UNPINNED: meshGenerator.cpp compiles only together with depthprocessing.h (needs <windows.h> stand-ins) and the
+ * reference holds no golden vectors for it. */
+long orc_generate_triangles(const uint16_t *depth, const int *pix_to_vert, int w, int h, int index_base, int *out);
+
+/* generateMeshFromDepthMaps with flags (false,false), complete: vertices (as orc_generate_mesh_vertices) AND the
+ * always-on triangulation (depthprocessing.cpp:1786) with rebased indices.  out_tri must hold 2*sum(w*h)*3 ints.
+ * Returns nVertices; *n_triangles receives nTriangles. */
+long orc_generate_mesh(int n_maps, const uint8_t *depth_maps, const uint8_t *depth_colors,
+                       const int *widths, const int *heights, const float *intr, const float *wt,
+                       const float *bounds6, orc_vertex *out, int *per_map_counts, int *out_tri, long *n_triangles);
+
 /* Exact 1-NN, squared L2 evaluated as (d0*d0 + d1*d1) + d2*d2 in f32
  * (include/NativeUtils/icp.h:40-47; query loop src/NativeUtils/icp.cpp:18-32).
  * Ties (equal f32 distance) resolve to the LOWEST target index -- nanoflann's tie

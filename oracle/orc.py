@@ -47,6 +47,10 @@ def lib():
         L.orc_generate_mesh_vertices.argtypes = [C.c_int, p, p, p, p, p, p, p, p, p, C.c_int]
         L.orc_generate_vertices_from_depth_map.restype = C.c_int
         L.orc_generate_vertices_from_depth_map.argtypes = [p, p, p, p, p, p, p, C.c_int, p]
+        L.orc_generate_triangles.restype = C.c_long
+        L.orc_generate_triangles.argtypes = [p, p, C.c_int, C.c_int, C.c_int, p]
+        L.orc_generate_mesh.restype = C.c_long
+        L.orc_generate_mesh.argtypes = [C.c_int, p, p, p, p, p, p, p, p, p, p, p]
         for f in (L.orc_nn_brute, L.orc_nn_kdtree):
             f.restype = None
             f.argtypes = [p, C.c_int, p, C.c_int, p, p, C.c_int]
@@ -105,6 +109,35 @@ def generate_mesh_vertices(depth_maps, depth_colors, widths, heights, intr, wt, 
     n = lib().orc_generate_mesh_vertices(n_maps, _ptr(depth_maps), _ptr(depth_colors), _ptr(widths), _ptr(heights),
                                          _ptr(intr), _ptr(wt), _ptr(bounds6), _ptr(out), _ptr(counts), n_threads)
     return out[:n].copy(), counts[:n_maps].copy()
+
+
+def generate_triangles(depth, pix_to_vert, index_base=0):
+    """generateTrianglesGradients for one sensor.  depth (h,w) u16, pix_to_vert (h*w) int32.  Returns int32 [n,3]."""
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    h, w = depth.shape
+    p2v = np.ascontiguousarray(pix_to_vert, dtype=np.int32).ravel()
+    assert p2v.size == h * w
+    out = np.zeros((2 * h * w, 3), dtype=np.int32)
+    n = lib().orc_generate_triangles(_ptr(depth), _ptr(p2v), w, h, int(index_base), _ptr(out))
+    return out[:n].copy()
+
+
+def generate_mesh(depth_maps, depth_colors, widths, heights, intr, wt, bounds6):
+    """generateMeshFromDepthMaps (flags false,false) with the always-on triangulation.
+    Returns (vertices, per_map_counts, triangles int32 [n,3])."""
+    widths, heights = _i32(widths), _i32(heights)
+    n_maps = len(widths)
+    depth_maps = np.ascontiguousarray(depth_maps).view(np.uint8).ravel()
+    depth_colors = np.ascontiguousarray(depth_colors, dtype=np.uint8).ravel()
+    total = int(np.sum(widths.astype(np.int64) * heights))
+    out = np.zeros(max(total, 1), dtype=VERTEX_DTYPE)
+    counts = np.zeros(max(n_maps, 1), dtype=np.int32)
+    tri = np.zeros((max(2 * total, 1), 3), dtype=np.int32)
+    nt = C.c_long(0)
+    intr, wt, bounds6 = _f32(intr, 7 * n_maps), _f32(wt, 12 * n_maps), _f32(bounds6, 6)
+    n = lib().orc_generate_mesh(n_maps, _ptr(depth_maps), _ptr(depth_colors), _ptr(widths), _ptr(heights), _ptr(intr), _ptr(wt),
+                                _ptr(bounds6), _ptr(out), _ptr(counts), _ptr(tri), C.byref(nt))
+    return out[:n].copy(), counts[:n_maps].copy(), tri[:nt.value].copy()
 
 
 def generate_vertices_from_depth_map(depth_maps, depth_colors, widths, heights, intr, wt, bounds6, index):

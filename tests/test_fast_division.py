@@ -32,3 +32,12 @@ def test_three_instruction_quotient_is_exact_for_every_u16_depth():
         e = rn32(D - Fraction(float(q0)) * 1000)
         q = rn32(Fraction(float(q0)) + Fraction(float(e)) * R)
         assert q == want, d
+
+
+def test_integer_triangle_threshold_equals_the_double_expression():
+    """csrc/fusion.hip computes checkTriangleConstraints' depth_thr (src/NativeUtils/meshGenerator.cpp:26,
+    (int)((v0+v1+v2) / 3.0 * 0.00272 + 7.273) in double) as (272 s + 2181900) / 300000 in integers: equal for every
+    possible sum s of three u16 depths."""
+    s = np.arange(0, 3 * 65535 + 1, dtype=np.int64)
+    ref = np.floor(s.astype(np.float64) / 3.0 * 0.00272 + 7.273).astype(np.int64)   # truncation = floor (positive)
+    assert np.array_equal((272 * s + 2181900) // 300000, ref)

@@ -28,11 +28,15 @@ def test_export_generate_mesh_matches_oracle(gpu, orc, kind, n, w, h):
     rig = synth.make_rig(kind, n, w, h, seed=3)
     verts, tris = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights,
                                                        rig.intr, rig.wt, rig.bounds)
-    want, counts = _oracle_cloud(orc, rig)
+    want, counts, want_tri = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
     assert len(want) > 0 and len(want) < rig.widths.astype(np.int64) @ rig.heights   # crop and validity both bite
     _assert_same(verts, want, f"{kind} {n}x{w}x{h}")
-    assert tris.size == 0
     assert (verts["A"] == 255).all()
+    # the always-on triangulation (meshGenerator.cpp): same triangles, same order, indices into the merged cloud
+    assert tris.shape == want_tri.shape, (tris.shape, want_tri.shape)
+    assert np.array_equal(tris, want_tri)
+    if kind == "scene":
+        assert len(want_tri) > len(want) // 2
 
 
 def test_export_single_sensor_matches_oracle(gpu, orc):
@@ -55,10 +59,11 @@ def test_ragged_sizes_and_unaligned_rows(gpu, orc):
         R, t = synth.ring_pose(s, 5)
         wt.append(synth.pack_pose(R, t))
     rig = synth.Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), [-1.0, -1.2, -1.5, 1.3, 1.1, 1.6])
-    verts, _ = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights,
-                                                    rig.intr, rig.wt, rig.bounds)
-    want, _ = _oracle_cloud(orc, rig)
+    verts, tris = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights,
+                                                       rig.intr, rig.wt, rig.bounds)
+    want, _, want_tri = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
     _assert_same(verts, want, "ragged")
+    assert np.array_equal(tris, want_tri)
 
 
 def test_edge_cases_empty_full_and_nan(gpu, orc):
@@ -191,3 +196,54 @@ def test_merge_shards_kernel_matches_single_plan(gpu, orc):
         assert n == len(want) and list(np.diff(mo[k])) == list(counts)
         got = merged[k, :n].cpu().numpy().view(native.VERTEX_DTYPE).reshape(-1)
         _assert_same(got, want, f"merged tick {k}")
+
+
+def test_triangulation_on_smooth_and_stepped_surfaces(gpu, orc):
+    """Depth ramps, steps at the linearity thresholds, holes and image borders: every branch of checkTriangleConstraints
+    (absolute, forward-linear, backward-linear, reject) and both triangle pairs, sizes with w % 8 == 0 and != 0."""
+    rng = np.random.default_rng(12)
+    for (w, h) in [(64, 48), (61, 37), (512, 424)]:
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = 1200 + 3 * xx + 2 * yy                                   # smooth ramp: mostly triangles 0 and 1
+        steps = base + 40 * ((xx // 7) % 2) + 25 * ((yy // 5) % 2)       # jumps around the 10..12 mm thresholds
+        lin = 1000 + 14 * xx + 11 * yy                                  # steep but linear: the forward/backward rules pass
+        holes = steps.copy(); holes[rng.random((h, w)) < 0.08] = 0
+        noise = base + rng.integers(-9, 10, size=(h, w))
+        for name, d in (("ramp", base), ("steps", steps), ("linear", lin), ("holes", holes), ("noise", noise)):
+            depth = np.clip(d, 0, 65535).astype(np.uint16)
+            rgb = synth.noise_frame(1, 0, 0, w, h)[1]
+            rig = synth.Rig([depth], [rgb], synth.kinect_intrinsics(w, h), synth.pack_pose(*synth.ring_pose(0, 1)), synth.DEFAULT_BOUNDS)
+            verts, tris = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+            want, _, want_tri = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+            _assert_same(verts, want, f"{name} {w}x{h}")
+            assert np.array_equal(tris, want_tri), f"{name} {w}x{h}: {tris.shape} vs {want_tri.shape}"
+            if name in ("ramp", "linear") and w <= 64:
+                assert len(want_tri) > 1.5 * (w - 4) * (h - 5)      # a smooth surface inside the bounds: ~2 triangles per pixel
+
+
+def test_device_resident_mesh_batch(gpu, orc):
+    """lsnFusionRunMesh on T ticks x N sensors resident in HBM: vertices, triangles and both offset tables."""
+    import torch
+    T, N, w, h = 3, 3, 512, 424
+    rigs = [synth.make_rig("scene", N, w, h, seed=8, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+    plan = native.FusionPlan(0, T, rigs[0].widths, rigs[0].heights)
+    plan.set_params(rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda()
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()
+    cap = plan.capacity
+    verts = torch.zeros((T, cap, 16), dtype=torch.uint8, device="cuda")
+    off = torch.zeros((T, N + 1), dtype=torch.int32, device="cuda")
+    tri = torch.zeros((T, 2 * cap, 3), dtype=torch.int32, device="cuda")
+    toff = torch.zeros((T, N + 1), dtype=torch.int32, device="cuda")
+    plan.run_mesh(depth.data_ptr(), rgb.data_ptr(), verts.data_ptr(), off.data_ptr(), tri.data_ptr(), toff.data_ptr(),
+                  int(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    off_h, toff_h = off.cpu().numpy(), toff.cpu().numpy()
+    for k in range(T):
+        want, counts, want_tri = orc.generate_mesh(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights,
+                                                   rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+        nv, nt = int(off_h[k, -1]), int(toff_h[k, -1])
+        assert nv == len(want) and nt == len(want_tri)
+        assert verts[k, :nv].cpu().numpy().tobytes() == want.tobytes()
+        assert np.array_equal(tri[k, :nt].cpu().numpy(), want_tri)
+        assert (np.diff(toff_h[k]) >= 0).all() and toff_h[k, 0] == 0

@@ -1,0 +1,93 @@
+"""The oracle's triangulation (oracle/lsn_oracle.c::orc_generate_triangles) against an independent pure-Python
+restatement of MeshGenerator::generateTrianglesGradients (src/NativeUtils/meshGenerator.cpp:14-181), including the
+4-thread row-band split the reference uses (:147-181), on small frames.  PARITY UNPINNED (no reference build, no
+reference fixtures): what is pinned is agreement of two independent restatements + committed digests."""
+import numpy as np
+import pytest
+
+from livescan3d_amd import synth
+
+
+def py_check(depth, p1, p2, p3):
+    vals = [int(depth[p1]), int(depth[p2]), int(depth[p3])]
+    ptrs = [p1, p2, p3]
+    if 0 in vals:
+        return False
+    thr = int((vals[0] + vals[1] + vals[2]) / 3.0 * 0.00272 + 7.273)
+    for a, b in ((0, 1), (1, 2), (2, 0)):
+        v1, v2 = vals[a], vals[b]
+        if abs(v1 - v2) < thr:
+            continue
+        shift = ptrs[b] - ptrs[a]
+        vf = int(depth[ptrs[b] + shift])
+        if vf != 0 and abs(v2 - v1 - (vf - v2)) < thr:
+            continue
+        vb = int(depth[ptrs[a] - shift])
+        if vb != 0 and abs(v2 - v1 - (v1 - vb)) < thr:
+            continue
+        return False
+    return True
+
+
+def py_region(depth, p2v, w, h, min_y, max_y, out):
+    min_x, max_x = 1, w - 2
+    min_y, max_y = max(min_y, 2), min(max_y, h - 2)
+    up, upright, right = -w, -w + 1, 1
+    tshift = [(right, up, 0), (right, upright, up), (0, upright, up), (0, right, upright)]
+    for y in range(min_y, max_y):
+        for x in range(min_x, max_x):
+            p = y * w + x
+            if p2v[p] == -1:
+                continue
+            tr = [py_check(depth, p, p + up, p + right), py_check(depth, p + right, p + up, p + upright), False, False]
+            if not tr[0] and not tr[1]:
+                tr[2] = py_check(depth, p, p + up, p + upright)
+                tr[3] = py_check(depth, p, p + upright, p + right)
+            for i in range(4):
+                if tr[i]:
+                    m = [int(p2v[p + s]) for s in tshift[i]]
+                    if -1 not in m:
+                        out.append(m)
+
+
+def py_triangles(depth2d, p2v):
+    h, w = depth2d.shape
+    depth = depth2d.ravel()
+    out = []
+    step, pos = h // 4 + 1, 0                       # generateTrianglesGradients :147-181: 4 bands, concatenated in order
+    for _ in range(4):
+        size = min(step, h - pos)
+        py_region(depth, p2v, w, h, pos, pos + size, out)
+        pos += size
+    return np.array(out, dtype=np.int32).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("w,h", [(40, 30), (33, 21), (64, 9), (5, 5), (8, 4)])
+def test_c_oracle_equals_python_restatement(orc, w, h):
+    rng = np.random.default_rng(w * 100 + h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for name, d in (("ramp", 1500 + 4 * xx + 3 * yy),
+                    ("steps", 1500 + 4 * xx + 35 * ((xx // 5) % 2) + 28 * ((yy // 4) % 2)),
+                    ("noise", 1500 + rng.integers(-14, 15, size=(h, w))),
+                    ("holes", np.where(rng.random((h, w)) < 0.1, 0, 1400 + 9 * xx + 7 * yy))):
+        depth = np.clip(d, 0, 65535).astype(np.uint16)
+        rgb = synth.noise_frame(2, 0, 0, w, h)[1]
+        intr, wt = synth.kinect_intrinsics(w, h), synth.pack_pose(*synth.ring_pose(0, 1))
+        v, v2p, p2v = orc.create_vertices(depth, rgb, intr, wt, [-0.4, -5, -5, 0.5, 5, 5], want_maps=True)
+        got = orc.generate_triangles(depth, p2v, index_base=7)
+        want = py_triangles(depth, p2v)
+        assert got.shape == want.shape, name
+        assert np.array_equal(got, want + 7 if len(want) else want), name
+
+
+def test_generate_mesh_rebases_indices_per_sensor(orc):
+    rig = synth.make_rig("scene", 3, 96, 80, seed=5)
+    v, counts, tri = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    v2, counts2 = orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    assert v.tobytes() == v2.tobytes() and list(counts) == list(counts2)
+    assert len(tri) > 0 and tri.min() >= 0 and tri.max() < len(v)
+    # a triangle never mixes sensors (formMesh rebases each sensor's triangles by its own vertex offset, :1614-1626)
+    edges = np.concatenate([[0], np.cumsum(counts)])
+    sensor_of = np.searchsorted(edges, tri, side="right") - 1
+    assert (sensor_of[:, 0] == sensor_of[:, 1]).all() and (sensor_of[:, 1] == sensor_of[:, 2]).all()
+    assert (np.diff(sensor_of[:, 0]) >= 0).all()                         # sensor-major order
