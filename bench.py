@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--no-mesh", action="store_true")
     ap.add_argument("--icp-reps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -192,6 +193,29 @@ def main():
                 "kernel_launches": kstats["launches"],
             },
         }
+
+    # ---- the complete merge call incl. the reference's always-on triangulation (extra field, never `value`) --------
+    if rank == 0 and world == 1 and not args.no_mesh:
+        cap = fus.capacity
+        tri = torch.empty((B, 2 * cap, 3), dtype=torch.int32, device=dev)
+        toff = torch.zeros((B, S_loc + 1), dtype=torch.int32, device=dev)
+
+        def mesh_step():
+            fus.plan.run_mesh(depth.data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(), tri.data_ptr(),
+                              toff.data_ptr(), stream)
+        for _ in range(2):
+            mesh_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.steps // 4)):
+            mesh_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        result["mesh"] = {"frames_per_s": B * max(3, args.steps // 4) / dt,
+                          "triangles_per_tick": float(toff[:, -1].float().mean().item()),
+                          "note": "vertices + triangulation (meshGenerator.cpp) per tick on the same noise inputs; hash-noise depth "
+                                  "exercises every rejection branch but yields few triangles"}
+        del tri, toff
 
     # ---- drop-in export on host buffers (PCIe-inclusive; never `value`) -----------------------------------------
     if rank == 0 and not args.no_host_path:

@@ -67,6 +67,12 @@ void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps, unsigned c
                                bool bcolor_transfer, float minX, float minY, float minZ, float maxX, float maxY,
                                float maxZ, bool bgenerate_triangles);
 
+/* Replaces depthMapAndColorSetRadialCorrection, include/NativeUtils/depthprocessing.h:111
+ * (src/NativeUtils/depthprocessing.cpp:191-261,1794-1815): radial-distortion correction of every sensor's depth map and
+ * colours, in place in the caller's host arrays (forward warp, last writer wins; raster-order in-place hole closing). */
+void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
+                                         int *heights, float *intr_params);
+
 /* Replaces createMesh / deleteMesh, src/NativeUtils/depthprocessing.cpp:1818-1835.  deleteMesh releases the two
  * arrays only (not the struct) and, unlike the reference, also nulls them so a second call is harmless. */
 Mesh *createMesh(void);
@@ -122,6 +128,10 @@ int lsnFusionRun(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_
 long long lsnFusionTickTriangleCapacity(const LsnFusion *plan);
 int lsnFusionRunMesh(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_colors, void *d_vertices, int *d_offsets,
                      void *d_triangles, int *d_tri_offsets, void *stream);
+
+/* Radial correction of n_ticks x n_maps frames in place in HBM (same layouts as lsnFusionRun's inputs);
+ * intr_params: host, 7 floats per sensor {cx,cy,fx,fy,r2,r4,r6}. */
+int lsnFusionRadialCorrect(LsnFusion *plan, const float *intr_params, void *d_depth_maps, void *d_depth_colors, void *stream);
 
 /* Name and average duration (ms, HIP events on the plan's stream) of the dominant kernel over the launches
  * since the last call with reset != 0; used by bench.py's roofline block.  Enable with lsnFusionProfile(plan,1). */

@@ -139,28 +139,33 @@ void empty_mesh(Ctx &c, Mesh *m)
     if (tri) c.live_tri[tri] = 1;
 }
 
+// The cached single-tick plan for sensors [first, first + count) of a call.  c.mu held.
+LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, int count)
+{
+    std::vector<int> key;
+    key.push_back(count);
+    for (int i = 0; i < count; i++) key.push_back(widths[first + i]);
+    for (int i = 0; i < count; i++) key.push_back(heights[first + i]);
+    auto it = c.plans.find(key);
+    if (it != c.plans.end()) return it->second;
+    LsnFusion *plan = lsnFusionCreate(c.device, 1, count, widths + first, heights + first);
+    if (!plan) return nullptr;
+    if (c.plans.size() > 64) {  // unbounded variety of geometries: start over
+        for (auto &kv : c.plans) lsnFusionDestroy(kv.second);
+        c.plans.clear();
+    }
+    c.plans[key] = plan;
+    return plan;
+}
+
 // Fuses n_maps sensors of one tick from host buffers into out_mesh.  first/count select the sensors
 // (generateVerticesFromDepthMap uses one).  c.mu held.
 int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
               const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count,
               bool with_triangles)
 {
-    std::vector<int> key;
-    key.push_back(count);
-    for (int i = 0; i < count; i++) key.push_back(widths[first + i]);
-    for (int i = 0; i < count; i++) key.push_back(heights[first + i]);
-    LsnFusion *plan = nullptr;
-    auto it = c.plans.find(key);
-    if (it != c.plans.end()) plan = it->second;
-    else {
-        plan = lsnFusionCreate(c.device, 1, count, widths + first, heights + first);
-        if (!plan) return -1;
-        if (c.plans.size() > 64) {  // unbounded variety of geometries: start over
-            for (auto &kv : c.plans) lsnFusionDestroy(kv.second);
-            c.plans.clear();
-        }
-        c.plans[key] = plan;
-    }
+    LsnFusion *plan = get_plan(c, widths, heights, first, count);
+    if (!plan) return -1;
     // sensor `first` starts after the frames before it (depthprocessing.cpp:1646-1650)
     size_t dskip = 0, cskip = 0, dbytes = 0, cbytes = 0;
     for (int i = 0; i < first; i++) {
@@ -270,6 +275,43 @@ extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps,
     if (bcolor_transfer || bgenerate_triangles)
         lsn::set_error("generateMeshFromDepthMaps: colour transfer / overlay merge are outside this library's scope; "
                        "returned the cropped vertices of all sensors (flags false,false behaviour)");
+}
+
+extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
+                                                    int *heights, float *intr_params)
+{
+    lsn::clear_error();
+    if (n_maps <= 0 || !depth_maps || !depth_colors || !widths || !heights || !intr_params) {
+        if (n_maps != 0) lsn::set_error("depthMapAndColorSetRadialCorrection: bad arguments");
+        return;
+    }
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (ensure_ready(c)) return;
+    LsnFusion *plan = get_plan(c, widths, heights, 0, n_maps);
+    if (!plan) return;
+    size_t dbytes = 0, cbytes = 0;
+    for (int i = 0; i < n_maps; i++) {
+        dbytes += (size_t)widths[i] * heights[i] * 2;
+        cbytes += (size_t)widths[i] * heights[i] * 3;
+    }
+    if (c.d_depth.reserve(dbytes + 16) || c.d_colors.reserve(cbytes + 16)) return;
+    if (hipMemcpyAsync(c.d_depth.p, depth_maps, dbytes, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
+        hipMemcpyAsync(c.d_colors.p, depth_colors, cbytes, hipMemcpyHostToDevice, c.stream) != hipSuccess) {
+        lsn::set_error("depthMapAndColorSetRadialCorrection: upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return;
+    }
+    if (lsnFusionRadialCorrect(plan, intr_params, c.d_depth.p, c.d_colors.p, c.stream)) return;
+    // the caller's arrays are only overwritten once everything has worked
+    std::vector<unsigned char> hd(dbytes), hc(cbytes);
+    if (hipMemcpyAsync(hd.data(), c.d_depth.p, dbytes, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+        hipMemcpyAsync(hc.data(), c.d_colors.p, cbytes, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+        hipStreamSynchronize(c.stream) != hipSuccess) {
+        lsn::set_error("depthMapAndColorSetRadialCorrection: download failed: %s", hipGetErrorString(hipGetLastError()));
+        return;
+    }
+    memcpy(depth_maps, hd.data(), dbytes);
+    memcpy(depth_colors, hc.data(), cbytes);
 }
 
 extern "C" Mesh *createMesh(void)

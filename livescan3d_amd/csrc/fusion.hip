@@ -797,6 +797,132 @@ __global__ __launch_bounds__(kThreads) void tri_kernel(const TriArgs a)
     }
 }
 
+
+// ---- radial correction (the step before the fusion path on every tick) ---------------------------------------------
+//
+// Replaces depthMapAndColorRadialCorrection (src/NativeUtils/depthprocessing.cpp:191-261) and its export (:1794-1815):
+//   1. forward warp of every valid pixel to (x_corr, y_corr); the reference's raster-order loop lets the LAST source
+//      pixel win a collision -> atomicMax of the source index per destination, then a gather;
+//   2. hole closing, which the reference does IN PLACE in raster order: a pixel filled earlier in the pass is seen by
+//      its right / lower neighbours.  Those dependencies (left, up-left, up, up-right) are honoured exactly by a skewed
+//      wavefront: one thread per row, row y runs two columns behind row y-1, one workgroup barrier per step.
+// All arithmetic in the reference's order (contraction off); (int) follows the x86-64 cvttss2si the reference is built
+// with: NaN / out-of-range -> INT_MIN, which then fails the >= 0 test.
+
+struct RadialParams { float cx, cy, fx, fy, r2, r4, r6, pad; };
+
+__device__ __forceinline__ int f2i_x86(float v)
+{
+    return (v > -2147483904.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+}
+
+__global__ __launch_bounds__(kThreads) void radial_warp_kernel(const FrameDesc *frames, const TileDesc *tiles, const RadialParams *rp,
+                                                               const unsigned short *depth, unsigned int *winner, int tiles_per_tick,
+                                                               long long tick_pix_stride)
+{
+    const int tick = blockIdx.x / tiles_per_tick;
+    const int tile = blockIdx.x - tick * tiles_per_tick;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const RadialParams P = rp[td.frame];
+    const unsigned short *dep = depth + tick * tick_pix_stride + fd.depth_off;
+    unsigned int *win = winner + tick * tick_pix_stride + fd.depth_off;
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {  // consecutive lanes -> consecutive pixels
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        if (dep[p] == 0) continue;                                             // :202-203
+        const int y = p / fd.w, x = p - y * fd.w;
+        const float u = ((float)x - P.cx) / P.fx;                              // :204
+        const float v = ((float)y - P.cy) / P.fy;                              // :205
+        const float r = u * u + v * v;                                         // :206
+        const float d = 1 - P.r2 * r - P.r4 * r * r - P.r6 * r * r * r;        // :207
+        const int x_corr = f2i_x86(u * d * P.fx + P.cx);                       // :209
+        const int y_corr = f2i_x86(v * d * P.fy + P.cy);                       // :210
+        if (x_corr >= 0 && y_corr >= 0 && x_corr < fd.w && y_corr < fd.h)      // :212
+            atomicMax(&win[x_corr + (long long)y_corr * fd.w], (unsigned int)p + 1u);  // later source pixel wins (:214-215)
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void radial_gather_kernel(const FrameDesc *frames, const TileDesc *tiles, const unsigned short *depth,
+                                                                 const unsigned char *rgb, const unsigned int *winner,
+                                                                 unsigned short *map_copy, unsigned char *colors_copy, int tiles_per_tick,
+                                                                 long long tick_pix_stride)
+{
+    const int tick = blockIdx.x / tiles_per_tick;
+    const int tile = blockIdx.x - tick * tiles_per_tick;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const long long fb = tick * tick_pix_stride + fd.depth_off;
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        const unsigned int wsrc = winner[fb + p];
+        unsigned short d = 0;
+        unsigned char c0 = 0, c1 = 0, c2 = 0;
+        if (wsrc) {
+            const long long s = fb + (long long)(wsrc - 1u);
+            d = depth[s];
+            c0 = rgb[3 * s]; c1 = rgb[3 * s + 1]; c2 = rgb[3 * s + 2];
+        }
+        map_copy[fb + p] = d;
+        colors_copy[3 * (fb + p)] = c0;
+        colors_copy[3 * (fb + p) + 1] = c1;
+        colors_copy[3 * (fb + p) + 2] = c2;
+    }
+}
+
+// One workgroup per sensor-frame, one thread per row (bands of blockDim rows when h is larger).  At step t the thread of
+// row y handles column x = t - 2 (y - band0): the pixels it reads from row y-1 (x-1, x, x+1) were finished at least one
+// barrier ago, its own left neighbour one step ago, everything to the right and below is still original -- exactly the
+// state the reference's raster-order in-place loop sees (:223-256).
+__global__ __launch_bounds__(1024) void radial_close_kernel(const FrameDesc *frames, int n_frames, unsigned short *map_copy,
+                                                            unsigned char *colors_copy, long long tick_pix_stride)
+{
+    const int tick = blockIdx.x / n_frames;
+    const int f = blockIdx.x - tick * n_frames;
+    const FrameDesc fd = frames[f];
+    const int w = fd.w, h = fd.h;
+    unsigned short *map = map_copy + tick * tick_pix_stride + fd.depth_off;
+    unsigned char *col = colors_copy + 3 * (tick * tick_pix_stride + fd.depth_off);
+    const int shifts[8] = {-w - 1, -w, -w + 1, -1, 1, w - 1, w, w + 1};       // :224
+    const int rows = blockDim.x;
+    for (int band0 = 1; band0 < h - 1; band0 += rows) {
+        const int r = threadIdx.x;
+        const int y = band0 + r;
+        const int steps = (w - 2) + 2 * (rows - 1);
+        for (int t = 0; t < steps; t++) {
+            const int x = 1 + t - 2 * r;
+            if (y < h - 1 && x >= 1 && x < w - 1) {
+                const long long pos = x + (long long)y * w;
+                if (map[pos] == 0) {                                           // :232-234
+                    int n = 0, sum = 0, sR = 0, sG = 0, sB = 0, prev_val = -1;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int mv = map[pos + shifts[i]];
+                        if (mv > 0 && (prev_val == -1 || abs(mv - prev_val) < 30)) {   // :241
+                            prev_val = mv;
+                            n++;
+                            sum += mv;
+                            sR += col[(pos + shifts[i]) * 3];
+                            sG += col[(pos + shifts[i]) * 3 + 1];
+                            sB += col[(pos + shifts[i]) * 3 + 2];
+                        }
+                    }
+                    if (n > 4) {                                               // :250-256
+                        map[pos] = (unsigned short)(sum / n);
+                        col[pos * 3] = (unsigned char)(sR / n);
+                        col[pos * 3 + 1] = (unsigned char)(sG / n);
+                        col[pos * 3 + 2] = (unsigned char)(sB / n);
+                    }
+                }
+            }
+            __syncthreads();  // workgroup-scope release/acquire: the next step sees this step's fills
+        }
+    }
+}
+
 // Fills a sensor's unprojection tables with the reference's own operations (depthprocessing.cpp:151-152):
 // xtab[x] = (float(x) - cx) / fx, ytab[y] = (cy - float(y)) / fy -- IEEE subtraction and correctly rounded division.
 __global__ __launch_bounds__(kThreads) void table_kernel(const FrameDesc *frames, const SensorParams *params, int n_frames, float *xtab,
@@ -865,6 +991,7 @@ struct LsnFusion {
     lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: error flag (word 0) + tickets
     lsn::DevBuf xtab, ytab;
     lsn::DevBuf pixmap, tri_counts;  // triangulation scratch, allocated on first use
+    lsn::DevBuf winner, map_copy, colors_copy, radial;  // radial-correction scratch, allocated on first use
     // dominant-kernel timing
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1206,6 +1333,49 @@ extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d
     if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), 0, s, t);
     else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), 0, s, t);
     LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, void *d_depth, void *d_colors, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !intr_params || !d_depth || !d_colors) {
+        lsn::set_error("lsnFusionRadialCorrect: null argument");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    hipStream_t s = lsn::as_stream(stream);
+    const size_t npix = (size_t)p->cap * p->n_ticks;
+    if (p->winner.reserve(4 * npix) || p->map_copy.reserve(2 * npix) || p->colors_copy.reserve(3 * npix) ||
+        p->radial.reserve(sizeof(RadialParams) * p->n_maps))
+        return -1;
+    std::vector<RadialParams> rp(p->n_maps);
+    for (int i = 0; i < p->n_maps; i++) {
+        const float *ip = intr_params + 7 * i;  // IntrinsicCameraParameters(float*), include/NativeUtils/depthprocessing.h:96-97
+        rp[i] = RadialParams{ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], 0.0f};
+    }
+    LSN_HIP(hipMemcpyAsync(p->radial.p, rp.data(), sizeof(RadialParams) * p->n_maps, hipMemcpyHostToDevice, s));
+    LSN_HIP(hipStreamSynchronize(s));  // rp is a local
+    LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * npix, s));
+    const int grid = p->tiles_per_tick * p->n_ticks;
+    hipLaunchKernelGGL(radial_warp_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                       p->radial.as<RadialParams>(), static_cast<const unsigned short *>(d_depth), p->winner.as<unsigned int>(),
+                       p->tiles_per_tick, p->cap);
+    hipLaunchKernelGGL(radial_gather_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                       static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors),
+                       (const unsigned int *)p->winner.as<unsigned int>(), p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(),
+                       p->tiles_per_tick, p->cap);
+    int max_h = 1;
+    for (int v : p->h) max_h = v > max_h ? v : max_h;
+    int rows = max_h - 2 < 64 ? 64 : ((max_h - 2 + 63) / 64) * 64;
+    if (rows > 1024) rows = 1024;
+    hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)(p->n_maps * p->n_ticks)), dim3(rows), 0, s, p->frames.as<FrameDesc>(), p->n_maps,
+                       p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap);
+    LSN_HIP(hipGetLastError());
+    // :259-260 the corrected maps replace the inputs
+    LSN_HIP(hipMemcpyAsync(d_depth, p->map_copy.p, 2 * npix, hipMemcpyDeviceToDevice, s));
+    LSN_HIP(hipMemcpyAsync(d_colors, p->colors_copy.p, 3 * npix, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 

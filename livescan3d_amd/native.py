@@ -20,10 +20,10 @@ VERTEX_DTYPE = np.dtype([("R", "u1"), ("G", "u1"), ("B", "u1"), ("A", "u1"),
 
 # every symbol include/NativeUtils.h declares
 EXPORTS = [
-    "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "createMesh", "deleteMesh", "ICP",
+    "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
-    "lsnFusionRun", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
+    "lsnFusionRun", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace",
 ]
 
@@ -68,6 +68,10 @@ def lib():
     L.generateMeshFromDepthMaps.restype = None
     L.generateMeshFromDepthMaps.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(Mesh), C.c_bool,
                                             f, f, f, f, f, f, C.c_bool]
+    L.depthMapAndColorSetRadialCorrection.restype = None
+    L.depthMapAndColorSetRadialCorrection.argtypes = [C.c_int, vp, vp, vp, vp, vp]
+    L.lsnFusionRadialCorrect.restype = C.c_int
+    L.lsnFusionRadialCorrect.argtypes = [vp, vp, vp, vp, vp]
     L.createMesh.restype = C.POINTER(Mesh)
     L.createMesh.argtypes = []
     L.deleteMesh.restype = None
@@ -186,6 +190,23 @@ def generate_mesh_from_depth_maps(depth_maps, depth_colors, widths, heights, int
     return _copy_mesh(mesh)
 
 
+def radial_correction(depth_maps, depth_colors, widths, heights, intr):
+    """KinectServer.CorrectRadialDistortionsForDepthMaps (KinectServer.cs:518-525): returns corrected copies
+    (depth as a uint8 view of the u16 maps, colours); the export itself works in place on the arrays it is given."""
+    require_gpu()
+    widths, heights = _as(widths, np.int32), _as(heights, np.int32)
+    n = len(widths)
+    dm = np.ascontiguousarray(depth_maps).view(np.uint8).ravel().copy()
+    dc = _as(depth_colors, np.uint8).ravel().copy()
+    intr = _as(intr, np.float32).ravel()
+    assert intr.size == 7 * n
+    lib().depthMapAndColorSetRadialCorrection(n, _ptr(dm), _ptr(dc), _ptr(widths), _ptr(heights), _ptr(intr))
+    err = last_error()
+    if err:
+        raise NativeUtilsError(err)
+    return dm, dc
+
+
 def generate_vertices_from_depth_map(depth_maps, depth_colors, widths, heights, intr, wt, bounds, index):
     """One sensor's cropped cloud, as KinectServer.GetLatestFrameVerticesOnly calls it (KinectServer.cs:527-554)."""
     require_gpu()
@@ -247,6 +268,12 @@ class FusionPlan:
     def run(self, d_depth, d_colors, d_vertices, d_offsets, stream=0):
         """All four are device pointers (ints); asynchronous on `stream` (a hipStream_t as int, 0 = null stream)."""
         _check(lib().lsnFusionRun(self._h, d_depth, d_colors, d_vertices, d_offsets, stream), "lsnFusionRun")
+
+    def radial_correct(self, intr, d_depth, d_colors, stream=0):
+        """In-place radial correction of the plan's n_ticks x n_maps frames resident in HBM."""
+        intr = _as(intr, np.float32).ravel()
+        assert intr.size == 7 * self.n_maps
+        _check(lib().lsnFusionRadialCorrect(self._h, _ptr(intr), d_depth, d_colors, stream), "lsnFusionRadialCorrect")
 
     def run_mesh(self, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream=0):
         """Vertices + triangles (the reference's complete merge call); d_triangles: n_ticks x 2*capacity x 3 int32."""

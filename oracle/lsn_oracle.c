@@ -132,6 +132,89 @@ int orc_generate_vertices_from_depth_map(const uint8_t *depth_maps, const uint8_
 }
 
 /* ------------------------------------------------------------------------------------------
+ * radial correction
+ * ---------------------------------------------------------------------------------------- */
+
+/* (int) of a float the way the reference's x86-64 build does it (cvttss2si): truncation toward zero,
+ * NaN and values outside int range give INT_MIN ("integer indefinite"). */
+static int f2i_x86(float v)
+{
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) return (int)0x80000000;
+    return (int)v;
+}
+
+void orc_radial_correction(uint16_t *depth_map, uint8_t *colors, int w, int h, const float *intr7)
+{
+    const float cx = intr7[0], cy = intr7[1], fx = intr7[2], fy = intr7[3];
+    const float r2 = intr7[4], r4 = intr7[5], r6 = intr7[6];                    /* :196-198 */
+    const long np = (long)w * h;
+    uint16_t *map_copy = (uint16_t *)calloc((size_t)(np > 0 ? np : 1), sizeof(uint16_t));
+    uint8_t *colors_copy = (uint8_t *)calloc((size_t)(np > 0 ? np : 1) * 3, 1);
+
+    for (int y = 0; y < h; y++)                                                  /* :200-218 forward warp */
+        for (int x = 0; x < w; x++) {
+            if (depth_map[x + (long)y * w] == 0) continue;
+            float u = ((float)x - cx) / fx;
+            float v = ((float)y - cy) / fy;
+            float r = u * u + v * v;
+            float d = 1 - r2 * r - r4 * r * r - r6 * r * r * r;
+            int x_corr = f2i_x86(u * d * fx + cx);
+            int y_corr = f2i_x86(v * d * fy + cy);
+            if (x_corr >= 0 && y_corr >= 0 && x_corr < w && y_corr < h) {
+                map_copy[x_corr + (long)y_corr * w] = depth_map[x + (long)y * w];
+                memcpy(colors_copy + (x_corr + (long)y_corr * w) * 3, colors + (x + (long)y * w) * 3, 3);
+            }
+        }
+
+    /* :223-256 closing holes, in place and in raster order */
+    const int shifts[8] = {-w - 1, -w, -w + 1, -1, 1, w - 1, w, w + 1};
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++) {
+            long pos = x + (long)y * w;
+            int val = map_copy[pos];
+            if (val == 0) {
+                int n = 0, sum = 0, sum_cR = 0, sum_cG = 0, sum_cB = 0, prev_val = -1;
+                for (int i = 0; i < 8; i++)
+                    if ((map_copy[pos + shifts[i]] > 0) && (prev_val == -1 || abs(map_copy[pos + shifts[i]] - prev_val) < 30)) {
+                        prev_val = map_copy[pos + shifts[i]];
+                        n++;
+                        sum += map_copy[pos + shifts[i]];
+                        sum_cR += colors_copy[(pos + shifts[i]) * 3];
+                        sum_cG += colors_copy[(pos + shifts[i]) * 3 + 1];
+                        sum_cB += colors_copy[(pos + shifts[i]) * 3 + 2];
+                    }
+                if (n > 4) {
+                    map_copy[pos] = (uint16_t)(sum / n);
+                    colors_copy[pos * 3] = (uint8_t)(sum_cR / n);
+                    colors_copy[pos * 3 + 1] = (uint8_t)(sum_cG / n);
+                    colors_copy[pos * 3 + 2] = (uint8_t)(sum_cB / n);
+                }
+            }
+        }
+    memcpy(depth_map, map_copy, (size_t)np * sizeof(uint16_t));                  /* :259-260 */
+    memcpy(colors, colors_copy, (size_t)np * 3);
+    free(colors_copy);
+    free(map_copy);
+}
+
+void orc_radial_correction_all(int n_maps, uint8_t *depth_maps, uint8_t *depth_colors, const int *widths, const int *heights,
+                               const float *intr, int n_threads)
+{
+    long *dpos = (long *)malloc(sizeof(long) * (size_t)(n_maps + 1) * 2);
+    long *cpos = dpos + (n_maps + 1);
+    dpos[0] = cpos[0] = 0;
+    for (int i = 0; i < n_maps; i++) {
+        dpos[i + 1] = dpos[i] + (long)widths[i] * heights[i] * 2;
+        cpos[i + 1] = cpos[i] + (long)widths[i] * heights[i] * 3;
+    }
+    (void)n_threads;
+#pragma omp parallel for schedule(static, 1) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int i = 0; i < n_maps; i++)                                              /* :1803-1814, one thread per map */
+        orc_radial_correction((uint16_t *)(depth_maps + dpos[i]), depth_colors + cpos[i], widths[i], heights[i], intr + 7 * i);
+    free(dpos);
+}
+
+/* ------------------------------------------------------------------------------------------
  * triangulation
  * ---------------------------------------------------------------------------------------- */
 

@@ -59,6 +59,17 @@ int orc_generate_vertices_from_depth_map(const uint8_t *depth_maps, const uint8_
                                          const float *intr, const float *wt, const float *bounds6,
                                          int depth_map_index, orc_vertex *out);
 
+/* depthMapAndColorRadialCorrection, src/NativeUtils/depthprocessing.cpp:191-261: forward warp of depth + colour with
+ * d = 1 - r2 r - r4 r^2 - r6 r^3 (later source pixels overwrite earlier ones), then the in-place, raster-order 8-neighbour
+ * hole closing (> 4 neighbours within 30 mm of the previously accepted one).  In place on depth (w*h u16) and rgb (w*h*3).
+ * The (int) casts follow x86-64 cvttss2si: NaN / out-of-range -> INT_MIN (then rejected by the >= 0 test).
+ * PARITY UNPINNED (same reason as the depth path). */
+void orc_radial_correction(uint16_t *depth, uint8_t *rgb, int w, int h, const float *intr7);
+
+/* depthMapAndColorSetRadialCorrection (export), depthprocessing.cpp:1794-1815: every sensor of the concatenated buffers. */
+void orc_radial_correction_all(int n_maps, uint8_t *depth_maps, uint8_t *depth_colors, const int *widths, const int *heights,
+                               const float *intr, int n_threads);
+
 /* MeshGenerator::generateTrianglesGradients, src/NativeUtils/meshGenerator.cpp:14-181 (driver
  * generateTriangles, src/NativeUtils/depthprocessing.cpp:1659-1691): 2x2-stencil triangulation of ONE sensor.
  * depth = the sensor's depth map (VerticesWithDepthColorMaps::depth_map, a copy of the input, depthprocessing.cpp:180),

@@ -47,6 +47,8 @@ def lib():
         L.orc_generate_mesh_vertices.argtypes = [C.c_int, p, p, p, p, p, p, p, p, p, C.c_int]
         L.orc_generate_vertices_from_depth_map.restype = C.c_int
         L.orc_generate_vertices_from_depth_map.argtypes = [p, p, p, p, p, p, p, C.c_int, p]
+        L.orc_radial_correction_all.restype = None
+        L.orc_radial_correction_all.argtypes = [C.c_int, p, p, p, p, p, C.c_int]
         L.orc_generate_triangles.restype = C.c_long
         L.orc_generate_triangles.argtypes = [p, p, C.c_int, C.c_int, C.c_int, p]
         L.orc_generate_mesh.restype = C.c_long
@@ -109,6 +111,17 @@ def generate_mesh_vertices(depth_maps, depth_colors, widths, heights, intr, wt, 
     n = lib().orc_generate_mesh_vertices(n_maps, _ptr(depth_maps), _ptr(depth_colors), _ptr(widths), _ptr(heights),
                                          _ptr(intr), _ptr(wt), _ptr(bounds6), _ptr(out), _ptr(counts), n_threads)
     return out[:n].copy(), counts[:n_maps].copy()
+
+
+def radial_correction(depth_maps, depth_colors, widths, heights, intr, n_threads=1):
+    """depthMapAndColorSetRadialCorrection on copies of the concatenated buffers.  Returns (depth_maps u8 view, colours)."""
+    widths, heights = _i32(widths), _i32(heights)
+    n_maps = len(widths)
+    dm = np.ascontiguousarray(depth_maps).view(np.uint8).ravel().copy()
+    dc = np.ascontiguousarray(depth_colors, dtype=np.uint8).ravel().copy()
+    intr = _f32(intr, 7 * n_maps)
+    lib().orc_radial_correction_all(n_maps, _ptr(dm), _ptr(dc), _ptr(widths), _ptr(heights), _ptr(intr), n_threads)
+    return dm, dc
 
 
 def generate_triangles(depth, pix_to_vert, index_base=0):

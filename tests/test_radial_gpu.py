@@ -1,0 +1,94 @@
+"""GPU parity of depthMapAndColorSetRadialCorrection (forward warp + raster-order in-place hole closing) against the
+CPU oracle: bit-exact depth and colour, through the C-ABI export and the device-resident entry point."""
+import numpy as np
+import pytest
+
+from livescan3d_amd import native, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rig(depths, rgbs, intr_list):
+    n = len(depths)
+    wt = np.concatenate([synth.pack_pose(*synth.ring_pose(s, n)) for s in range(n)])
+    return synth.Rig(depths, rgbs, np.concatenate(intr_list), wt, synth.DEFAULT_BOUNDS)
+
+
+def _check(orc, rig, what):
+    got_d, got_c = native.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+    want_d, want_c = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+    assert np.array_equal(got_d, want_d), f"{what}: depth differs at {np.flatnonzero(got_d != want_d)[:8]}"
+    assert np.array_equal(got_c, want_c), f"{what}: colour differs"
+    return want_d
+
+
+def test_scene_and_noise_frames(gpu, orc):
+    for kind, n, w, h in [("scene", 2, 512, 424), ("noise", 3, 64, 48), ("scene", 1, 128, 96), ("noise", 1, 512, 424)]:
+        rig = synth.make_rig(kind, n, w, h, seed=6)
+        out = _check(orc, rig, f"{kind} {n}x{w}x{h}")
+        assert not np.array_equal(out, rig.depth_maps)        # the correction really moves pixels (r2,r4,r6 = .09,-.27,.09)
+
+
+def test_hole_closing_chains(gpu, orc):
+    """Patterns whose result depends on the in-place raster order: 1-pixel gap rows / columns / diagonals (every filled
+    pixel feeds its right and lower neighbours), random holes, depth steps around the 30 mm acceptance window."""
+    rng = np.random.default_rng(4)
+    zero_dist = [0.0, 0.0, 0.0]                                # r2=r4=r6=0: the warp is the identity, only the closing acts
+    for (w, h) in [(64, 48), (61, 37), (512, 424), (24, 1100)]:
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = (1500 + 2 * xx + 3 * yy).astype(np.int64)
+        cases = {}
+        d = base.copy(); d[::7, :] = 0; cases["gap rows"] = d
+        d = base.copy(); d[:, ::5] = 0; cases["gap columns"] = d
+        d = base.copy(); d[(xx + yy) % 6 == 0] = 0; cases["gap diagonals"] = d
+        d = base.copy(); d[rng.random((h, w)) < 0.25] = 0; cases["random holes"] = d
+        d = base + 26 * ((xx // 3) % 2) + 33 * ((yy // 4) % 2); d[rng.random((h, w)) < 0.15] = 0; cases["steps"] = d
+        d = base.copy(); d[h // 3:h // 2, w // 4:3 * w // 4] = 0; d[::4, :] = np.where(rng.random((h // 4 + (h % 4 > 0), w)) < 0.5, 0, d[::4, :]); cases["blob"] = d
+        for name, dd in cases.items():
+            depth = np.clip(dd, 0, 65535).astype(np.uint16)
+            rgb = synth.noise_frame(3, 0, 0, w, h)[1]
+            intr = synth.kinect_intrinsics(w, h).copy()
+            intr[4:7] = zero_dist
+            rig = _rig([depth], [rgb], [intr])
+            out = _check(orc, rig, f"{name} {w}x{h}").view(np.uint16)
+            if name in ("gap rows", "gap columns", "gap diagonals"):
+                assert (out.reshape(h, w)[2:-2, 2:-2] != 0).mean() > 0.9       # most gaps got closed (the (int) cast itself opens a few)
+
+
+def test_warp_edge_cases(gpu, orc):
+    w, h = 64, 48
+    rgb = synth.noise_frame(5, 0, 0, w, h)[1]
+    depth = synth.noise_frame(5, 0, 1, w, h)[0]
+    for r in ([0.5, 0.0, 0.0], [-0.8, 0.3, 0.0], [3.0, -5.0, 9.0], [np.nan, 0, 0], [1e30, 0, 0]):
+        intr = synth.kinect_intrinsics(w, h).copy()
+        intr[4:7] = r
+        _check(orc, _rig([depth], [rgb], [intr]), f"r={r}")
+    intr = synth.kinect_intrinsics(w, h).copy()
+    intr[2] = 0.0                                              # fx = 0: u = +-inf / NaN -> every destination rejected in x
+    _check(orc, _rig([depth], [rgb], [intr]), "fx=0")
+    _check(orc, _rig([np.zeros((h, w), np.uint16)], [rgb], [synth.kinect_intrinsics(w, h)]), "all invalid")
+
+
+def test_device_resident_batch_then_fusion(gpu, orc):
+    """The per-tick order of LiveScanServer (KinectServer.cs:518-525 then :354-374): radial correction, then the merge
+    call, all on HBM-resident ticks."""
+    import torch
+    T, N, w, h = 3, 2, 512, 424
+    rigs = [synth.make_rig("scene", N, w, h, seed=9, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+    plan = native.FusionPlan(0, T, rigs[0].widths, rigs[0].heights)
+    plan.set_params(rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda()
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()
+    st = int(torch.cuda.current_stream().cuda_stream)
+    plan.radial_correct(rigs[0].intr, depth.data_ptr(), rgb.data_ptr(), st)
+    verts = torch.zeros((T, plan.capacity, 16), dtype=torch.uint8, device="cuda")
+    off = torch.zeros((T, N + 1), dtype=torch.int32, device="cuda")
+    plan.run(depth.data_ptr(), rgb.data_ptr(), verts.data_ptr(), off.data_ptr(), st)
+    torch.cuda.synchronize()
+    for k in range(T):
+        want_d, want_c = orc.radial_correction(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, rigs[0].intr)
+        assert np.array_equal(depth[k].cpu().numpy().view(np.uint8), want_d)
+        assert np.array_equal(rgb[k].cpu().numpy(), want_c)
+        want_v, _ = orc.generate_mesh_vertices(want_d, want_c, rigs[k].widths, rigs[k].heights, rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+        n = int(off[k, -1])
+        assert verts[k, :n].cpu().numpy().tobytes() == want_v.tobytes()
