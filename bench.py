@@ -217,6 +217,21 @@ def main():
                                   "exercises every rejection branch but yields few triangles"}
         del tri, toff
 
+    # ---- radial correction, the step before the merge call on every tick (extra field) ---------------------------
+    if rank == 0 and world == 1 and not args.no_mesh:
+        d2, c2 = depth.clone(), rgb.clone()
+        intr_loc = intr_all[7 * s0:7 * (s0 + S_loc)]
+        fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        d2.copy_(depth); c2.copy_(rgb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        result["radial_correction"] = {"frames_per_s": B / (time.perf_counter() - t0),
+                                       "note": "depthMapAndColorSetRadialCorrection on the same ticks, HBM resident, one pass"}
+        del d2, c2
+
     # ---- drop-in export on host buffers (PCIe-inclusive; never `value`) -----------------------------------------
     if rank == 0 and not args.no_host_path:
         rig = synth.make_rig("noise", S, w, h, seed=1, bounds=bounds)

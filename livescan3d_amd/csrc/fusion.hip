@@ -874,51 +874,189 @@ __global__ __launch_bounds__(kThreads) void radial_gather_kernel(const FrameDesc
 }
 
 // One workgroup per sensor-frame, one thread per row (bands of blockDim rows when h is larger).  At step t the thread of
-// row y handles column x = t - 2 (y - band0): the pixels it reads from row y-1 (x-1, x, x+1) were finished at least one
-// barrier ago, its own left neighbour one step ago, everything to the right and below is still original -- exactly the
-// state the reference's raster-order in-place loop sees (:223-256).
-__global__ __launch_bounds__(1024) void radial_close_kernel(const FrameDesc *frames, int n_frames, unsigned short *map_copy,
+// row y handles column x = 1 + t - 2 (y - band0): the pixels it reads from row y-1 (x-1, x, x+1) were finished at least
+// one barrier ago, its own left neighbour one step ago, everything to the right and below is still original -- exactly
+// the state the reference's raster-order in-place loop sees (:223-256).
+// Everything a step touches lives in LDS rings of 32 columns per row (4 chunks of 8; u16 depth and packed RGB): a row's
+// thread streams its row through the rings two chunks ahead of where it works (the global loads are issued 8 steps
+// before their data is needed) and overwrites a slot when it fills a hole, so the row below reads finals, the row above
+// reads originals, no step waits for global memory, and the step barrier only has to order LDS traffic.  Filled pixels
+// are also stored to the global maps, fire-and-forget.
+constexpr int kRing = 32;
+
+struct RingChunk { unsigned int d[4]; unsigned int c[8]; };  // 8 pixels: depth u16 x 8, colour 0x00BBGGRR x 8
+
+// Loads chunk `chunk` (columns 8 chunk .. 8 chunk + 7) of `row`; anything outside the frame reads as 0.
+__device__ __forceinline__ void ring_load_chunk(const unsigned short *map, const unsigned char *col, int w, int h, int row, int chunk,
+                                                RingChunk &reg)
+{
+    const bool row_ok = row >= 0 && row < h;
+    if ((w & 7) == 0) {
+        // aligned rows: one 16-B depth load and 24 B of colour (three 8-B loads)
+        uint4 dv = make_uint4(0, 0, 0, 0);
+        uint2 c0 = make_uint2(0, 0), c1 = c0, c2 = c0;
+        if (row_ok && chunk >= 0 && chunk * 8 < w) {
+            const long long p = (long long)row * w + chunk * 8;
+            dv = *reinterpret_cast<const uint4 *>(map + p);
+            const uint2 *cp = reinterpret_cast<const uint2 *>(col + 3 * p);
+            c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
+        }
+        reg.d[0] = dv.x; reg.d[1] = dv.y; reg.d[2] = dv.z; reg.d[3] = dv.w;
+        const unsigned int cw[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = 3 * j;
+            const unsigned int lo = cw[b >> 2], hi = cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
+            reg.c[j] = __funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c0 = chunk * 8 + j;
+        unsigned int dv = 0, cv = 0;
+        if (row_ok && c0 >= 0 && c0 < w) {
+            const long long p = (long long)row * w + c0;
+            dv = map[p];
+            cv = col[3 * p] | (col[3 * p + 1] << 8) | (col[3 * p + 2] << 16);
+        }
+        if (j & 1) reg.d[j >> 1] |= dv << 16;
+        else reg.d[j >> 1] = dv;
+        reg.c[j] = cv;
+    }
+}
+
+__device__ __forceinline__ void ring_store_chunk(unsigned short *dring_row, unsigned int *cring_row, int chunk, const RingChunk &reg)
+{
+    const int s0 = (chunk * 8) & (kRing - 1);
+    unsigned int *dd = reinterpret_cast<unsigned int *>(dring_row + s0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) dd[j] = reg.d[j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) cring_row[s0 + j] = reg.c[j];
+}
+
+// A streamed row: its ring slot and the two chunks in flight.
+struct RingFeed {
+    int ring, row;
+    RingChunk p0, p1;
+};
+
+__global__ __launch_bounds__(768) void radial_close_kernel(const FrameDesc *frames, int n_frames, unsigned short *map_copy,
                                                             unsigned char *colors_copy, long long tick_pix_stride)
 {
+    extern __shared__ unsigned int ring_mem[];  // colours: (blockDim.x + 2) x kRing u32, then depths: the same count of u16
+    const int rows = blockDim.x;
+    unsigned int *cring = ring_mem;
+    unsigned short *dring = reinterpret_cast<unsigned short *>(ring_mem + (rows + 2) * kRing);
     const int tick = blockIdx.x / n_frames;
     const int f = blockIdx.x - tick * n_frames;
     const FrameDesc fd = frames[f];
     const int w = fd.w, h = fd.h;
     unsigned short *map = map_copy + tick * tick_pix_stride + fd.depth_off;
     unsigned char *col = colors_copy + 3 * (tick * tick_pix_stride + fd.depth_off);
-    const int shifts[8] = {-w - 1, -w, -w + 1, -1, 1, w - 1, w, w + 1};       // :224
-    const int rows = blockDim.x;
+    const int r = threadIdx.x;
     for (int band0 = 1; band0 < h - 1; band0 += rows) {
-        const int r = threadIdx.x;
         const int y = band0 + r;
+        // Rows this thread streams through the rings (two named feeds, no runtime-indexed arrays -- those would live in
+        // scratch memory): A = its own row (ring index r + 1); B = a ghost row: the row above the band for thread 0
+        // (index 0), the row below it for the last thread (index rows + 1).
+        const bool has_a = y <= h - 1;
+        const bool has_b = (r == 0) || (r == rows - 1);
+        RingFeed A, B;
+        A.ring = r + 1; A.row = y;
+        B.ring = r == 0 ? 0 : rows + 1; B.row = r == 0 ? band0 - 1 : y + 1;
+        // Every 16 steps ALL lanes publish the two chunks they fetched 16 steps earlier and fetch the next two, so the
+        // wave's global loads are consumed a full round after they were issued.  During the round that starts at column
+        // x0 the neighbours touch columns x0 - 3 .. x0 + 18 of this row: chunks (x0 - 3) >> 3 .. (x0 + 18) >> 3, at most
+        // four -- exactly the ring.
+        const int x_start = 1 - 2 * r;
+        auto top_chunk = [](int x0) { return (x0 + 18) >> 3; };  // arithmetic shift: floor for negative columns too
+        __syncthreads();  // the previous band is done with the rings (and its fills have reached the global maps)
+        {
+            const int P = top_chunk(x_start);
+            if (has_a) {
+                for (int c = P - 3; c <= P; c++) {
+                    ring_load_chunk(map, col, w, h, A.row, c, A.p0);
+                    ring_store_chunk(dring + A.ring * kRing, cring + A.ring * kRing, c, A.p0);
+                }
+                ring_load_chunk(map, col, w, h, A.row, P + 1, A.p0);
+                ring_load_chunk(map, col, w, h, A.row, P + 2, A.p1);
+            }
+            if (has_b) {
+                for (int c = P - 3; c <= P; c++) {
+                    ring_load_chunk(map, col, w, h, B.row, c, B.p0);
+                    ring_store_chunk(dring + B.ring * kRing, cring + B.ring * kRing, c, B.p0);
+                }
+                ring_load_chunk(map, col, w, h, B.row, P + 1, B.p0);
+                ring_load_chunk(map, col, w, h, B.row, P + 2, B.p1);
+            }
+        }
+        __syncthreads();
+        const unsigned short *d_up = dring + r * kRing, *d_below = dring + (r + 2) * kRing;
+        unsigned short *d_mine = dring + (r + 1) * kRing;
+        const unsigned int *c_up = cring + r * kRing, *c_below = cring + (r + 2) * kRing;
+        unsigned int *c_mine = cring + (r + 1) * kRing;
         const int steps = (w - 2) + 2 * (rows - 1);
         for (int t = 0; t < steps; t++) {
-            const int x = 1 + t - 2 * r;
-            if (y < h - 1 && x >= 1 && x < w - 1) {
-                const long long pos = x + (long long)y * w;
-                if (map[pos] == 0) {                                           // :232-234
-                    int n = 0, sum = 0, sR = 0, sG = 0, sB = 0, prev_val = -1;
+            const int x = x_start + t;
+            if (t > 0 && (t & 15) == 0) {  // uniform over the workgroup
+                const int P = top_chunk(x);
+                if (has_a) {
+                    ring_store_chunk(dring + A.ring * kRing, cring + A.ring * kRing, P - 1, A.p0);
+                    ring_store_chunk(dring + A.ring * kRing, cring + A.ring * kRing, P, A.p1);
+                    ring_load_chunk(map, col, w, h, A.row, P + 1, A.p0);
+                    ring_load_chunk(map, col, w, h, A.row, P + 2, A.p1);
+                }
+                if (has_b) {
+                    ring_store_chunk(dring + B.ring * kRing, cring + B.ring * kRing, P - 1, B.p0);
+                    ring_store_chunk(dring + B.ring * kRing, cring + B.ring * kRing, P, B.p1);
+                    ring_load_chunk(map, col, w, h, B.row, P + 1, B.p0);
+                    ring_load_chunk(map, col, w, h, B.row, P + 2, B.p1);
+                }
+                // the new chunks must be in place before any neighbour reads them in this very step
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            }
+            if (y < h - 1 && x >= 1 && x < w - 1 && d_mine[x & (kRing - 1)] == 0) {        // :229-234
+                const int xm = (x - 1) & (kRing - 1), x0 = x & (kRing - 1), xp = (x + 1) & (kRing - 1);
+                const int nb[8] = {d_up[xm], d_up[x0], d_up[xp], d_mine[xm], d_mine[xp], d_below[xm], d_below[x0], d_below[xp]};
+                int n = 0, sum = 0, prev_val = -1;
+                unsigned int accepted = 0;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int mv = map[pos + shifts[i]];
-                        if (mv > 0 && (prev_val == -1 || abs(mv - prev_val) < 30)) {   // :241
-                            prev_val = mv;
-                            n++;
-                            sum += mv;
-                            sR += col[(pos + shifts[i]) * 3];
-                            sG += col[(pos + shifts[i]) * 3 + 1];
-                            sB += col[(pos + shifts[i]) * 3 + 2];
-                        }
-                    }
-                    if (n > 4) {                                               // :250-256
-                        map[pos] = (unsigned short)(sum / n);
-                        col[pos * 3] = (unsigned char)(sR / n);
-                        col[pos * 3 + 1] = (unsigned char)(sG / n);
-                        col[pos * 3 + 2] = (unsigned char)(sB / n);
+                for (int i = 0; i < 8; i++) {
+                    if (nb[i] > 0 && (prev_val == -1 || abs(nb[i] - prev_val) < 30)) {      // :241
+                        prev_val = nb[i];
+                        n++;
+                        sum += nb[i];
+                        accepted |= 1u << i;
                     }
                 }
+                if (n > 4) {                                                                // :250-256
+                    const unsigned int nc[8] = {c_up[xm], c_up[x0], c_up[xp], c_mine[xm], c_mine[xp], c_below[xm], c_below[x0], c_below[xp]};
+                    int sR = 0, sG = 0, sB = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (accepted & (1u << i)) {
+                            sR += nc[i] & 0xFF; sG += (nc[i] >> 8) & 0xFF; sB += (nc[i] >> 16) & 0xFF;
+                        }
+                    const unsigned int fd_ = (unsigned int)(sum / n);
+                    const unsigned int fR = sR / n, fG = sG / n, fB = sB / n;
+                    d_mine[x0] = (unsigned short)fd_;
+                    c_mine[x0] = fR | (fG << 8) | (fB << 16);
+                    const long long pos = x + (long long)y * w;
+                    map[pos] = (unsigned short)fd_;
+                    col[pos * 3] = (unsigned char)fR;
+                    col[pos * 3 + 1] = (unsigned char)fG;
+                    col[pos * 3 + 2] = (unsigned char)fB;
+                }
             }
-            __syncthreads();  // workgroup-scope release/acquire: the next step sees this step's fills
+            // Step barrier on LDS traffic only: a plain __syncthreads() would also wait for the chunk prefetches and
+            // the fire-and-forget fills (a global round trip per step).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
     }
 }
@@ -1369,8 +1507,9 @@ extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, vo
     int max_h = 1;
     for (int v : p->h) max_h = v > max_h ? v : max_h;
     int rows = max_h - 2 < 64 ? 64 : ((max_h - 2 + 63) / 64) * 64;
-    if (rows > 1024) rows = 1024;
-    hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)(p->n_maps * p->n_ticks)), dim3(rows), 0, s, p->frames.as<FrameDesc>(), p->n_maps,
+    if (rows > 768) rows = 768;  // (rows + 2) x 32 columns x 6 B of LDS rings must fit in 160 KB
+    hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)(p->n_maps * p->n_ticks)), dim3(rows), (sizeof(unsigned int) + sizeof(unsigned short)) * kRing * (rows + 2), s,
+                       p->frames.as<FrameDesc>(), p->n_maps,
                        p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap);
     LSN_HIP(hipGetLastError());
     // :259-260 the corrected maps replace the inputs
