@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-mesh", action="store_true")
+    ap.add_argument("--padded-exchange", action="store_true", help="N > 1: all-gather full-capacity slabs (no host sync)")
+    ap.add_argument("--no-tick-parallel", action="store_true", help="N > 1: skip the extra tick-parallel (no-exchange) leg")
     ap.add_argument("--icp-reps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -100,18 +102,7 @@ def main():
 
     xch = None
     if world > 1:
-        xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev)
-        if share:
-            # gloo has no device all-gather: stage through the host (rehearsal only)
-            def _exchange(lv, lo, _x=xch):
-                gv, go = _x.g_verts.cpu(), _x.g_off.cpu()
-                dist.all_gather_into_tensor(gv.view(world * B, _x.shard_cap, 16), lv.cpu())
-                dist.all_gather_into_tensor(go.view(world * B, S_loc + 1), lo.cpu())
-                _x.g_verts.copy_(gv)
-                _x.g_off.copy_(go)
-                native.merge_shards(dev_index, world, B, S_loc, _x.g_verts.data_ptr(), _x.shard_cap, _x.g_off.data_ptr(),
-                                    _x.merged.data_ptr(), _x.shard_cap * world, _x.merged_off.data_ptr(), stream)
-            xch.exchange = _exchange
+        xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
 
     def step():
         fus.run(depth, rgb)
@@ -193,6 +184,34 @@ def main():
                 "kernel_launches": kstats["launches"],
             },
         }
+
+    # ---- N > 1, extra leg: the same ticks spread over the GPUs instead of the sensors (no exchange step at all) ------
+    if world > 1 and not args.no_tick_parallel:
+        fus_all = fus
+        d_all, c_all = depth, rgb
+        if S_loc != S:
+            fus_all = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=args.mode)
+            fus_all.set_params(intr_all, wt_all, bounds)
+            d_all, c_all = synth.noise_frames_torch(dev, 1, B, S, w, h, tick0=rank * B)
+            d_all, c_all = d_all.view(B, S * P), c_all.view(B, S * P * 3)
+        for _ in range(args.warmup):
+            fus_all.run(d_all, c_all)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fus_all.run(d_all, c_all)
+        sync()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            result["tick_parallel"] = {
+                "value": world * B * args.steps / float(el.item()), "unit": "frames/s", "scaling": "weak",
+                "note": "every GPU fuses whole ticks (all sensors) of its own tick range: no exchange step, no collective in "
+                        "the timed region; reported beside the north-star's sensor-sharded + all-gather scheme"}
+            if xch is not None:
+                result["config"]["exchange_slab_vertices"] = xch.last_slab
+        if fus_all is not fus:
+            del fus_all, d_all, c_all
 
     # ---- the complete merge call incl. the reference's always-on triangulation (extra field, never `value`) --------
     if rank == 0 and world == 1 and not args.no_mesh:

@@ -22,33 +22,60 @@ def sensor_block(n_sensors, world, rank):
 
 
 class MergedCloudExchange:
-    """Buffers + the exchange step for T ticks, `maps_per_rank` sensors per rank, `shard_cap` vertices per rank-tick."""
+    """Buffers + the exchange step for T ticks, `maps_per_rank` sensors per rank, `shard_cap` vertices per rank-tick.
 
-    def __init__(self, world, n_ticks, maps_per_rank, shard_cap, device, merge_fn=None, group=None):
+    compact=True (default) first all-gathers the (tiny) offset tables, reads the largest per-tick shard count M back to
+    the host (one synchronisation per step) and then moves slabs of M instead of shard_cap vertices per tick: the crop
+    usually keeps ~half of the pixels, so about half of the xGMI traffic disappears.  compact=False moves the padded
+    slabs and never touches the host.  via_host=True runs the collectives on host copies (gloo rehearsal on a box
+    without one GPU per rank); it is not a product path."""
+
+    def __init__(self, world, n_ticks, maps_per_rank, shard_cap, device, merge_fn=None, group=None, compact=True, via_host=False):
         self.world, self.n_ticks, self.mpr, self.shard_cap = world, n_ticks, maps_per_rank, int(shard_cap)
         self.device = torch.device(device)
         self.group = group
         self.merge_fn = merge_fn
+        self.compact = compact
+        self.via_host = via_host
         if self.device.type != "cuda" and merge_fn is None:
             raise native.NativeUtilsError("MergedCloudExchange on a non-GPU device needs an explicit merge_fn (tests only); "
                                           "the product path packs the shards with the HIP kernel lsnMergeShards")
-        self.g_verts = torch.empty((world, n_ticks, self.shard_cap, 16), dtype=torch.uint8, device=self.device)
+        self.g_flat = torch.empty((world * n_ticks * self.shard_cap, 16), dtype=torch.uint8, device=self.device)
+        self.stage = torch.empty((n_ticks * self.shard_cap, 16), dtype=torch.uint8, device=self.device) if compact else None
         self.g_off = torch.empty((world, n_ticks, maps_per_rank + 1), dtype=torch.int32, device=self.device)
         self.merged = torch.empty((n_ticks, self.shard_cap * world, 16), dtype=torch.uint8, device=self.device)
         self.merged_off = torch.zeros((n_ticks, world * maps_per_rank + 1), dtype=torch.int32, device=self.device)
+        self.last_slab = self.shard_cap
+
+    def _all_gather(self, out, inp):
+        # output = the rank slabs concatenated along dim 0 (the layout both RCCL and gloo accept)
+        if self.via_host:
+            o = out.cpu()
+            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def exchange(self, local_vertices, local_offsets):
         """local_vertices [T, shard_cap, 16] u8, local_offsets [T, maps_per_rank+1] i32 (lsnFusionRun outputs).
-        Returns (merged [T, world*shard_cap, 16], merged_offsets [T, S+1]); asynchronous on the current stream."""
-        assert tuple(local_vertices.shape) == (self.n_ticks, self.shard_cap, 16)
-        assert tuple(local_offsets.shape) == (self.n_ticks, self.mpr + 1)
-        # output = the rank slabs concatenated along dim 0 (the layout both RCCL and gloo accept)
-        dist.all_gather_into_tensor(self.g_verts.view(self.world * self.n_ticks, self.shard_cap, 16), local_vertices, group=self.group)
-        dist.all_gather_into_tensor(self.g_off.view(self.world * self.n_ticks, self.mpr + 1), local_offsets, group=self.group)
+        Returns (merged [T, world*shard_cap, 16], merged_offsets [T, S+1]); asynchronous on the current stream
+        (compact=True synchronises once to learn the slab size)."""
+        T, W = self.n_ticks, self.world
+        assert tuple(local_vertices.shape) == (T, self.shard_cap, 16)
+        assert tuple(local_offsets.shape) == (T, self.mpr + 1)
+        self._all_gather(self.g_off.view(W * T, self.mpr + 1), local_offsets)
+        m = self.shard_cap
+        src = local_vertices
+        if self.compact:
+            m = max(1, int(self.g_off[:, :, self.mpr].max().item()))          # largest shard of any rank / tick
+            src = self.stage[: T * m].view(T, m, 16)
+            src.copy_(local_vertices[:, :m])                                  # strided slabs -> one contiguous block
+        self.last_slab = m
+        g = self.g_flat[: W * T * m].view(W * T, m, 16)
+        self._all_gather(g, src)
         if self.merge_fn is not None:
-            self.merge_fn(self.g_verts, self.g_off, self.merged, self.merged_off)
+            self.merge_fn(g.view(W, T, m, 16), self.g_off, self.merged, self.merged_off)
         else:
-            native.merge_shards(self.device.index, self.world, self.n_ticks, self.mpr, self.g_verts.data_ptr(), self.shard_cap,
-                                self.g_off.data_ptr(), self.merged.data_ptr(), self.shard_cap * self.world,
-                                self.merged_off.data_ptr(), int(torch.cuda.current_stream().cuda_stream))
+            native.merge_shards(self.device.index, W, T, self.mpr, g.data_ptr(), m, self.g_off.data_ptr(), self.merged.data_ptr(),
+                                self.shard_cap * W, self.merged_off.data_ptr(), int(torch.cuda.current_stream().cuda_stream))
         return self.merged, self.merged_off
