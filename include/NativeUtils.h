@@ -113,6 +113,12 @@ int lsnFusionSetParams(LsnFusion *plan, const float *intr_params, const float *w
  * 1 = single pass with decoupled look-back.  Results are identical. */
 int lsnFusionSetMode(LsnFusion *plan, int mode);
 
+/* Pipelined calls (mode 0 only): the caller promises that the INPUTS of a call are already resident and stay untouched
+ * when the call is issued, whatever is still queued on its stream (true for double-buffered ingest).  The count + scan
+ * of call k+1 then run on an internal side stream while the write kernel of call k is still running on the caller's
+ * stream; outputs and their ordering on the caller's stream are unchanged. */
+int lsnFusionSetPipelined(LsnFusion *plan, int enable);
+
 /* Fuses n_ticks ticks.  d_depth_maps: n_ticks x (concatenated u16 maps of one tick); d_depth_colors likewise RGB8;
  * d_vertices: n_ticks x lsnFusionTickCapacity() VertexC4ubV3f, tick k's merged cloud starts at k*capacity;
  * d_offsets: n_ticks x (n_maps+1) ints, [k][i] = index of sensor i's first vertex inside tick k's cloud,

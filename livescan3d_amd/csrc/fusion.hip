@@ -1130,6 +1130,12 @@ struct LsnFusion {
     lsn::DevBuf xtab, ytab;
     lsn::DevBuf pixmap, tri_counts;  // triangulation scratch, allocated on first use
     lsn::DevBuf winner, map_copy, colors_copy, radial;  // radial-correction scratch, allocated on first use
+    // pipelined mode: the count + scan of call k+1 run on a side stream while the write kernel of call k is still busy
+    bool pipelined = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_counted = nullptr, ev_written[2] = {nullptr, nullptr};
+    lsn::DevBuf tile_counts_b, offs_int;  // second count buffer, internal offsets [2][n_ticks][n_maps+1]
+    unsigned long long calls = 0;
     // dominant-kernel timing
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1240,6 +1246,13 @@ extern "C" void lsnFusionDestroy(LsnFusion *p)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (p->side) {
+        (void)hipStreamSynchronize(p->side);
+        (void)hipStreamDestroy(p->side);
+        (void)hipEventDestroy(p->ev_counted);
+        (void)hipEventDestroy(p->ev_written[0]);
+        (void)hipEventDestroy(p->ev_written[1]);
+    }
     delete p;
 }
 
@@ -1283,6 +1296,27 @@ extern "C" int lsnFusionSetMode(LsnFusion *p, int mode)
         return -1;
     }
     p->mode = mode;
+    return 0;
+}
+
+extern "C" int lsnFusionSetPipelined(LsnFusion *p, int enable)
+{
+    lsn::clear_error();
+    if (!p) return -1;
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    if (enable && !p->side) {
+        if (p->tile_counts_b.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks) ||
+            p->offs_int.reserve(sizeof(int) * 2 * (size_t)p->n_ticks * (p->n_maps + 1)))
+            return -1;
+        LSN_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+        LSN_HIP(hipEventCreateWithFlags(&p->ev_counted, hipEventDisableTiming));
+        LSN_HIP(hipEventCreateWithFlags(&p->ev_written[0], hipEventDisableTiming));
+        LSN_HIP(hipEventCreateWithFlags(&p->ev_written[1], hipEventDisableTiming));
+    }
+    if (!enable && p->side) LSN_HIP(hipStreamSynchronize(p->side));
+    p->pipelined = enable != 0;
+    p->calls = 0;
     return 0;
 }
 
@@ -1408,7 +1442,30 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         p->ev_used++;
     }
 
-    if (p->mode == 0 || p->want_pixmap) {
+    if (p->pipelined && p->mode == 0 && !p->want_pixmap) {
+        // Count + scan of THIS call go to the side stream: they only read the inputs (promised resident by
+        // lsnFusionSetPipelined) and write this call's half of the double-buffered scratch, so they overlap with the
+        // previous call's write kernel, which is still running on the caller's stream (a VALU-bound kernel beside an
+        // HBM-bound one).  The caller's stream then waits for them and runs the write kernel.
+        const int b = (int)(p->calls & 1);
+        const size_t off_elems = (size_t)p->n_ticks * (p->n_maps + 1);
+        a.tile_counts = b ? p->tile_counts_b.as<int>() : p->tile_counts.as<int>();
+        int *off_int = p->offs_int.as<int>() + b * off_elems;
+        if (p->calls >= 2) LSN_HIP(hipStreamWaitEvent(p->side, p->ev_written[b], 0));  // the write that last read this half
+        FuseArgs ac = a;
+        ac.offsets = off_int;
+        launch<0>(vec, grid, p->side, ac);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, p->side, ac.tile_counts, ac.tiles_per_tick, ac.frames,
+                           ac.n_frames, off_int);
+        LSN_HIP(hipEventRecord(p->ev_counted, p->side));
+        LSN_HIP(hipStreamWaitEvent(s, p->ev_counted, 0));
+        LSN_HIP(hipMemcpyAsync(d_offsets, off_int, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
+        if (e0) LSN_HIP(hipEventRecord(e0, s));
+        launch<1>(vec, grid, s, a);
+        if (e1) LSN_HIP(hipEventRecord(e1, s));
+        LSN_HIP(hipEventRecord(p->ev_written[b], s));
+        p->calls++;
+    } else if (p->mode == 0 || p->want_pixmap) {
         launch<0>(vec, grid, s, a);
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
                            a.offsets);

@@ -23,7 +23,7 @@ EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
-    "lsnFusionRun", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
+    "lsnFusionRun", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace",
 ]
 
@@ -92,6 +92,8 @@ def lib():
     L.lsnFusionSetParams.argtypes = [vp, vp, vp, vp, vp]
     L.lsnFusionSetMode.restype = C.c_int
     L.lsnFusionSetMode.argtypes = [vp, C.c_int]
+    L.lsnFusionSetPipelined.restype = C.c_int
+    L.lsnFusionSetPipelined.argtypes = [vp, C.c_int]
     L.lsnFusionRun.restype = C.c_int
     L.lsnFusionRun.argtypes = [vp, vp, vp, vp, vp, vp]
     L.lsnFusionRunMesh.restype = C.c_int
@@ -261,6 +263,10 @@ class FusionPlan:
         intr, wt, b = _as(intr, np.float32).ravel(), _as(wt, np.float32).ravel(), _as(bounds, np.float32).ravel()
         assert intr.size == 7 * self.n_maps and wt.size == 12 * self.n_maps and b.size == 6
         _check(lib().lsnFusionSetParams(self._h, _ptr(intr), _ptr(wt), _ptr(b), stream), "lsnFusionSetParams")
+
+    def set_pipelined(self, enable=True):
+        """Overlap the count pass of the next call with the write kernel of the current one (inputs must be resident)."""
+        _check(lib().lsnFusionSetPipelined(self._h, 1 if enable else 0), "lsnFusionSetPipelined")
 
     def set_mode(self, mode):
         _check(lib().lsnFusionSetMode(self._h, int(mode)), "lsnFusionSetMode")

@@ -247,3 +247,33 @@ def test_device_resident_mesh_batch(gpu, orc):
         assert verts[k, :nv].cpu().numpy().tobytes() == want.tobytes()
         assert np.array_equal(tri[k, :nt].cpu().numpy(), want_tri)
         assert (np.diff(toff_h[k]) >= 0).all() and toff_h[k, 0] == 0
+
+
+def test_pipelined_calls_match(gpu, orc):
+    """lsnFusionSetPipelined: count/scan of call k+1 on a side stream beside write(k); results identical, call after call."""
+    import torch
+    from livescan3d_amd.fusion import DeviceFusion
+    T, N, w, h = 4, 2, 512, 424
+    batches = []
+    for b in range(3):
+        rigs = [synth.make_rig("noise", N, w, h, seed=30 + b, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+        batches.append((rigs, torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda(),
+                        torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()))
+    fus = DeviceFusion(T, [w] * N, [h] * N)
+    fus.set_params(batches[0][0][0].intr, batches[0][0][0].wt, synth.CROP_BOUNDS)
+    fus.plan.set_pipelined(True)
+    outs = []
+    for rep in range(2):
+        for rigs, d, c in batches:               # back-to-back calls with different (resident) inputs
+            v, o = fus.run(d, c)
+            outs.append((rigs, v.clone(), o.clone()))   # clone is ordered after the call on the same stream
+    torch.cuda.synchronize()
+    fus.plan.set_pipelined(False)
+    for rigs, v, o in outs:
+        oh = o.cpu().numpy()
+        for k in range(T):
+            want, counts = orc.generate_mesh_vertices(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights,
+                                                      batches[0][0][0].intr, batches[0][0][0].wt, synth.CROP_BOUNDS)
+            n = int(oh[k, -1])
+            assert n == len(want) and list(np.diff(oh[k])) == list(counts)
+            assert v[k, :n].cpu().numpy().tobytes() == want.tobytes()
