@@ -310,7 +310,7 @@ def main():
 
 def pmc_traffic(args, S_loc, B, w, h):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json, written by
-    tools_pmc.sh on the GPU box: separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    tools/pmc.sh on the GPU box: separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     None when no pass was recorded for this exact workload."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):

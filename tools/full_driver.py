@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev helper: one pass of radial correction + full mesh on 16 ticks x 8 sensors (scene data), for kernel traces."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from livescan3d_amd import native, synth

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dev helper (GPU box): PMC passes for the fusion kernels; usage: tools_pmc.sh <tag> <mode>
+# Dev helper (GPU box): PMC passes for the fusion kernels; usage: tools/pmc.sh <tag> <mode>
 # Counters are collected in separate runs (TCC slot limits; FETCH_SIZE and WRITE_SIZE cannot share a pass).
 tag=$1; mode=$2
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
@@ -7,7 +7,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   name=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $out/$name -- python3 $GRAFT_REPO_ROOT/tools_pmc_driver.py $mode > $out/$name.log 2>&1 || echo "pass $name failed: $(tail -1 $out/$name.log)"
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $out/$name -- python3 $GRAFT_REPO_ROOT/tools/pmc_driver.py $mode > $out/$name.log 2>&1 || echo "pass $name failed: $(tail -1 $out/$name.log)"
 done
 python3 - <<PY
 import csv, glob, collections

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev helper: minimal driver for PMC passes (few dispatches: numpy-generated frames, a handful of launches)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from livescan3d_amd import synth
