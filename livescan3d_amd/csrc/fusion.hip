@@ -585,6 +585,7 @@ struct TriArgs {
     const int *pixmap;   // [n_ticks][pixels per tick]
     int *tri;            // [n_ticks][tri_cap][3]
     int *tile_counts;    // [n_ticks * tiles_per_tick] counts, then exclusive prefixes (scan_kernel)
+    unsigned int *codes; // [n_ticks * tiles_per_tick * 256] per-lane 4-bit-per-pixel triangle codes: count pass -> write pass
     int tiles_per_tick;
     long long tick_pix_stride;  // pixels per tick
     long long tick_tri_stride;  // triangles per tick (capacity)
@@ -672,7 +673,21 @@ __global__ __launch_bounds__(kThreads) void tri_kernel(const TriArgs a)
 #pragma unroll
         for (int c = 0; c <= kPxPerLane; c++) M[r][c] = -1;
 
-    if (VEC) {
+    const size_t code_slot = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (MODE == 1) {
+        // the count pass already evaluated every stencil: reload its verdicts, fetch only the vertex indices
+        code = a.codes[code_slot];
+        if (VEC && code != 0) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int *mrow = map + (long long)(y0 - 1 + r) * w + x0;
+                const int4 m0 = reinterpret_cast<const int4 *>(mrow)[0], m1 = reinterpret_cast<const int4 *>(mrow)[1];
+                M[r][0] = m0.x; M[r][1] = m0.y; M[r][2] = m0.z; M[r][3] = m0.w;
+                M[r][4] = m1.x; M[r][5] = m1.y; M[r][6] = m1.z; M[r][7] = m1.w;
+                M[r][8] = x0 + 8 < w ? mrow[8] : -1;
+            }
+        }
+    } else if (VEC) {
         // w % 8 == 0: the 8 pixels share row y0; window rows y0-2 .. y0+1, columns x0-1 .. x0+9
         const bool row_ok = in_frame && y0 >= 2 && y0 < h - 2;   // :87-90 (bands clamp to [2, h-2))
         if (row_ok) {
@@ -749,6 +764,7 @@ __global__ __launch_bounds__(kThreads) void tri_kernel(const TriArgs a)
         tile_tot += t;
     }
     if (MODE == 0) {
+        a.codes[code_slot] = code;
         if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = tile_tot;
         return;
     }
@@ -1128,7 +1144,7 @@ struct LsnFusion {
     float bounds[6] = {0, 0, 0, 0, 0, 0};
     lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: error flag (word 0) + tickets
     lsn::DevBuf xtab, ytab;
-    lsn::DevBuf pixmap, tri_counts;  // triangulation scratch, allocated on first use
+    lsn::DevBuf pixmap, tri_counts, tri_codes;  // triangulation scratch, allocated on first use
     lsn::DevBuf winner, map_copy, colors_copy, radial;  // radial-correction scratch, allocated on first use
     // pipelined mode: the count + scan of call k+1 run on a side stream while the write kernel of call k is still busy
     bool pipelined = false;
@@ -1499,7 +1515,8 @@ extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d
         std::lock_guard<std::mutex> g(p->mu);
         LSN_HIP(hipSetDevice(p->device));
         if (p->pixmap.reserve(sizeof(int) * (size_t)p->cap * p->n_ticks) ||
-            p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks))
+            p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks) ||
+            p->tri_codes.reserve(sizeof(unsigned int) * (size_t)p->tiles_per_tick * p->n_ticks * kThreads))
             return -1;
         p->want_pixmap = true;
     }
@@ -1516,6 +1533,7 @@ extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d
     t.pixmap = p->pixmap.as<int>();
     t.tri = static_cast<int *>(d_triangles);
     t.tile_counts = p->tri_counts.as<int>();
+    t.codes = p->tri_codes.as<unsigned int>();
     t.tiles_per_tick = p->tiles_per_tick;
     t.tick_pix_stride = p->cap;
     t.tick_tri_stride = 2 * p->cap;
