@@ -170,6 +170,14 @@ int lsnIcpRun(LsnIcp *icp, const float *d_verts1, int n1, float *d_verts2, int n
 int lsnIcpNearest(LsnIcp *icp, const float *d_verts1, int n1, const float *d_verts2, int n2, int *d_idx,
                   float *d_dist2, int nn_mode, void *stream);
 
+/* The whole pose-refinement pass of LiveScanServer (refineWorker_DoWork, LiveScanServer/MainWindowForm.cs:330-410) in one
+ * call: Gauss-Seidel over the sensors x n_refine_iters, each step ICP(all other sensors' current clouds, this sensor's
+ * cloud, Rs[i], Ts[i], n_icp_iters), with every cloud resident in HBM for the whole pass.  clouds[i] = counts[i] x 3 floats
+ * on the HOST, moved in place; world_R (n x 9) / world_t (n x 3), nullable, are updated like worldTransforms[i]
+ * (:382-410, the C# loops as written); Rs_out (n x 9) / Ts_out (n x 3), nullable, receive the accumulated ICP poses. */
+int lsnRefine(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
+              float *world_R, float *world_t, float *Rs_out, float *Ts_out);
+
 /* Per-iteration diagnostics of the last lsnIcpRun (copied to host; synchronises `stream`):
  * out[iter] = {n_matched, n_kept, mean, stddev, T[3], Rn[9]} as 16 floats (counts stored as floats). */
 int lsnIcpTrace(LsnIcp *icp, float *out16_per_iter, int max_iters, void *stream);

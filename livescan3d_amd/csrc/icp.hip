@@ -1007,3 +1007,97 @@ extern "C" int lsnIcpTrace(LsnIcp *w, float *out, int max_iters, void *stream)
     if (n > 0) LSN_HIP(hipMemcpy(out, w->trace.p, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost));
     return n;
 }
+
+// refineWorker_DoWork (LiveScanServer/MainWindowForm.cs:330-410) with every cloud resident in HBM for the whole
+// Gauss-Seidel loop: the reference re-uploads "all other sensors" and the sensor's own cloud for each of the
+// n_sensors x n_refine_iters ICP calls; here each cloud goes up once and comes back once.  The pose composition at the
+// end repeats the C# loops literally, including their in-place update of worldTransforms[i].R while later rows still
+// read it (:398-406).
+extern "C" int lsnRefine(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
+                         float *world_R, float *world_t, float *Rs_out, float *Ts_out)
+{
+    lsn::clear_error();
+    if (n_sensors <= 0 || !clouds || !counts) {
+        lsn::set_error("lsnRefine: bad arguments");
+        return -1;
+    }
+    long long total = 0;
+    int max_n = 0, min_n = 0x7FFFFFFF;
+    for (int i = 0; i < n_sensors; i++) {
+        if (counts[i] < 0 || (counts[i] > 0 && !clouds[i])) {
+            lsn::set_error("lsnRefine: bad cloud %d", i);
+            return -1;
+        }
+        total += counts[i];
+        max_n = counts[i] > max_n ? counts[i] : max_n;
+        min_n = counts[i] < min_n ? counts[i] : min_n;
+    }
+    std::vector<float> Rt((size_t)n_sensors * 12, 0.0f);
+    for (int i = 0; i < n_sensors; i++)
+        for (int j = 0; j < 3; j++) Rt[(size_t)i * 12 + j + j * 3] = 1.0f;   // Rs[i] = I, Ts[i] = 0 (:330-344)
+    const bool runnable = n_sensors >= 2 && min_n > 0 && total - min_n <= 0x7FFFFFFFll && n_refine_iters > 0 && n_icp_iters > 0;
+    if (runnable) {
+        LSN_HIP(hipSetDevice(device));
+        hipStream_t s = nullptr;
+        LSN_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        lsn::DevBuf d_all, d_others, d_Rt;
+        LsnIcp *ws = lsnIcpCreate(device, (int)(total - min_n), max_n);
+        int rc = ws ? 0 : -1;
+        if (!rc) rc = d_all.reserve(sizeof(float) * 3 * (size_t)total) || d_others.reserve(sizeof(float) * 3 * (size_t)(total - min_n)) ||
+                      d_Rt.reserve(sizeof(float) * Rt.size());
+        std::vector<long long> off(n_sensors + 1, 0);
+        for (int i = 0; i < n_sensors; i++) off[i + 1] = off[i] + counts[i];
+        for (int i = 0; i < n_sensors && !rc; i++)
+            rc = hipMemcpyAsync(d_all.as<float>() + 3 * off[i], clouds[i], sizeof(float) * 3 * (size_t)counts[i], hipMemcpyHostToDevice, s) != hipSuccess;
+        if (!rc) rc = hipMemcpyAsync(d_Rt.p, Rt.data(), sizeof(float) * Rt.size(), hipMemcpyHostToDevice, s) != hipSuccess;
+        for (int it = 0; it < n_refine_iters && !rc; it++) {                  // :347
+            for (int i = 0; i < n_sensors && !rc; i++) {                      // :349
+                long long pos = 0;                                             // :352-357 all other sensors' current clouds
+                for (int j = 0; j < n_sensors && !rc; j++) {
+                    if (j == i) continue;
+                    rc = hipMemcpyAsync(d_others.as<float>() + 3 * pos, d_all.as<float>() + 3 * off[j], sizeof(float) * 3 * (size_t)counts[j],
+                                        hipMemcpyDeviceToDevice, s) != hipSuccess;
+                    pos += counts[j];
+                }
+                if (!rc)
+                    rc = lsnIcpRun(ws, d_others.as<float>(), (int)pos, d_all.as<float>() + 3 * off[i], counts[i], d_Rt.as<float>() + 12 * i,
+                                   d_Rt.as<float>() + 12 * i + 9, n_icp_iters, 1, s);     // :370
+            }
+        }
+        // results land in scratch first: the caller's arrays are only touched when everything worked
+        std::vector<float> back((size_t)total * 3);
+        if (!rc) rc = hipMemcpyAsync(back.data(), d_all.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess;
+        if (!rc) rc = hipMemcpyAsync(Rt.data(), d_Rt.p, sizeof(float) * Rt.size(), hipMemcpyDeviceToHost, s) != hipSuccess;
+        if (!rc) rc = hipStreamSynchronize(s) != hipSuccess;
+        if (ws) lsnIcpDestroy(ws);
+        (void)hipStreamDestroy(s);
+        if (rc) {
+            if (lsn::last_error().empty()) lsn::set_error("lsnRefine: %s", hipGetErrorString(hipGetLastError()));
+            return -1;
+        }
+        for (int i = 0; i < n_sensors; i++) memcpy(clouds[i], back.data() + 3 * off[i], sizeof(float) * 3 * (size_t)counts[i]);
+    }
+    // :382-410 pose composition, the C# loops as written
+    if (world_R && world_t) {
+        for (int i = 0; i < n_sensors; i++) {
+            float *WR = world_R + 9 * i, *Wt = world_t + 3 * i;
+            const float *Ri = Rt.data() + 12 * (size_t)i, *Ti = Ri + 9;
+            float tempT[3] = {0, 0, 0};
+            float tempR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < 3; j++) {
+                for (int k = 0; k < 3; k++) tempT[j] += Ti[k] * WR[3 * k + j];
+                Wt[j] += tempT[j];
+            }
+            for (int j = 0; j < 3; j++)
+                for (int k = 0; k < 3; k++) {
+                    for (int l = 0; l < 3; l++) tempR[3 * j + k] += Ri[l * 3 + j] * WR[3 * l + k];
+                    WR[3 * j + k] = tempR[3 * j + k];
+                }
+        }
+    }
+    for (int i = 0; i < n_sensors; i++) {
+        if (Rs_out) memcpy(Rs_out + 9 * i, Rt.data() + 12 * (size_t)i, 9 * sizeof(float));
+        if (Ts_out) memcpy(Ts_out + 3 * i, Rt.data() + 12 * (size_t)i + 9, 3 * sizeof(float));
+    }
+    return 0;
+}

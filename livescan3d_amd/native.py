@@ -24,7 +24,7 @@ EXPORTS = [
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
-    "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace",
+    "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnRefine",
 ]
 
 
@@ -116,6 +116,8 @@ def lib():
     L.lsnIcpRun.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]
     L.lsnIcpNearest.restype = C.c_int
     L.lsnIcpNearest.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
+    L.lsnRefine.restype = C.c_int
+    L.lsnRefine.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.lsnIcpTrace.restype = C.c_int
     L.lsnIcpTrace.argtypes = [vp, vp, C.c_int, vp]
     _lib = L
@@ -240,6 +242,23 @@ def icp(verts1, verts2, R=None, t=None, max_iter=10):
     if err:
         raise NativeUtilsError(err)
     return v2, R.reshape(3, 3), t
+
+
+def refine(clouds, world_R, world_t, n_refine_iters=2, n_icp_iters=10, device=0):
+    """refineWorker_DoWork (MainWindowForm.cs:330-410) through lsnRefine.  clouds: list of [n_i, 3] float arrays.
+    Returns (clouds_out, world_R [n,3,3], world_t [n,3], Rs [n,3,3], Ts [n,3]); inputs are not modified."""
+    require_gpu()
+    cl = [_as(c, np.float32).reshape(-1, 3).copy() for c in clouds]
+    n = np.array([len(c) for c in cl], dtype=np.int32)
+    ptrs = (C.c_void_p * len(cl))(*[c.ctypes.data for c in cl])
+    wR = _as(world_R, np.float32).reshape(-1).copy()
+    wt = _as(world_t, np.float32).reshape(-1).copy()
+    assert wR.size == 9 * len(cl) and wt.size == 3 * len(cl)
+    Rs = np.zeros(9 * len(cl), dtype=np.float32)
+    Ts = np.zeros(3 * len(cl), dtype=np.float32)
+    _check(lib().lsnRefine(int(device), len(cl), C.cast(ptrs, C.c_void_p), _ptr(n), int(n_refine_iters), int(n_icp_iters),
+                           _ptr(wR), _ptr(wt), _ptr(Rs), _ptr(Ts)), "lsnRefine")
+    return cl, wR.reshape(-1, 3, 3), wt.reshape(-1, 3), Rs.reshape(-1, 3, 3), Ts.reshape(-1, 3)
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -127,3 +127,27 @@ def test_icp_edge_cases(gpu, orc):
     R = np.eye(3, dtype=np.float32).ravel(); tt = np.zeros(3, np.float32)
     ret = L.ICP(a.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), 0, 10, R.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), 10)
     assert ret == 1.0 and native.last_error() != "" and np.array_equal(R, np.eye(3, dtype=np.float32).ravel())
+
+
+def test_refine_loop_matches_oracle(gpu, orc):
+    """lsnRefine = refineWorker_DoWork (MainWindowForm.cs:330-410) with the clouds resident in HBM: Gauss-Seidel order,
+    accumulated Rs/Ts, and the C#'s in-place pose composition -- against the oracle's mirror of the same loop."""
+    import time
+    clouds = _scene_clouds(orc, 4, 256, 212, seed=7)
+    n = len(clouds)
+    rng = np.random.default_rng(3)
+    wR = np.stack([synth.rot_y(0.3 * i) @ synth.rot_x(0.1 * i) for i in range(n)]).astype(np.float32)
+    wt = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    t0 = time.perf_counter()
+    got_c, got_R, got_t, got_Rs, got_Ts = native.refine(clouds, wR, wt, n_refine_iters=2, n_icp_iters=5)
+    t_gpu = time.perf_counter() - t0
+    ref_c, ref_R, ref_t, ref_Rs, ref_Ts = orc.refine(clouds, wR, wt, n_refine_iters=2, n_icp_iters=5, n_threads=8)
+    for i in range(n):
+        assert np.abs(got_c[i] - ref_c[i]).max() <= TOL, i
+        assert np.abs(got_c[i] - clouds[i]).max() > 1e-4          # the clouds did move
+    assert np.abs(got_Rs - ref_Rs).max() <= TOL and np.abs(got_Ts - ref_Ts).max() <= TOL
+    assert np.abs(got_R - ref_R).max() <= TOL and np.abs(got_t - ref_t).max() <= TOL
+    # fewer than two sensors: nothing to refine against (MainWindowForm.cs:469-473 guards the same way)
+    c1, R1, t1, Rs1, Ts1 = native.refine(clouds[:1], wR[:1], wt[:1])
+    assert np.array_equal(c1[0], clouds[0]) and np.array_equal(Rs1[0], np.eye(3, dtype=np.float32)) and not Ts1.any()
+    assert np.array_equal(R1[0], wR[0]) and np.array_equal(t1[0], wt[0])
