@@ -403,12 +403,32 @@ __global__ __launch_bounds__(kThreads) void nn_grid_kernel(const float *queries,
     const int cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
     float best = INFINITY;
     int best_i = 0x7FFFFFFF;
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); z++)
-        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); y++)
-            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.nx - 1); x++) {
-                const int c = cell_index(x, y, z, g);
-                scan_range(sorted, cell_start[c], cell_start[c + 1], qx, qy, qz, best, best_i);
-            }
+    // This kernel is a chain of dependent memory round trips per query, not arithmetic: fetch all 27 cell ranges at once
+    // (54 independent loads in flight), then walk them with the point loads issued four at a time.
+    int rs[27], re[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        const int x = cx + (k % 3) - 1, y = cy + ((k / 3) % 3) - 1, z = cz + (k / 9) - 1;
+        const bool in = (unsigned int)x < (unsigned int)g.nx && (unsigned int)y < (unsigned int)g.ny && (unsigned int)z < (unsigned int)g.nz;
+        const int c = in ? cell_index(x, y, z, g) : 0;
+        rs[k] = in ? cell_start[c] : 0;
+        re[k] = in ? cell_start[c + 1] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        int j = rs[k];
+        for (; j + 4 <= re[k]; j += 4) {
+            const float4 p0 = sorted[j], p1 = sorted[j + 1], p2 = sorted[j + 2], p3 = sorted[j + 3];
+            const float d0 = dist2(qx, qy, qz, p0.x, p0.y, p0.z), d1 = dist2(qx, qy, qz, p1.x, p1.y, p1.z);
+            const float d2 = dist2(qx, qy, qz, p2.x, p2.y, p2.z), d3 = dist2(qx, qy, qz, p3.x, p3.y, p3.z);
+            const int k0 = __float_as_int(p0.w), k1 = __float_as_int(p1.w), k2 = __float_as_int(p2.w), k3 = __float_as_int(p3.w);
+            if (d0 < best || (d0 == best && k0 < best_i)) { best = d0; best_i = k0; }
+            if (d1 < best || (d1 == best && k1 < best_i)) { best = d1; best_i = k1; }
+            if (d2 < best || (d2 == best && k2 < best_i)) { best = d2; best_i = k2; }
+            if (d3 < best || (d3 == best && k3 < best_i)) { best = d3; best_i = k3; }
+        }
+        scan_range(sorted, j, re[k], qx, qy, qz, best, best_i);
+    }
     const float bound = g.h * kBoundSlack;
     if (best <= bound * bound) {
         idx[i] = best_i;
