@@ -462,8 +462,11 @@ __global__ __launch_bounds__(kThreads) void nn_far_kernel(const float *queries, 
                                                           const float4 *sorted, const Box *boxes, const Box *supers, const int *far_list,
                                                           const int *n_far, int *idx, float *dist, unsigned long long *keys)
 {
-    constexpr int kChunks = kMaxSupers / 64;  // 16
+    // every super-block's minimum distance lives in LDS (lane l owns entries l, 64 + l, ...): the loops below then run
+    // over the chunks that exist (3 for a typical 2-sensor scene) instead of a compile-time 16
+    __shared__ float s_md[kThreads / 64][kMaxSupers];
     const int lane = threadIdx.x & 63;
+    float *md = s_md[threadIdx.x >> 6];
     const int slot = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);  // one query per wave
     if (slot >= *n_far) return;                                          // wave-uniform
     const int i = far_list[slot];
@@ -472,18 +475,17 @@ __global__ __launch_bounds__(kThreads) void nn_far_kernel(const float *queries, 
     float best = dist[i];  // uniform across the wave from here on
     int best_i = idx[i];
 
-    // every super-block's minimum distance (lane l holds supers l, 64 + l, ...) and the farthest-corner upper bound
-    float md[kChunks];
+    const int n_chunks = (n_supers + 63) >> 6;
     float ub = INFINITY;
-#pragma unroll
-    for (int c = 0; c < kChunks; c++) {
-        md[c] = INFINITY;
+    for (int c = 0; c < n_chunks; c++) {
         const int s = c * 64 + lane;
-        if (c * 64 < n_supers && s < n_supers) {
+        float m = INFINITY;
+        if (s < n_supers) {
             const Box b = supers[s];
-            md[c] = box_min_dist2(qx, qy, qz, b);
+            m = box_min_dist2(qx, qy, qz, b);
             ub = fminf(ub, box_max_dist2(qx, qy, qz, b));
         }
+        md[s] = m;
     }
     float bound = fminf(best, wave_min_f(ub));
 
@@ -491,19 +493,18 @@ __global__ __launch_bounds__(kThreads) void nn_far_kernel(const float *queries, 
         // nearest unvisited super-block
         float m = INFINITY;
         int mc = 0;
-#pragma unroll
-        for (int c = 0; c < kChunks; c++)
-            if (md[c] < m) {
-                m = md[c];
+        for (int c = 0; c < n_chunks; c++) {
+            const float v = md[c * 64 + lane];
+            if (v < m) {
+                m = v;
                 mc = c;
             }
+        }
         const float wm = wave_min_f(m);
         if (!(wm <= bound)) break;  // nothing left that could hold a point at distance <= bound (also ends on NaN)
         const int src = __ffsll((long long)__ballot(m == wm)) - 1;
         const int s = __shfl(mc, src, 64) * 64 + src;
-#pragma unroll
-        for (int c = 0; c < kChunks; c++)
-            if (lane == src && c == mc) md[c] = INFINITY;  // visited (static indices keep md[] in registers)
+        if (lane == src) md[s] = INFINITY;  // visited (only this lane ever reads the entry again)
 
         // its 64 blocks, one per lane
         const Box bb = boxes[s * 64 + lane];
