@@ -202,6 +202,33 @@ def main():
                                "note": "same steps with lsnFusionSetPipelined: the VALU-bound count pass of call k+1 overlaps the "
                                        "HBM-bound write kernel of call k (inputs resident, double-buffered scratch)"}
 
+    # ---- streamed calls (extra field): write(k) and count(k+1) inside one kernel -----------------------------------------
+    if rank == 0 and world == 1 and args.mode == 0:
+        d2 = depth.clone()                       # a second resident batch, so that "next" is a different buffer
+        bufs = [depth, d2]
+        fus.plan.profile(True)
+        fus.plan.kernel_stats(reset=True)
+        def sstep(i):
+            fus.plan.run_streamed(bufs[i & 1].data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(),
+                                  bufs[(i + 1) & 1].data_ptr(), stream)
+        for i in range(args.warmup + 1):
+            sstep(i)
+        torch.cuda.synchronize()
+        fus.plan.kernel_stats(reset=True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sstep(i + args.warmup + 1)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        ks = fus.plan.kernel_stats(reset=True)
+        fus.plan.profile(False)
+        ok = bool(torch.equal(fus.offsets.cpu(), torch.from_numpy(off.astype(np.int32))))
+        result["streamed"] = {"value": B * args.steps / dts, "unit": "frames/s", "ms_per_step": 1e3 * dts / args.steps, "offsets_identical": ok,
+                              "kernel_avg_ms": ks["avg_ms"], "achieved_GBps": alg_bytes / (ks["avg_ms"] * 1e-3) / 1e9 if ks["avg_ms"] > 0 else 0.0,
+                              "note": "lsnFusionRunStreamed: one kernel writes batch k (HBM-bound) and counts the resident batch k+1 "
+                                      "(VALU-bound); same work per step as the default path, no separate count launch"}
+        del d2
+
     # ---- N > 1, extra leg: the same ticks spread over the GPUs instead of the sensors (no exchange step at all) ------
     if world > 1 and not args.no_tick_parallel:
         fus_all = fus

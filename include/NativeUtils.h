@@ -119,6 +119,13 @@ int lsnFusionSetMode(LsnFusion *plan, int mode);
  * stream; outputs and their ordering on the caller's stream are unchanged. */
 int lsnFusionSetPipelined(LsnFusion *plan, int enable);
 
+/* Streamed calls: like lsnFusionRun (mode 0), but while this batch is written the NEXT batch's depth maps
+ * (d_next_depth_maps, already resident; NULL = none) are counted by the same kernel -- the count pass is VALU-bound, the
+ * write pass HBM-bound, so in one kernel they share every CU.  The following call with d_depth_maps == this call's
+ * d_next_depth_maps skips its count pass.  Results are identical to lsnFusionRun. */
+int lsnFusionRunStreamed(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_colors, void *d_vertices, int *d_offsets,
+                         const void *d_next_depth_maps, void *stream);
+
 /* Fuses n_ticks ticks.  d_depth_maps: n_ticks x (concatenated u16 maps of one tick); d_depth_colors likewise RGB8;
  * d_vertices: n_ticks x lsnFusionTickCapacity() VertexC4ubV3f, tick k's merged cloud starts at k*capacity;
  * d_offsets: n_ticks x (n_maps+1) ints, [k][i] = index of sensor i's first vertex inside tick k's cloud,

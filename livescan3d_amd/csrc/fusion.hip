@@ -79,6 +79,8 @@ struct FuseArgs {
     unsigned int *ticket;            // mode 1: per-tick run tickets, 32 words apart
     int *offsets;                    // [n_ticks][n_frames + 1]
     int *pixmap;                     // optional [n_ticks][pixels per tick]: vertex index inside the tick's cloud, -1 = none
+    const unsigned short *depth_next;  // streamed mode (MODE 3): the NEXT batch's depth, counted in the shadow of this write
+    int *tile_counts_next;             // ... and where its per-tile counts go
     int *error_flag;                 // mode 1: set when a bounded spin gives up (sticky until read)
     int n_frames;
     int tiles_per_tick;
@@ -331,13 +333,16 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
 
 // ---- mode 0: count kernel, scan kernel, write kernel ------------------------------------------------------------
 
-// MODE 0 = count only (writes tile_counts), 1 = write with offsets from tile_counts (exclusive prefixes by then).
+// MODE 0 = count only (writes tile_counts), 1 = write with offsets from tile_counts (exclusive prefixes by then),
+// 3 = streamed: mode 1 for this batch AND the count of the same tile of the NEXT batch (depth_next) in one workgroup --
+// the count pass is VALU-bound, the write pass HBM-bound, and inside one kernel they share every CU all the time.
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
 {
     constexpr bool kWrite = MODE != 0;
     __shared__ uint4 stage[kWrite ? (kWin + kWin / 8) : 1];
     __shared__ int s_wave_tot[4];
+    __shared__ int s_wave_next[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tick = blockIdx.x / a.tiles_per_tick;
@@ -346,6 +351,20 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     const Tile t = locate(a, tick, tile);
     Inputs in;
     load_inputs<VEC, kWrite>(t, in);
+    if (MODE == 3) {
+        // the next batch's tile: same geometry, other depth buffer; its loads fly together with this tile's
+        Tile tn = t;
+        tn.dptr = a.depth_next + tick * a.tick_depth_stride + t.pix_base;
+        Inputs nx;
+        load_inputs<VEC, false>(tn, nx);
+        bool keep_n[kPxPerLane];
+        uint4 unused[kPxPerLane];
+        compute_tile<VEC, false>(a, tn, nx, keep_n, unused);
+        int wt = 0;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) wt += __popcll(__ballot(keep_n[k]));
+        if (lane == 0) s_wave_next[wave] = wt;
+    }
     bool keep[kPxPerLane];
     uint4 vert[kPxPerLane];
     compute_tile<VEC, kWrite>(a, t, in, keep, vert);
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     rank_from_masks(keep, below, wave_total);
     if (lane == 0) s_wave_tot[wave] = wave_total;
     int base = 0;
-    if (MODE == 1) base = a.tile_counts[blockIdx.x];  // scan_kernel left the exclusive prefix inside the tick here
+    if (MODE == 1 || MODE == 3) base = a.tile_counts[blockIdx.x];  // scan_kernel left the exclusive prefix inside the tick here
     __syncthreads();
     int wave_off = 0, tile_tot = 0;
 #pragma unroll
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
         if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = tile_tot;
         return;
     }
+    if (MODE == 3 && threadIdx.x == 0) a.tile_counts_next[blockIdx.x] = s_wave_next[0] + s_wave_next[1] + s_wave_next[2] + s_wave_next[3];
     if (a.pixmap) {
         // depth_to_vertices_map (depthprocessing.cpp:166), already rebased to the tick's merged cloud like formMesh
         // rebases triangle indices (:1614-1626): what the triangulation pass reads
@@ -1152,6 +1172,10 @@ struct LsnFusion {
     hipEvent_t ev_counted = nullptr, ev_written[2] = {nullptr, nullptr};
     lsn::DevBuf tile_counts_b, offs_int;  // second count buffer, internal offsets [2][n_ticks][n_maps+1]
     unsigned long long calls = 0;
+    // streamed mode: which batch the "other" half of the count scratch was counted for
+    const void *counted_for = nullptr;
+    unsigned long long counted_gen = 0, params_gen = 1;
+    int stream_half = 0;
     // dominant-kernel timing
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1302,6 +1326,7 @@ extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *
     LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
     memcpy(p->bounds, bounds6, sizeof(p->bounds));
     p->params_set = true;
+    p->params_gen++;  // counts made ahead with the old parameters are void
     return 0;
 }
 
@@ -1373,34 +1398,9 @@ extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *lau
     return 0;
 }
 
-template <int MODE>
-static void launch(bool vec, int grid, hipStream_t s, const FuseArgs &a)
+// Kernel arguments of one call (everything but the per-mode scratch selection).
+static void fill_args(LsnFusion *p, FuseArgs &a, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets)
 {
-    if (vec) hipLaunchKernelGGL((fuse_kernel<MODE, true>), dim3(grid), dim3(kThreads), 0, s, a);
-    else     hipLaunchKernelGGL((fuse_kernel<MODE, false>), dim3(grid), dim3(kThreads), 0, s, a);
-}
-
-extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
-                            void *stream)
-{
-    lsn::clear_error();
-    if (!p || !d_depth || !d_colors || !d_vertices || !d_offsets) {
-        lsn::set_error("lsnFusionRun: null argument");
-        return -1;
-    }
-    if (!p->params_set) {
-        lsn::set_error("lsnFusionRun: lsnFusionSetParams has not been called");
-        return -1;
-    }
-    if (((uintptr_t)d_vertices & 15) != 0) {
-        lsn::set_error("lsnFusionRun: d_vertices must be 16-byte aligned");
-        return -1;
-    }
-    std::lock_guard<std::mutex> g(p->mu);
-    LSN_HIP(hipSetDevice(p->device));
-    hipStream_t s = lsn::as_stream(stream);
-
-    FuseArgs a;
     a.frames = p->frames.as<FrameDesc>();
     a.tiles = p->tile_frame.as<TileDesc>();
     a.params = p->params.as<SensorParams>();
@@ -1436,27 +1436,66 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
     a.minX = p->bounds[0]; a.minY = p->bounds[1]; a.minZ = p->bounds[2];
     a.maxX = p->bounds[3]; a.maxY = p->bounds[4]; a.maxZ = p->bounds[5];
 
+    a.depth_next = nullptr;
+    a.tile_counts_next = nullptr;
+}
+
+// Next HIP-event pair of the dominant-kernel timer (profiling on).
+static int next_event_pair(LsnFusion *p, hipEvent_t &e0, hipEvent_t &e1)
+{
+    if (p->ev_used == p->events.size()) {
+        if (p->events.size() >= 4096) {
+            if (drain_events(p)) return -1;
+        } else {
+            hipEvent_t x, y;
+            LSN_HIP(hipEventCreate(&x));
+            LSN_HIP(hipEventCreate(&y));
+            p->events.emplace_back(x, y);
+        }
+    }
+    e0 = p->events[p->ev_used].first;
+    e1 = p->events[p->ev_used].second;
+    p->ev_used++;
+    return 0;
+}
+
+template <int MODE>
+static void launch(bool vec, int grid, hipStream_t s, const FuseArgs &a)
+{
+    if (vec) hipLaunchKernelGGL((fuse_kernel<MODE, true>), dim3(grid), dim3(kThreads), 0, s, a);
+    else     hipLaunchKernelGGL((fuse_kernel<MODE, false>), dim3(grid), dim3(kThreads), 0, s, a);
+}
+
+extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+                            void *stream)
+{
+    lsn::clear_error();
+    if (!p || !d_depth || !d_colors || !d_vertices || !d_offsets) {
+        lsn::set_error("lsnFusionRun: null argument");
+        return -1;
+    }
+    if (!p->params_set) {
+        lsn::set_error("lsnFusionRun: lsnFusionSetParams has not been called");
+        return -1;
+    }
+    if (((uintptr_t)d_vertices & 15) != 0) {
+        lsn::set_error("lsnFusionRun: d_vertices must be 16-byte aligned");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    hipStream_t s = lsn::as_stream(stream);
+
+    FuseArgs a;
+    fill_args(p, a, d_depth, d_colors, d_vertices, d_offsets);
+
     // the wide-load path also needs 16-B aligned buffers and every tick to start 16-B / 8-B aligned
     const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 &&
                      (p->tick_depth_elems % 8) == 0;
     const int grid = p->tiles_per_tick * p->n_ticks;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (p->profile) {
-        if (p->ev_used == p->events.size()) {
-            if (p->events.size() >= 4096) {
-                if (drain_events(p)) return -1;
-            } else {
-                hipEvent_t x, y;
-                LSN_HIP(hipEventCreate(&x));
-                LSN_HIP(hipEventCreate(&y));
-                p->events.emplace_back(x, y);
-            }
-        }
-        e0 = p->events[p->ev_used].first;
-        e1 = p->events[p->ev_used].second;
-        p->ev_used++;
-    }
+    if (p->profile && next_event_pair(p, e0, e1)) return -1;
 
     if (p->pipelined && p->mode == 0 && !p->want_pixmap) {
         // Count + scan of THIS call go to the side stream: they only read the inputs (promised resident by
@@ -1496,6 +1535,67 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         if (vec) hipLaunchKernelGGL((run_kernel<true>), dim3(rgrid), dim3(kThreads), 0, s, a);
         else     hipLaunchKernelGGL((run_kernel<false>), dim3(rgrid), dim3(kThreads), 0, s, a);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
+    }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+// Streamed calls: this batch is written while the NEXT batch (already resident) is counted by the same kernel.
+extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+                                    const void *d_next_depth, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !d_depth || !d_colors || !d_vertices || !d_offsets) {
+        lsn::set_error("lsnFusionRunStreamed: null argument");
+        return -1;
+    }
+    if (!p->params_set) {
+        lsn::set_error("lsnFusionRunStreamed: lsnFusionSetParams has not been called");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    hipStream_t s = lsn::as_stream(stream);
+    const size_t n_tiles = (size_t)p->tiles_per_tick * p->n_ticks;
+    const size_t off_elems = (size_t)p->n_ticks * (p->n_maps + 1);
+    if (p->tile_counts_b.reserve(sizeof(int) * n_tiles) || p->offs_int.reserve(sizeof(int) * 2 * off_elems)) return -1;
+
+    FuseArgs a;
+    fill_args(p, a, d_depth, d_colors, d_vertices, d_offsets);
+    const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && (p->tick_depth_elems % 8) == 0 &&
+                     (!d_next_depth || ((uintptr_t)d_next_depth & 15) == 0);
+    const int grid = (int)n_tiles;
+    int *cur = p->stream_half ? p->tile_counts_b.as<int>() : p->tile_counts.as<int>();
+    int *nxt = p->stream_half ? p->tile_counts.as<int>() : p->tile_counts_b.as<int>();
+    int *off_cur = p->offs_int.as<int>() + (p->stream_half ? off_elems : 0);
+    int *off_nxt = p->offs_int.as<int>() + (p->stream_half ? 0 : off_elems);
+    a.tile_counts = cur;
+    if (p->counted_for != d_depth || p->counted_gen != p->params_gen) {
+        // nothing (valid) was counted ahead for this batch: do it now, like mode 0
+        a.offsets = off_cur;
+        launch<0>(vec, grid, s, a);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, cur, a.tiles_per_tick, a.frames, a.n_frames, off_cur);
+    }
+    LSN_HIP(hipMemcpyAsync(d_offsets, off_cur, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
+    a.offsets = d_offsets;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (p->profile && next_event_pair(p, e0, e1)) return -1;
+    if (e0) LSN_HIP(hipEventRecord(e0, s));
+    if (d_next_depth) {
+        a.depth_next = static_cast<const unsigned short *>(d_next_depth);
+        a.tile_counts_next = nxt;
+        launch<3>(vec, grid, s, a);
+    } else {
+        launch<1>(vec, grid, s, a);
+    }
+    if (e1) LSN_HIP(hipEventRecord(e1, s));
+    if (d_next_depth) {
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, nxt, a.tiles_per_tick, a.frames, a.n_frames, off_nxt);
+        p->counted_for = d_next_depth;
+        p->counted_gen = p->params_gen;
+        p->stream_half ^= 1;
+    } else {
+        p->counted_for = nullptr;
     }
     LSN_HIP(hipGetLastError());
     return 0;

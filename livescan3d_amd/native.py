@@ -23,7 +23,7 @@ EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
-    "lsnFusionRun", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
+    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnRefine",
 ]
 
@@ -92,6 +92,8 @@ def lib():
     L.lsnFusionSetParams.argtypes = [vp, vp, vp, vp, vp]
     L.lsnFusionSetMode.restype = C.c_int
     L.lsnFusionSetMode.argtypes = [vp, C.c_int]
+    L.lsnFusionRunStreamed.restype = C.c_int
+    L.lsnFusionRunStreamed.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.lsnFusionSetPipelined.restype = C.c_int
     L.lsnFusionSetPipelined.argtypes = [vp, C.c_int]
     L.lsnFusionRun.restype = C.c_int
@@ -307,6 +309,10 @@ class FusionPlan:
 
     def lookback_failed(self, stream=0):
         return int(lib().lsnFusionLookbackFailed(self._h, stream))
+
+    def run_streamed(self, d_depth, d_colors, d_vertices, d_offsets, d_next_depth=None, stream=0):
+        """This batch is written while the next batch's depth (already resident) is counted in the same kernel."""
+        _check(lib().lsnFusionRunStreamed(self._h, d_depth, d_colors, d_vertices, d_offsets, d_next_depth, stream), "lsnFusionRunStreamed")
 
     def profile(self, enable=True):
         _check(lib().lsnFusionProfile(self._h, 1 if enable else 0), "lsnFusionProfile")

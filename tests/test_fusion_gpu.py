@@ -277,3 +277,41 @@ def test_pipelined_calls_match(gpu, orc):
             n = int(oh[k, -1])
             assert n == len(want) and list(np.diff(oh[k])) == list(counts)
             assert v[k, :n].cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_streamed_calls_match(gpu, orc):
+    """lsnFusionRunStreamed: batch k is written while batch k+1 is counted inside the same kernel; a changed parameter set
+    or an unexpected next batch falls back to counting on the spot.  Results identical to the oracle, call after call."""
+    import torch
+    T, N, w, h = 3, 2, 512, 424
+    batches = []
+    for b in range(4):
+        rigs = [synth.make_rig("noise" if b % 2 else "scene", N, w, h, seed=40 + b, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+        batches.append((rigs, torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda(),
+                        torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()))
+    plan = native.FusionPlan(0, T, [w] * N, [h] * N)
+    intr, wt = batches[0][0][0].intr, batches[0][0][0].wt
+    plan.set_params(intr, wt, synth.CROP_BOUNDS)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    order = [0, 1, 2, 3, 3, 1]                      # includes a repeated batch and a batch that was not announced
+    announce = [1, 2, 3, None, 0, None]             # what each call names as "next" (the 5th call lies: next is 0, 1 comes)
+    bounds = synth.CROP_BOUNDS
+    for i, b in enumerate(order):
+        if i == 2:                                   # parameters change: counts made ahead are void
+            bounds = np.array([-1.0, -0.8, -1.2, 1.1, 1.2, 1.3], np.float32)
+            plan.set_params(intr, wt, bounds)
+        rigs, d, c = batches[b]
+        v = torch.zeros((T, plan.capacity, 16), dtype=torch.uint8, device="cuda")
+        o = torch.zeros((T, N + 1), dtype=torch.int32, device="cuda")
+        nxt = batches[announce[i]][1].data_ptr() if announce[i] is not None else None
+        plan.run_streamed(d.data_ptr(), c.data_ptr(), v.data_ptr(), o.data_ptr(), nxt, st)
+        outs.append((rigs, v, o, bounds.copy()))
+    torch.cuda.synchronize()
+    for rigs, v, o, bnd in outs:
+        oh = o.cpu().numpy()
+        for k in range(T):
+            want, counts = orc.generate_mesh_vertices(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, intr, wt, bnd)
+            n = int(oh[k, -1])
+            assert n == len(want) and list(np.diff(oh[k])) == list(counts)
+            assert v[k, :n].cpu().numpy().tobytes() == want.tobytes()
