@@ -244,11 +244,10 @@ __device__ __forceinline__ void load_inputs(const Tile &t, Inputs &in)
 
 // Keep predicates (wave-wide lane masks in SGPR pairs) and, when WRITE, the assembled vertices of a lane's 8 pixels.
 // Branch-free: a zero depth (invalid pixel, :144, or a lane past the frame end) is computed and then dropped.
-template <bool VEC, bool WRITE>
-__device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, const Inputs &in, bool (&keep)[kPxPerLane],
-                                             uint4 (&vert)[kPxPerLane])
+// The column / row factors of a lane's 8 pixels (they depend on the tile geometry only, not on the tick or the batch).
+template <bool VEC>
+__device__ __forceinline__ void tile_factors(const Tile &t, float (&xf)[kPxPerLane], float (&yf)[kPxPerLane])
 {
-    const SensorParams P = a.params[t.f];
     const int p0 = t.px0 + threadIdx.x * kPxPerLane;
     const bool in_frame = p0 < t.npix;
     // (x, y) of the lane's first pixel: the tile starts at (x0, y0) and the lane is v = x0 + 8*tid < w + 2048 columns
@@ -261,7 +260,6 @@ __device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, c
     int y = t.y0 + q;
     if (!in_frame) { x = 0; y = 0; }
     float yfac = t.yt[y];
-    float xf[kPxPerLane], yf[kPxPerLane];
     if (VEC) {
         // w % 8 == 0: the lane's 8 pixels share a row and their columns are 8 consecutive, 32-B aligned table entries
         const float4 x0 = *reinterpret_cast<const float4 *>(t.xt + x);
@@ -284,6 +282,12 @@ __device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, c
             }
         }
     }
+}
+
+template <bool WRITE>
+__device__ __forceinline__ void compute_pixels(const FuseArgs &a, const SensorParams &P, const Inputs &in, const float (&xf)[kPxPerLane],
+                                               const float (&yf)[kPxPerLane], bool (&keep)[kPxPerLane], uint4 (&vert)[kPxPerLane])
+{
 #pragma unroll
     for (int k = 0; k < kPxPerLane; k += 2) {
         const unsigned int d0 = in.dw[k >> 1] & 0xFFFFu, d1 = in.dw[k >> 1] >> 16;
@@ -304,6 +308,16 @@ __device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, c
             }
         }
     }
+}
+
+template <bool VEC, bool WRITE>
+__device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, const Inputs &in, bool (&keep)[kPxPerLane],
+                                             uint4 (&vert)[kPxPerLane])
+{
+    const SensorParams P = a.params[t.f];
+    float xf[kPxPerLane], yf[kPxPerLane];
+    tile_factors<VEC>(t, xf, yf);
+    compute_pixels<WRITE>(a, P, in, xf, yf, keep, vert);
 }
 
 // Stages a tile's survivors in LDS in rank order, window by window, and copies them out with consecutive lanes writing
@@ -351,23 +365,29 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     const Tile t = locate(a, tick, tile);
     Inputs in;
     load_inputs<VEC, kWrite>(t, in);
+    Inputs nx;
     if (MODE == 3) {
         // the next batch's tile: same geometry, other depth buffer; its loads fly together with this tile's
         Tile tn = t;
         tn.dptr = a.depth_next + tick * a.tick_depth_stride + t.pix_base;
-        Inputs nx;
         load_inputs<VEC, false>(tn, nx);
+    }
+    const SensorParams P = a.params[t.f];
+    float xf[kPxPerLane], yf[kPxPerLane];
+    tile_factors<VEC>(t, xf, yf);
+    bool keep[kPxPerLane];
+    uint4 vert[kPxPerLane];
+    compute_pixels<kWrite>(a, P, in, xf, yf, keep, vert);
+    if (MODE == 3) {
+        // same sensor, same tile geometry: the column / row factors and the pose are shared with this batch's tile
         bool keep_n[kPxPerLane];
         uint4 unused[kPxPerLane];
-        compute_tile<VEC, false>(a, tn, nx, keep_n, unused);
+        compute_pixels<false>(a, P, nx, xf, yf, keep_n, unused);
         int wt = 0;
 #pragma unroll
         for (int k = 0; k < kPxPerLane; k++) wt += __popcll(__ballot(keep_n[k]));
         if (lane == 0) s_wave_next[wave] = wt;
     }
-    bool keep[kPxPerLane];
-    uint4 vert[kPxPerLane];
-    compute_tile<VEC, kWrite>(a, t, in, keep, vert);
 
     int below, wave_total;
     rank_from_masks(keep, below, wave_total);
