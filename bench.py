@@ -42,11 +42,15 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-mesh", action="store_true")
+    ap.add_argument("--core-only", action="store_true", help="only the timed region behind `value` (for rocprofv3 summaries): no extra legs")
     ap.add_argument("--padded-exchange", action="store_true", help="N > 1: all-gather full-capacity slabs (no host sync)")
     ap.add_argument("--no-tick-parallel", action="store_true", help="N > 1: skip the extra tick-parallel (no-exchange) leg")
     ap.add_argument("--icp-reps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.core_only:
+        args.no_icp = args.no_cpu = args.no_host_path = args.no_mesh = args.no_tick_parallel = True
+    return args
 
 
 def main():
@@ -186,7 +190,7 @@ def main():
         }
 
     # ---- pipelined calls (extra field): count(k+1) beside write(k) on an internal side stream -------------------------
-    if rank == 0 and world == 1 and args.mode == 0:
+    if rank == 0 and world == 1 and args.mode == 0 and not args.core_only:
         fus.plan.set_pipelined(True)
         for _ in range(args.warmup + 1):
             fus.run(depth, rgb)
@@ -203,7 +207,7 @@ def main():
                                        "HBM-bound write kernel of call k (inputs resident, double-buffered scratch)"}
 
     # ---- streamed calls (extra field): write(k) and count(k+1) inside one kernel -----------------------------------------
-    if rank == 0 and world == 1 and args.mode == 0:
+    if rank == 0 and world == 1 and args.mode == 0 and not args.core_only:
         d2 = depth.clone()                       # a second resident batch, so that "next" is a different buffer
         bufs = [depth, d2]
         fus.plan.profile(True)
