@@ -14,6 +14,10 @@
  *   - exact nearest neighbour (orc_nn_*): PINNED against the reference's vendored
  *     nanoflann 1.1.9 + its PointCloud adaptor compiled from /root/reference
  *     (oracle/_ref/ref_nn, fixtures in tests/golden/nn_*.npz).
+ *   - triangulation (orc_generate_triangles): PINNED against the reference's own
+ *     src/NativeUtils/meshGenerator.cpp compiled where it lies (oracle/_ref/libref_tri.so,
+ *     fixtures in tests/golden/tri_reference.npz).
+ *   - radial correction: PARITY UNPINNED (lives in depthprocessing.cpp, see above).
  *   - rest of ICP (matching, rejection, Kabsch): PARITY UNPINNED (needs OpenCV
  *     3.2.0 core binaries, absent; the only reference ICP test is commented out,
  *     src/NativeUtils/main.cpp:253-268).
@@ -77,8 +81,7 @@ void orc_radial_correction_all(int n_maps, uint8_t *depth_maps, uint8_t *depth_c
  * the bands in order, which is plain raster order over y in [2,h-2), x in [1,w-2).  index_base is added to every
  * index (formMesh rebases by the cumulative vertex count, depthprocessing.cpp:1611-1627).
  * out must hold 2*w*h triangles (3 ints each).  Returns the number of triangles.
- * PARITY UNPINNED: meshGenerator.cpp compiles only together with depthprocessing.h (needs <windows.h> stand-ins) and the
- * reference holds no golden vectors for it. */
+ * PINNED: bit-exact against meshGenerator.cpp itself (oracle/_ref/libref_tri.so, tests/golden/tri_reference.npz). */
 long orc_generate_triangles(const uint16_t *depth, const int *pix_to_vert, int w, int h, int index_base, int *out);
 
 /* generateMeshFromDepthMaps with flags (false,false), complete: vertices (as orc_generate_mesh_vertices) AND the

@@ -231,3 +231,30 @@ def ref_nn(targets, queries):
     dist = np.zeros(len(q), dtype=np.float32)
     _ref.ref_nn_query(_ptr(t), len(t), _ptr(q), len(q), _ptr(idx), _ptr(dist))
     return idx, dist
+
+
+# ---- compiled reference triangulation (oracle/_ref) --------------------------------------------------------
+
+_REF_TRI_SO = os.path.join(_HERE, "_ref", "libref_tri.so")
+_ref_tri = None
+
+
+def have_ref_tri():
+    return os.path.exists(_REF_TRI_SO)
+
+
+def ref_triangles(depth, pix_to_vert):
+    """The reference's own MeshGenerator::generateTrianglesGradients (src/NativeUtils/meshGenerator.cpp compiled from
+    /root/reference).  depth (h,w) u16 = the cropped depth map, pix_to_vert (h*w) int32.  Returns int32 [n,3]."""
+    global _ref_tri
+    if _ref_tri is None:
+        _ref_tri = C.CDLL(_REF_TRI_SO)
+        _ref_tri.ref_generate_triangles.restype = C.c_long
+        _ref_tri.ref_generate_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    h, w = depth.shape
+    p2v = np.ascontiguousarray(pix_to_vert, dtype=np.int32).ravel()
+    assert p2v.size == h * w
+    out = np.zeros((2 * h * w, 3), dtype=np.int32)
+    n = _ref_tri.ref_generate_triangles(_ptr(depth), _ptr(p2v), w, h, _ptr(out))
+    return out[:n].copy()

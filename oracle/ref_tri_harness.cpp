@@ -1,0 +1,22 @@
+// ref_tri_harness.cpp -- drives the REFERENCE's own triangulation.
+//
+// TEST INFRASTRUCTURE ONLY.  Compiled by oracle/Makefile (target _ref/libref_tri.so) together with
+// src/NativeUtils/meshGenerator.cpp where it lies under /root/reference; no reference source is copied
+// into this repository.  Recipe-level accommodations, all on the compiler command line: -D__int64='long long'
+// (MSVC keyword at meshGenerator.cpp:39) and -include cstring (memcpy at :178, which MSVC's <vector> drags in).
+// The call below is the one depthprocessing.cpp:844 / :1677 makes per sensor.
+#include "NativeUtils/meshGenerator.h"
+#include <cstdint>
+#include <cstring>
+
+// depth: w*h u16 (the cropped depth map: rejected pixels already zeroed, depthprocessing.cpp:796-812);
+// pix_to_vert: w*h ints, -1 = no vertex.  out must hold 2*w*h*3 ints.  Returns the triangle count.
+extern "C" long ref_generate_triangles(const uint16_t *depth, const int *pix_to_vert, int w, int h, int *out)
+{
+    std::vector<UINT16> d(depth, depth + (size_t)w * h);
+    std::vector<int> map(pix_to_vert, pix_to_vert + (size_t)w * h);
+    std::vector<TriangleIndexes> tri;
+    MeshGenerator::generateTrianglesGradients(d.data(), map, tri, w, h);
+    if (!tri.empty()) memcpy(out, tri.data(), tri.size() * sizeof(TriangleIndexes));
+    return (long)tri.size();
+}

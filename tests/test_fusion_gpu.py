@@ -315,3 +315,19 @@ def test_streamed_calls_match(gpu, orc):
             n = int(oh[k, -1])
             assert n == len(want) and list(np.diff(oh[k])) == list(counts)
             assert v[k, :n].cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_triangles_match_reference_fixture(gpu):
+    """tests/golden/tri_reference.npz::scene{0,1}_96x80 are the triangle lists the REFERENCE's own meshGenerator.cpp
+    produced (tests/golden/make_tri_golden.py) for the two sensors of this rig; the export must return the same
+    triangles, rebased per sensor (formMesh, depthprocessing.cpp:1614-1626)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tri_reference.npz"))
+    rig = synth.make_rig("scene", 2, 96, 80, seed=9, perturb=False)
+    verts, tris = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights,
+                                                       rig.intr, rig.wt, rig.bounds)
+    n0 = int((z["scene0_96x80_p2v"] >= 0).sum())
+    n1 = int((z["scene1_96x80_p2v"] >= 0).sum())
+    assert len(verts) == n0 + n1
+    want = np.concatenate([z["scene0_96x80_tri"], z["scene1_96x80_tri"] + n0])
+    assert tris.shape == want.shape and np.array_equal(tris, want)

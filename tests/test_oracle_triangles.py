@@ -1,7 +1,10 @@
 """The oracle's triangulation (oracle/lsn_oracle.c::orc_generate_triangles) against an independent pure-Python
 restatement of MeshGenerator::generateTrianglesGradients (src/NativeUtils/meshGenerator.cpp:14-181), including the
-4-thread row-band split the reference uses (:147-181), on small frames.  PARITY UNPINNED (no reference build, no
-reference fixtures): what is pinned is agreement of two independent restatements + committed digests."""
+4-thread row-band split the reference uses (:147-181), on small frames -- and, the pin proper, against the REFERENCE's
+own meshGenerator.cpp: committed fixtures made by tests/golden/make_tri_golden.py from oracle/_ref/libref_tri.so, plus
+a wider live sweep (up to 512x424) whenever that compiled reference is present."""
+import os
+
 import numpy as np
 import pytest
 
@@ -91,3 +94,38 @@ def test_generate_mesh_rebases_indices_per_sensor(orc):
     sensor_of = np.searchsorted(edges, tri, side="right") - 1
     assert (sensor_of[:, 0] == sensor_of[:, 1]).all() and (sensor_of[:, 1] == sensor_of[:, 2]).all()
     assert (np.diff(sensor_of[:, 0]) >= 0).all()                         # sensor-major order
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tri_reference.npz")
+
+
+def test_oracle_equals_reference_fixtures(orc):
+    """tri_reference.npz holds the output of the reference's own generateTrianglesGradients."""
+    z = np.load(GOLDEN)
+    assert len(z["names"]) >= 20
+    for name in z["names"]:
+        depth, p2v, want = z[f"{name}_depth"], z[f"{name}_p2v"], z[f"{name}_tri"]
+        got = orc.generate_triangles(depth, p2v)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+
+
+def test_oracle_equals_compiled_reference_sweep(orc):
+    """Live comparison with oracle/_ref/libref_tri.so (src/NativeUtils/meshGenerator.cpp compiled as it lies)."""
+    if not orc.have_ref_tri():
+        pytest.skip("oracle/_ref/libref_tri.so not built (needs /root/reference)")
+    rng = np.random.default_rng(77)
+    total = 0
+    for (w, h) in ((512, 424), (640, 576), (97, 61), (16, 16), (4, 4), (3, 9), (200, 5)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        for k in range(4):
+            base = rng.integers(300, 9000)
+            d = base + rng.integers(1, 12) * xx + rng.integers(1, 9) * yy + rng.integers(-20, 21, size=(h, w)) * (k % 2) \
+                + 60 * ((xx // rng.integers(3, 40)) % 2) * (k // 2)
+            depth = np.clip(d, 0, 65535).astype(np.uint16)
+            depth[rng.random((h, w)) < 0.04] = 0
+            valid = (depth != 0) & ~(rng.random((h, w)) < 0.02)
+            p2v = np.where(valid.ravel(), np.cumsum(valid.ravel()) - 1, -1).astype(np.int32)
+            got, want = orc.generate_triangles(depth, p2v), orc.ref_triangles(depth, p2v)
+            assert got.shape == want.shape and np.array_equal(got, want), (w, h, k)
+            total += len(want)
+    assert total > 500000
