@@ -75,8 +75,14 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # LSN_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, exchange step, collectives) with whatever world size
+    # was launched, including 1 -- the only way to drive the RCCL calls on a one-GPU box
+    multi = world > 1 or os.environ.get("LSN_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             dist.init_process_group("gloo")
         else:
@@ -105,7 +111,7 @@ def main():
     stream = int(torch.cuda.current_stream().cuda_stream)
 
     xch = None
-    if world > 1:
+    if multi:
         xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
 
     def step():
@@ -116,7 +122,7 @@ def main():
             xch.exchange(fus.vertices, fus.offsets)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -131,7 +137,7 @@ def main():
     sync()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     kstats = fus.plan.kernel_stats(reset=True)
@@ -141,7 +147,7 @@ def main():
     off = fus.offsets.cpu().numpy().astype(np.int64)
     V_local = int(off[:, -1].sum())
     alg_bytes = 2 * P * S_loc * B + 19 * V_local
-    if world > 1:
+    if multi:
         V_total = int(xch.merged_off[:, -1].sum().item())
     else:
         V_total = V_local
@@ -172,7 +178,7 @@ def main():
                 "sensors_per_gpu": S_loc,
                 "survivor_fraction": V_total / float(B * S * P),
                 "compaction": "two-pass" if args.mode == 0 else "look-back",
-                "parallelism": f"sensor-shard{world}" + ("+allgather" if world > 1 else ""),
+                "parallelism": f"sensor-shard{world}" + ("+allgather" if multi else ""),
                 "bounds": [float(x) for x in bounds],
             },
             "roofline": {
@@ -190,7 +196,7 @@ def main():
         }
 
     # ---- pipelined calls (extra field): count(k+1) beside write(k) on an internal side stream -------------------------
-    if rank == 0 and world == 1 and args.mode == 0 and not args.core_only:
+    if rank == 0 and not multi and args.mode == 0 and not args.core_only:
         fus.plan.set_pipelined(True)
         for _ in range(args.warmup + 1):
             fus.run(depth, rgb)
@@ -207,7 +213,7 @@ def main():
                                        "HBM-bound write kernel of call k (inputs resident, double-buffered scratch)"}
 
     # ---- streamed calls (extra field): write(k) and count(k+1) inside one kernel -----------------------------------------
-    if rank == 0 and world == 1 and args.mode == 0 and not args.core_only:
+    if rank == 0 and not multi and args.mode == 0 and not args.core_only:
         d2 = depth.clone()                       # a second resident batch, so that "next" is a different buffer
         bufs = [depth, d2]
         fus.plan.profile(True)
@@ -234,7 +240,7 @@ def main():
         del d2
 
     # ---- N > 1, extra leg: the same ticks spread over the GPUs instead of the sensors (no exchange step at all) ------
-    if world > 1 and not args.no_tick_parallel:
+    if multi and not args.no_tick_parallel:
         fus_all = fus
         d_all, c_all = depth, rgb
         if S_loc != S:
@@ -262,7 +268,7 @@ def main():
             del fus_all, d_all, c_all
 
     # ---- the complete merge call incl. the reference's always-on triangulation (extra field, never `value`) --------
-    if rank == 0 and world == 1 and not args.no_mesh:
+    if rank == 0 and not multi and not args.no_mesh:
         cap = fus.capacity
         tri = torch.empty((B, 2 * cap, 3), dtype=torch.int32, device=dev)
         toff = torch.zeros((B, S_loc + 1), dtype=torch.int32, device=dev)
@@ -285,7 +291,7 @@ def main():
         del tri, toff
 
     # ---- radial correction, the step before the merge call on every tick (extra field) ---------------------------
-    if rank == 0 and world == 1 and not args.no_mesh:
+    if rank == 0 and not multi and not args.no_mesh:
         d2, c2 = depth.clone(), rgb.clone()
         intr_loc = intr_all[7 * s0:7 * (s0 + S_loc)]
         fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
@@ -332,7 +338,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, synth, S, w, h, bounds)
 
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -245,7 +245,7 @@ def have_ref_tri():
 
 def ref_triangles(depth, pix_to_vert):
     """The reference's own MeshGenerator::generateTrianglesGradients (src/NativeUtils/meshGenerator.cpp compiled from
-    /root/reference).  depth (h,w) u16 = the cropped depth map, pix_to_vert (h*w) int32.  Returns int32 [n,3]."""
+    /root/reference).  depth (h,w) u16 = the sensor's depth map, pix_to_vert (h*w) int32.  Returns int32 [n,3]."""
     global _ref_tri
     if _ref_tri is None:
         _ref_tri = C.CDLL(_REF_TRI_SO)

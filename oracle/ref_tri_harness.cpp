@@ -9,7 +9,7 @@
 #include <cstdint>
 #include <cstring>
 
-// depth: w*h u16 (the cropped depth map: rejected pixels already zeroed, depthprocessing.cpp:796-812);
+// depth: w*h u16 (the sensor's depth map as createVertices copies it, depthprocessing.cpp:181);
 // pix_to_vert: w*h ints, -1 = no vertex.  out must hold 2*w*h*3 ints.  Returns the triangle count.
 extern "C" long ref_generate_triangles(const uint16_t *depth, const int *pix_to_vert, int w, int h, int *out)
 {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/tri_*.npz: cropped depth maps + pixel->vertex maps and the triangle list produced by the
+"""Generates tests/golden/tri_*.npz: depth maps + pixel->vertex maps and the triangle list produced by the
 REFERENCE's own MeshGenerator::generateTrianglesGradients (src/NativeUtils/meshGenerator.cpp, compiled where it lies
 under /root/reference by oracle/Makefile into oracle/_ref/libref_tri.so).  Run in the build container:
 
@@ -36,8 +36,9 @@ def cases():
         }
         for name, d in shapes.items():
             depth = np.clip(d, 0, 65535).astype(np.uint16)
-            # vertex map: raster-order ids of the non-zero pixels, with ~5% knocked out (zero depth there as well, the way
-            # createVertices zeroes rejected pixels, depthprocessing.cpp:796-812) and a second 3% knocked out in the map only
+            # vertex map: raster-order ids of the non-zero pixels; ~5% of the pixels get zero depth (sensor dropout) and a
+            # further 3% keep their depth but have no vertex (cropped away: createVertices hands the triangulation the
+            # unmodified depth map, depthprocessing.cpp:181, and -1 in depth_to_vertices_map, :128,165)
             drop = rng.random((h, w)) < 0.05
             depth = np.where(drop, 0, depth).astype(np.uint16)
             valid = (depth != 0) & ~(rng.random((h, w)) < 0.03)
@@ -48,8 +49,7 @@ def cases():
         depth = np.frombuffer(rig.depth_maps, dtype=np.uint16)[i * 96 * 80:(i + 1) * 96 * 80].reshape(80, 96)
         rgb = np.frombuffer(rig.depth_colors, dtype=np.uint8)[i * 96 * 80 * 3:(i + 1) * 96 * 80 * 3].reshape(80, 96, 3)
         v, v2p, p2v = orc.create_vertices(depth, rgb, rig.intr[i * 7:(i + 1) * 7], rig.wt[i * 12:(i + 1) * 12], rig.bounds, want_maps=True)
-        cropped = np.where(p2v.reshape(80, 96) >= 0, depth, 0).astype(np.uint16)
-        out.append((f"scene{i}_96x80", cropped, p2v.astype(np.int32)))
+        out.append((f"scene{i}_96x80", depth.copy(), p2v.astype(np.int32)))      # the full depth map, as the reference passes it
     return out
 
 
