@@ -189,6 +189,75 @@ int lsnRefine(int device, int n_sensors, float *const *clouds, const int *counts
  * out[iter] = {n_matched, n_kept, mean, stddev, T[3], Rn[9]} as 16 floats (counts stored as floats). */
 int lsnIcpTrace(LsnIcp *icp, float *out16_per_iter, int max_iters, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Part 3 -- the data formats either side of the path.
+ *
+ * Outbound, built on the device from a cloud / mesh that is already in HBM (e.g. the outputs of lsnFusionRunMesh):
+ * the byte stream TransferSocket.SendFrame writes (LiveScanServer/TransferSocket.cs:50-104) for the chunks
+ * TransferServer forms (formMeshChunks, LiveScanServer/TransferServer.cs:203-270, when there are triangles, else
+ * formVerticesChunks, :177-201), and the file Utils.saveToPly(binary) writes (LiveScanServer/Utils.cs:222-262).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct LsnTransfer LsnTransfer;
+
+/* Workspace for clouds of at most max_vertices vertices / max_triangles triangles. */
+LsnTransfer *lsnTransferCreate(int device, int max_vertices, int max_triangles);
+void lsnTransferDestroy(LsnTransfer *t);
+
+/* Upper bound on the length of the SendFrame stream. */
+long long lsnTransferFrameBound(int n_vertices, int n_triangles);
+
+/* d_vertices: n_vertices VertexC4ubV3f, d_triangles: n_triangles x 3 ints (may be null when n_triangles == 0), both on
+ * the device.  Writes to d_out (device, 4-byte aligned, out_cap bytes):
+ *   int nVertices, int nTriangles, int nChunks, int vChunkSizes[nChunks], int tChunkSizes[nChunks],
+ *   float xyz[3*nVertices], u8 rgb[3*nVertices], int tri[3*nTriangles]
+ * where, as in formMeshChunks, vertices are re-emitted per chunk in order of first use, triangle indices are
+ * chunk-local, a chunk closes at the first triangle end with >= 64997 vertices (and the first chunk's triangle count
+ * is one short when there are several chunks, TransferServer.cs:244).  Returns the stream length in bytes, -1 on
+ * error (an index outside [0, n_vertices) is an error; the reference would throw).  Synchronises `stream`. */
+long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles,
+                          void *d_out, long long out_cap, void *stream);
+
+/* Binary PLY: header + 15-byte vertex records {f32 x,y,z; u8 r,g,b} + 13-byte face records {u8 3; i32 a,b,c}.
+ * lsnPlyBinaryBytes gives the exact file length; lsnPlyPack writes the file image to d_out (device, any alignment),
+ * asynchronously on `stream`, and returns its length (-1 on error). */
+long long lsnPlyBinaryBytes(int n_vertices, int n_triangles);
+long long lsnPlyPack(int device, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles, void *d_out,
+                     long long out_cap, void *stream);
+
+/* Host callers (LiveScanServer): the mesh the last generateMeshFromDepthMaps / generateVerticesFromDepthMap call returned
+ * is still in HBM; these build its SendFrame stream / binary PLY image there and copy the bytes to `out` (host).  With
+ * out == NULL they return an upper bound on (stream) / the exact (PLY) length.  Return the length, -1 on error. */
+long long lsnLastMeshTransferFrame(unsigned char *out, long long out_cap);
+long long lsnLastMeshPly(unsigned char *out, long long out_cap);
+
+/* Inbound (host-side parsing, no device work): the client's frame message -- LiveScanClient::SerializeFrame
+ * (src/LiveScanClient/liveScanClient.cpp:185-290) as KinectSocket.ReceiveFrame reads it
+ * (LiveScanServer/KinectSocket.cs:211-304): 16-byte header {i32 payload bytes, i32 compressed, i32 w, i32 h}, then
+ * the payload (one zstd frame when compressed == 1) = u16 depth[w*h], u8 rgb[3*w*h], body block.  zstd is the system
+ * libzstd.so.1, loaded on first use (the reference P/Invokes libzstd.dll, LiveScanServer/ZSTDDecompressor.cs:13-31). */
+typedef struct LsnFrameInfo { int payload_bytes, compressed, width, height; } LsnFrameInfo;
+
+int lsnZstdAvailable(void);
+/* 0 = a frame follows, 1 = "no more frames" (payload_bytes <= 0, KinectSocket.cs:231-235), -1 = malformed. */
+int lsnFrameParseHeader(const unsigned char *header16, LsnFrameInfo *info);
+/* Copies depth (w*h*2 bytes), rgb (w*h*3) and the body block (at most bodies_cap bytes) out of a payload; any of the
+ * three outputs may be null.  Returns the length of the body block (>= 4), -1 on error. */
+long long lsnFrameDecode(const unsigned char *payload, int payload_bytes, int compressed, int width, int height,
+                         unsigned char *depth_out, unsigned char *rgb_out, unsigned char *bodies_out, int bodies_cap,
+                         int *n_bodies);
+/* The inverse (SerializeFrame after its colour mapping): header + payload into out; compression_level 0 = raw,
+ * > 0 = zstd at that level.  bodies may be null (= no bodies).  Returns the message length, -1 on error. */
+long long lsnFrameEncode(const unsigned char *depth, const unsigned char *rgb, int width, int height, const unsigned char *bodies,
+                         int bodies_bytes, int compression_level, unsigned char *out, long long out_cap);
+
+/* The client's recording file (src/LiveScanClient/frameFileWriterReader.cpp:59-82 reader, :115-130 writer): records
+ * "bufferSize= %d\nframe_timestamp= %d\n" + frame message + "\n", parsed from / appended to a memory image of the
+ * file.  lsnRecordingNext returns the position after the record at `pos` (-1 at the end of the file or on a malformed
+ * record -- then lsnGetLastError is non-empty); lsnRecordingAppend returns the bytes written (-1 when out is too small). */
+long long lsnRecordingNext(const unsigned char *file, long long len, long long pos, long long *frame_off, int *frame_len,
+                           int *timestamp_ms);
+long long lsnRecordingAppend(unsigned char *out, long long cap, const unsigned char *frame, int len, int timestamp_ms);
+
 #ifdef __cplusplus
 }
 #endif

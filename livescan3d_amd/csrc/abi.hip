@@ -67,6 +67,11 @@ struct Ctx {
     std::unordered_map<void *, size_t> live;          // ptr -> capacity (bytes)
     std::multimap<size_t, void *> pool;               // capacity -> ptr
     std::unordered_map<void *, int> live_tri;         // triangles arrays we own
+    // the mesh of the last merge / single-sensor call is still in d_out / d_tri (lsnLastMesh* read it there)
+    int last_nv = -1, last_nt = 0;
+    LsnTransfer *xfer = nullptr;
+    int xfer_v = 0, xfer_t = 0;
+    lsn::DevBuf d_wire;
 };
 
 Ctx &ctx()
@@ -194,6 +199,7 @@ int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const u
     } else {
         if (lsnFusionRun(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.stream)) return -1;
     }
+    c.last_nv = -1;                                   // d_out / d_tri are being overwritten
     LSN_HIP(hipMemcpyAsync(off.data(), c.d_off.p, sizeof(int) * (count + 1), hipMemcpyDeviceToHost, c.stream));
     LSN_HIP(hipStreamSynchronize(c.stream));
     const int nv = off[count];
@@ -219,6 +225,8 @@ int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const u
     if (nv > 0) LSN_HIP(hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, c.stream));
     if (nt > 0) LSN_HIP(hipMemcpyAsync(host_tri, c.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, c.stream));
     if (nv > 0 || nt > 0) LSN_HIP(hipStreamSynchronize(c.stream));
+    c.last_nv = nv;
+    c.last_nt = nt;
     out->nVertices = nv;
     out->vertices = static_cast<VertexC4ubV3f *>(host);
     out->nTriangles = nt;
@@ -389,4 +397,63 @@ extern "C" float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2,
     memcpy(R, Rt, sizeof(float) * 9);
     memcpy(t, Rt + 9, sizeof(float) * 3);
     return error;
+}
+
+// ---- the outbound formats of the mesh the last merge call left in HBM (include/NativeUtils.h part 3) ----------------------------
+
+namespace {
+// requires c.mu held; kind 0 = TransferSocket.SendFrame stream, 1 = binary PLY file image
+long long last_mesh_bytes(Ctx &c, int kind, unsigned char *out, long long out_cap)
+{
+    if (ensure_ready(c)) return -1;
+    if (c.last_nv < 0) {
+        lsn::set_error("lsnLastMesh*: no mesh is resident (call generateMeshFromDepthMaps / generateVerticesFromDepthMap first)");
+        return -1;
+    }
+    const int nv = c.last_nv, nt = c.last_nt;
+    const long long bound = kind == 0 ? lsnTransferFrameBound(nv, nt) : lsnPlyBinaryBytes(nv, nt);
+    if (!out) return bound;
+    if (c.d_wire.reserve((size_t)bound + 16)) return -1;
+    long long n = -1;
+    if (kind == 0) {
+        if (!c.xfer || nv > c.xfer_v || nt > c.xfer_t) {
+            if (c.xfer) lsnTransferDestroy(c.xfer);
+            c.xfer_v = nv > c.xfer_v ? nv : c.xfer_v;
+            c.xfer_t = nt > c.xfer_t ? nt : c.xfer_t;
+            c.xfer = lsnTransferCreate(c.device, c.xfer_v, c.xfer_t);
+            if (!c.xfer) {
+                c.xfer_v = c.xfer_t = 0;
+                return -1;
+            }
+        }
+        n = lsnTransferPack(c.xfer, c.d_out.p, nv, nt > 0 ? c.d_tri.as<int>() : nullptr, nt, c.d_wire.p, bound, c.stream);
+    } else {
+        n = lsnPlyPack(c.device, c.d_out.p, nv, nt > 0 ? c.d_tri.as<int>() : nullptr, nt, c.d_wire.p, bound, c.stream);
+    }
+    if (n < 0) return -1;
+    if (n > out_cap) {
+        (void)hipStreamSynchronize(c.stream);
+        lsn::set_error("lsnLastMesh*: the result is %lld bytes, the buffer holds %lld", n, out_cap);
+        return -1;
+    }
+    LSN_HIP(hipMemcpyAsync(out, c.d_wire.p, (size_t)n, hipMemcpyDeviceToHost, c.stream));
+    LSN_HIP(hipStreamSynchronize(c.stream));
+    return n;
+}
+}  // namespace
+
+extern "C" long long lsnLastMeshTransferFrame(unsigned char *out, long long out_cap)
+{
+    lsn::clear_error();
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return last_mesh_bytes(c, 0, out, out_cap);
+}
+
+extern "C" long long lsnLastMeshPly(unsigned char *out, long long out_cap)
+{
+    lsn::clear_error();
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return last_mesh_bytes(c, 1, out, out_cap);
 }

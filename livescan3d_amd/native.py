@@ -25,6 +25,9 @@ EXPORTS = [
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnRefine",
+    "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
+    "lsnLastMeshTransferFrame", "lsnLastMeshPly",
+    "lsnZstdAvailable", "lsnFrameParseHeader", "lsnFrameDecode", "lsnFrameEncode", "lsnRecordingNext", "lsnRecordingAppend",
 ]
 
 
@@ -38,6 +41,11 @@ class Mesh(C.Structure):
 
 
 assert C.sizeof(Mesh) == 32
+
+
+class FrameInfo(C.Structure):
+    """LsnFrameInfo: the 16-byte header of a frame message (KinectSocket.cs:229-239)."""
+    _fields_ = [("payload_bytes", C.c_int), ("compressed", C.c_int), ("width", C.c_int), ("height", C.c_int)]
 
 _lib = None
 
@@ -122,6 +130,35 @@ def lib():
     L.lsnRefine.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.lsnIcpTrace.restype = C.c_int
     L.lsnIcpTrace.argtypes = [vp, vp, C.c_int, vp]
+    ll = C.c_longlong
+    L.lsnTransferCreate.restype = vp
+    L.lsnTransferCreate.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.lsnTransferDestroy.restype = None
+    L.lsnTransferDestroy.argtypes = [vp]
+    L.lsnTransferFrameBound.restype = ll
+    L.lsnTransferFrameBound.argtypes = [C.c_int, C.c_int]
+    L.lsnTransferPack.restype = ll
+    L.lsnTransferPack.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, ll, vp]
+    L.lsnPlyBinaryBytes.restype = ll
+    L.lsnPlyBinaryBytes.argtypes = [C.c_int, C.c_int]
+    L.lsnPlyPack.restype = ll
+    L.lsnPlyPack.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, ll, vp]
+    L.lsnLastMeshTransferFrame.restype = ll
+    L.lsnLastMeshTransferFrame.argtypes = [vp, ll]
+    L.lsnLastMeshPly.restype = ll
+    L.lsnLastMeshPly.argtypes = [vp, ll]
+    L.lsnZstdAvailable.restype = C.c_int
+    L.lsnZstdAvailable.argtypes = []
+    L.lsnFrameParseHeader.restype = C.c_int
+    L.lsnFrameParseHeader.argtypes = [vp, C.POINTER(FrameInfo)]
+    L.lsnFrameDecode.restype = ll
+    L.lsnFrameDecode.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.lsnFrameEncode.restype = ll
+    L.lsnFrameEncode.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, ll]
+    L.lsnRecordingNext.restype = ll
+    L.lsnRecordingNext.argtypes = [vp, ll, ll, C.POINTER(ll), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.lsnRecordingAppend.restype = ll
+    L.lsnRecordingAppend.argtypes = [vp, ll, vp, C.c_int, C.c_int]
     _lib = L
     return L
 
@@ -380,3 +417,147 @@ class IcpWorkspace:
             self.close()
         except Exception:
             pass
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Part 3: wire / disk formats either side of the path
+# ----------------------------------------------------------------------------------------------------------
+
+class TransferPacker:
+    """LsnTransfer: builds the TransferSocket.SendFrame byte stream (TransferSocket.cs:50-104; chunks as
+    TransferServer.cs:177-270) on the device."""
+
+    def __init__(self, device, max_vertices, max_triangles):
+        require_gpu()
+        self.h = lib().lsnTransferCreate(int(device), int(max_vertices), int(max_triangles))
+        if not self.h:
+            raise NativeUtilsError(f"lsnTransferCreate failed: {last_error()}")
+
+    def pack(self, d_vertices, n_vertices, d_triangles, n_triangles, d_out, out_cap, stream=0):
+        n = lib().lsnTransferPack(self.h, d_vertices, int(n_vertices), d_triangles or None, int(n_triangles), d_out, int(out_cap), stream or None)
+        if n < 0:
+            raise NativeUtilsError(f"lsnTransferPack failed: {last_error()}")
+        return int(n)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lsnTransferDestroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def transfer_frame_bound(n_vertices, n_triangles):
+    return int(lib().lsnTransferFrameBound(int(n_vertices), int(n_triangles)))
+
+
+def ply_binary_bytes(n_vertices, n_triangles):
+    return int(lib().lsnPlyBinaryBytes(int(n_vertices), int(n_triangles)))
+
+
+def ply_pack(device, d_vertices, n_vertices, d_triangles, n_triangles, d_out, out_cap, stream=0):
+    require_gpu()
+    n = lib().lsnPlyPack(int(device), d_vertices, int(n_vertices), d_triangles or None, int(n_triangles), d_out, int(out_cap), stream or None)
+    if n < 0:
+        raise NativeUtilsError(f"lsnPlyPack failed: {last_error()}")
+    return int(n)
+
+
+def _last_mesh(fn, what):
+    require_gpu()
+    cap = fn(None, 0)
+    if cap < 0:
+        raise NativeUtilsError(f"{what} failed: {last_error()}")
+    out = np.zeros(cap, dtype=np.uint8)
+    n = fn(_ptr(out), cap)
+    if n < 0:
+        raise NativeUtilsError(f"{what} failed: {last_error()}")
+    return out[:n].tobytes()
+
+
+def last_mesh_transfer_frame():
+    """SendFrame stream (TransferSocket.cs:50-104) of the mesh the last merge call returned, built in HBM."""
+    return _last_mesh(lib().lsnLastMeshTransferFrame, "lsnLastMeshTransferFrame")
+
+
+def last_mesh_ply():
+    """Binary PLY file image (Utils.cs:222-262) of the mesh the last merge call returned, built in HBM."""
+    return _last_mesh(lib().lsnLastMeshPly, "lsnLastMeshPly")
+
+
+def zstd_available():
+    return bool(lib().lsnZstdAvailable())
+
+
+def frame_parse_header(header16):
+    """Returns FrameInfo, or None for the "no more frames" header (payload_bytes <= 0)."""
+    buf = np.frombuffer(bytes(header16[:16]), dtype=np.uint8)
+    if buf.size != 16:
+        raise NativeUtilsError("a frame header is 16 bytes")
+    info = FrameInfo()
+    rc = lib().lsnFrameParseHeader(_ptr(buf), C.byref(info))
+    if rc < 0:
+        raise NativeUtilsError(f"lsnFrameParseHeader failed: {last_error()}")
+    return None if rc == 1 else info
+
+
+def frame_decode(message):
+    """One whole frame message (header + payload) -> (depth u16 [h,w], rgb u8 [h,w,3], bodies bytes, n_bodies)."""
+    msg = np.frombuffer(bytes(message), dtype=np.uint8)
+    info = frame_parse_header(msg[:16])
+    if info is None:
+        return None
+    if 16 + info.payload_bytes > msg.size:
+        raise NativeUtilsError("frame message shorter than its header says")
+    w, h = info.width, info.height
+    depth = np.zeros((h, w), dtype=np.uint16)
+    rgb = np.zeros((h, w, 3), dtype=np.uint8)
+    bodies = np.zeros(1 << 16, dtype=np.uint8)
+    nb = C.c_int(0)
+    payload = np.ascontiguousarray(msg[16:16 + info.payload_bytes])
+    bl = lib().lsnFrameDecode(_ptr(payload), info.payload_bytes, info.compressed, w, h, _ptr(depth), _ptr(rgb), _ptr(bodies), bodies.size, C.byref(nb))
+    if bl < 0:
+        raise NativeUtilsError(f"lsnFrameDecode failed: {last_error()}")
+    return depth, rgb, bodies[:bl].tobytes(), nb.value
+
+
+def frame_encode(depth, rgb, bodies=None, compression_level=0):
+    depth = _as(depth, np.uint16)
+    h, w = depth.shape
+    rgb = _as(rgb, np.uint8).reshape(h, w, 3)
+    b = np.frombuffer(bodies, dtype=np.uint8) if bodies else None
+    out = np.zeros(16 + 5 * w * h + (b.size if b is not None else 4) + 1024 + (w * h * 5) // 64, dtype=np.uint8)
+    n = lib().lsnFrameEncode(_ptr(depth), _ptr(rgb), w, h, _ptr(b) if b is not None else None, b.size if b is not None else 0,
+                             int(compression_level), _ptr(out), out.size)
+    if n < 0:
+        raise NativeUtilsError(f"lsnFrameEncode failed: {last_error()}")
+    return out[:n].tobytes()
+
+
+def recording_frames(file_bytes):
+    """Iterates (timestamp_ms, frame message bytes) over the memory image of a client recording file."""
+    buf = np.frombuffer(file_bytes, dtype=np.uint8)
+    pos = 0
+    off, ln, ts = C.c_longlong(0), C.c_int(0), C.c_int(0)
+    while True:
+        nxt = lib().lsnRecordingNext(_ptr(buf), buf.size, pos, C.byref(off), C.byref(ln), C.byref(ts))
+        if nxt < 0:
+            err = last_error()
+            if err:
+                raise NativeUtilsError(err)
+            return
+        yield ts.value, buf[off.value:off.value + ln.value].tobytes()
+        pos = nxt
+
+
+def recording_append(frame, timestamp_ms):
+    f = np.frombuffer(bytes(frame), dtype=np.uint8)
+    out = np.zeros(f.size + 96, dtype=np.uint8)
+    n = lib().lsnRecordingAppend(_ptr(out), out.size, _ptr(f) if f.size else None, f.size, int(timestamp_ms))
+    if n < 0:
+        raise NativeUtilsError(f"lsnRecordingAppend failed: {last_error()}")
+    return out[:n].tobytes()

@@ -9,6 +9,7 @@
 #include "lsn_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -749,4 +750,241 @@ void orc_refine(int n_sensors, float **clouds, const int *n, int n_refine_iters,
     if (Rs_out) memcpy(Rs_out, Rs, sizeof(float) * 9 * (size_t)n_sensors);
     if (Ts_out) memcpy(Ts_out, Ts, sizeof(float) * 3 * (size_t)n_sensors);
     free(others); free(Ts); free(Rs);
+}
+
+/* ======================================================================================================
+ * Wire / disk formats
+ * ====================================================================================================== */
+
+/* TransferServer.cs:177-201 (no triangles) and :203-270 (mesh) */
+int orc_form_chunks(const orc_vertex *v, int nv, const int *tri, int nt, orc_vertex *new_v, int *new_tri,
+                    int *v_chunks, int *t_chunks, int *n_new_v)
+{
+    const int limit = ORC_CHUNK_LIMIT;
+    int n_chunks = 0;
+    if (nt <= 0) {                                   /* formVerticesChunks :177-201 */
+        int cur = 0;
+        while (cur < nv) {
+            int size = nv - cur < limit ? nv - cur : limit;
+            v_chunks[n_chunks] = size;
+            t_chunks[n_chunks] = 0;
+            n_chunks++;
+            cur += size;
+        }
+        memcpy(new_v, v, (size_t)nv * sizeof(orc_vertex));
+        *n_new_v = nv;
+        return n_chunks;
+    }
+    int *chunk_index = (int *)malloc((size_t)(nv > 0 ? nv : 1) * sizeof(int));
+    int *vertices_map = (int *)malloc((size_t)(nv > 0 ? nv : 1) * sizeof(int));
+    for (int i = 0; i < nv; i++) chunk_index[i] = -1;                          /* :221-222 */
+    int triangles_chunk_start = 0, current_chunk = 0, current_vertex = 0, in_chunk = 0;
+    for (int t = 0; t < nt * 3; t++) {                                          /* :230-254 */
+        const int val = tri[t];
+        if (chunk_index[val] != current_chunk) {
+            new_v[current_vertex] = v[val];
+            vertices_map[val] = in_chunk;
+            chunk_index[val] = current_chunk;
+            current_vertex++;
+            new_tri[t] = in_chunk;
+            in_chunk++;
+        } else {
+            new_tri[t] = vertices_map[val];
+        }
+        if (in_chunk >= limit && ((t + 1) % 3) == 0) {
+            current_chunk++;
+            v_chunks[n_chunks] = in_chunk;
+            t_chunks[n_chunks] = (t - triangles_chunk_start) / 3;
+            n_chunks++;
+            in_chunk = 0;
+            triangles_chunk_start = t;                                          /* sic: t, not t + 1 */
+        }
+    }
+    if (in_chunk != 0) {                                                        /* :256-260 */
+        v_chunks[n_chunks] = in_chunk;
+        t_chunks[n_chunks] = (nt * 3 - triangles_chunk_start) / 3;
+        n_chunks++;
+    }
+    free(chunk_index);
+    free(vertices_map);
+    *n_new_v = current_vertex;
+    return n_chunks;
+}
+
+static void put_i32(uint8_t *p, int v) { memcpy(p, &v, 4); }
+
+/* TransferSocket.cs:50-104 */
+long orc_transfer_frame(const orc_vertex *v, int nv, const int *tri, int nt, uint8_t *out, long cap)
+{
+    const long max_v = nt > 0 ? 3L * nt : nv;
+    const long max_chunks = 3L * (nt > 0 ? nt : 0) / ORC_CHUNK_LIMIT + nv / ORC_CHUNK_LIMIT + 2;
+    orc_vertex *nvv = (orc_vertex *)malloc((size_t)(max_v > 0 ? max_v : 1) * sizeof(orc_vertex));
+    int *ntri = (int *)malloc((size_t)(nt > 0 ? 3L * nt : 1) * sizeof(int));
+    int *vc = (int *)malloc((size_t)max_chunks * sizeof(int)), *tc = (int *)malloc((size_t)max_chunks * sizeof(int));
+    int n_send = 0;
+    const int n_chunks = orc_form_chunks(v, nv, tri, nt, nvv, ntri, vc, tc, &n_send);
+    const int n_tri = nt > 0 ? nt : 0;
+    const long need = 12 + 8L * n_chunks + 15L * n_send + 12L * n_tri;
+    long ret = need;
+    if (need > cap) {
+        ret = -need;
+    } else {
+        uint8_t *p = out;
+        put_i32(p, n_send); put_i32(p + 4, n_tri); put_i32(p + 8, n_chunks);   /* :92-94 */
+        p += 12;
+        memcpy(p, vc, 4L * n_chunks); p += 4L * n_chunks;                       /* :95 */
+        memcpy(p, tc, 4L * n_chunks); p += 4L * n_chunks;                       /* :96 */
+        for (int i = 0; i < n_send; i++) {                                      /* :97, packed at :66-75 */
+            memcpy(p + 12L * i, &nvv[i].X, 4); memcpy(p + 12L * i + 4, &nvv[i].Y, 4); memcpy(p + 12L * i + 8, &nvv[i].Z, 4);
+        }
+        p += 12L * n_send;
+        for (int i = 0; i < n_send; i++) { p[3L * i] = nvv[i].R; p[3L * i + 1] = nvv[i].G; p[3L * i + 2] = nvv[i].B; }   /* :98 */
+        p += 3L * n_send;
+        if (n_tri) memcpy(p, ntri, 12L * n_tri);                                /* :99 */
+    }
+    free(nvv); free(ntri); free(vc); free(tc);
+    return ret;
+}
+
+/* Utils.cs:222-262 (binary branch) */
+long orc_ply_binary(const orc_vertex *v, int nv, const int *tri, int nt, uint8_t *out, long cap)
+{
+    char hdr[512];
+    const int hl = snprintf(hdr, sizeof hdr,
+                            "ply\nformat binary_little_endian 1.0\r\n"                       /* WriteLine :234 */
+                            "element vertex %d\n"
+                            "property float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+                            "element face %d\n"
+                            "property list uchar int vertex_index\n"
+                            "end_header\n", nv, nt);
+    const long need = hl + 15L * nv + 13L * nt;
+    if (need > cap) return -need;
+    uint8_t *p = out;
+    memcpy(p, hdr, (size_t)hl); p += hl;
+    for (int j = 0; j < nv; j++) {                                              /* :246-255 */
+        memcpy(p, &v[j].X, 4); memcpy(p + 4, &v[j].Y, 4); memcpy(p + 8, &v[j].Z, 4);
+        p[12] = v[j].R; p[13] = v[j].G; p[14] = v[j].B;
+        p += 15;
+    }
+    for (int j = 0; j < nt; j++) {                                              /* :257-263 */
+        p[0] = 3;
+        memcpy(p + 1, tri + 3L * j, 12);
+        p += 13;
+    }
+    return need;
+}
+
+/* walks the serialized body block (liveScanClient.cpp:233-268 / KinectSocket.cs:262-303); returns its length or -1 */
+static long body_block_length(const uint8_t *b, long avail, int *n_bodies)
+{
+    if (avail < 4) return -1;
+    int nb;
+    memcpy(&nb, b, 4);
+    if (nb < 0) return -1;
+    long pos = 4;
+    for (int i = 0; i < nb; i++) {
+        if (pos + 5 > avail) return -1;
+        int nj;
+        memcpy(&nj, b + pos + 1, 4);
+        if (nj < 0) return -1;
+        pos += 5 + 28L * nj;
+        if (pos > avail) return -1;
+    }
+    *n_bodies = nb;
+    return pos;
+}
+
+long orc_frame_encode(const uint8_t *depth, const uint8_t *rgb, int w, int h, const uint8_t *bodies, int bodies_bytes,
+                      uint8_t *out, long cap)
+{
+    const long P = (long)w * h;
+    static const uint8_t no_bodies[4] = {0, 0, 0, 0};
+    if (!bodies || bodies_bytes < 4) { bodies = no_bodies; bodies_bytes = 4; }
+    const long size = 5 * P + bodies_bytes;
+    if (16 + size > cap) return -(16 + size);
+    const int isize = (int)size, comp = 0;
+    memcpy(out, &isize, 4); memcpy(out + 4, &comp, 4); memcpy(out + 8, &w, 4); memcpy(out + 12, &h, 4);   /* :281-286 */
+    memcpy(out + 16, depth, (size_t)(2 * P));                                   /* :211 */
+    memcpy(out + 16 + 2 * P, rgb, (size_t)(3 * P));                             /* :214-231 */
+    memcpy(out + 16 + 5 * P, bodies, (size_t)bodies_bytes);                     /* :233-268 */
+    return 16 + size;
+}
+
+int orc_frame_decode(const uint8_t *msg, long len, int *w, int *h, const uint8_t **depth, const uint8_t **rgb,
+                     const uint8_t **bodies, int *bodies_bytes, int *n_bodies)
+{
+    if (len < 16) return -1;
+    int size, comp, ww, hh;
+    memcpy(&size, msg, 4); memcpy(&comp, msg + 4, 4); memcpy(&ww, msg + 8, 4); memcpy(&hh, msg + 12, 4);   /* KinectSocket.cs:229-241 */
+    if (size <= 0 || comp != 0 || ww < 0 || hh < 0 || 16 + (long)size > len) return -1;
+    const long P = (long)ww * hh;
+    if (5 * P + 4 > size) return -1;
+    int nb = 0;
+    const long bl = body_block_length(msg + 16 + 5 * P, size - 5 * P, &nb);
+    if (bl < 0) return -1;
+    *w = ww; *h = hh;
+    *depth = msg + 16; *rgb = msg + 16 + 2 * P; *bodies = msg + 16 + 5 * P;
+    *bodies_bytes = (int)(size - 5 * P);
+    *n_bodies = nb;
+    return 0;
+}
+
+long orc_recording_append(uint8_t *out, long cap, const uint8_t *frame, int len, int timestamp_ms)
+{
+    char hdr[96];
+    const int hl = snprintf(hdr, sizeof hdr, "bufferSize= %d\nframe_timestamp= %d\n", len, timestamp_ms);   /* :123 */
+    const long need = hl + (long)len + 1;
+    if (need > cap) return -need;
+    memcpy(out, hdr, (size_t)hl);
+    if (len > 0) memcpy(out + hl, frame, (size_t)len);
+    out[hl + len] = '\n';                                                       /* :127 */
+    return need;
+}
+
+/* fscanf("%s %d %s %d") as the reader uses it (:66): skip white space, token, int, token, int */
+static long scan_token(const uint8_t *f, long len, long pos, long *end)
+{
+    while (pos < len && (f[pos] == ' ' || f[pos] == '\n' || f[pos] == '\r' || f[pos] == '\t')) pos++;
+    if (pos >= len) return -1;
+    long e = pos;
+    while (e < len && !(f[e] == ' ' || f[e] == '\n' || f[e] == '\r' || f[e] == '\t')) e++;
+    *end = e;
+    return pos;
+}
+
+static int scan_int(const uint8_t *f, long len, long *pos, int *out)
+{
+    long e, b = scan_token(f, len, *pos, &e);
+    if (b < 0 || e - b > 11) return -1;
+    char tmp[16];
+    memcpy(tmp, f + b, (size_t)(e - b));
+    tmp[e - b] = 0;
+    char *endp;
+    const long v = strtol(tmp, &endp, 10);
+    if (*endp != 0 || endp == tmp) return -1;
+    *out = (int)v;
+    *pos = e;
+    return 0;
+}
+
+long orc_recording_next(const uint8_t *file, long len, long pos, long *frame_off, int *frame_len, int *timestamp_ms)
+{
+    long e;
+    int size, ts;
+    if (scan_token(file, len, pos, &e) < 0) return -1;                           /* "bufferSize=" */
+    pos = e;
+    if (scan_int(file, len, &pos, &size) < 0) return -1;
+    if (scan_token(file, len, pos, &e) < 0) return -1;                           /* "frame_timestamp=" */
+    pos = e;
+    if (scan_int(file, len, &pos, &ts) < 0) return -1;
+    if (size < 0) return -1;
+    *frame_len = size;
+    *timestamp_ms = ts;
+    if (size == 0) { *frame_off = pos; return pos; }                             /* :72-73: returns before the fgetc */
+    pos += 1;                                                                    /* fgetc '\n' :75 */
+    if (pos + size > len) return -1;
+    *frame_off = pos;
+    pos += size;
+    if (pos < len) pos += 1;                                                     /* fgetc '\n' :78 */
+    return pos;
 }

@@ -127,6 +127,47 @@ void orc_refine(int n_sensors, float **clouds, const int *n, int n_refine_iters,
 /* 3x3 SVD-based rotation: Rn = U*Vt (last column of U negated if det<0), icp.cpp:152-163. */
 void orc_kabsch_rotation(const float *M9, float *Rn9);
 
+/* ---- wire / disk formats either side of the path.  PARITY UNPINNED: the C# side cannot run here
+ * (no dotnet/mono) and the reference holds no sample files; these follow the cited lines literally. ---- */
+
+#define ORC_CHUNK_LIMIT (65000 - 3)   /* TransferServer.cs:179,205 */
+
+/* TransferServer.formMeshChunks (LiveScanServer/TransferServer.cs:203-270) when nt > 0, else formVerticesChunks
+ * (:177-201).  new_v must hold max(nv, 3*nt) vertices, new_tri 3*nt ints, v_chunks / t_chunks 3*nt/ORC_CHUNK_LIMIT + nv/ORC_CHUNK_LIMIT + 2
+ * ints.  Returns the number of chunks; *n_new_v receives the number of vertices to send.
+ * The triangle count of the first chunk is one short when there is more than one chunk (trianglesChunkStart = t at
+ * :244 instead of t+1) -- reproduced as written. */
+int orc_form_chunks(const orc_vertex *v, int nv, const int *tri, int nt, orc_vertex *new_v, int *new_tri,
+                    int *v_chunks, int *t_chunks, int *n_new_v);
+
+/* The bytes TransferSocket.SendFrame writes (LiveScanServer/TransferSocket.cs:50-104) for the cloud/mesh the
+ * TransferServer would send (TransferServer.cs:142-157): int nVertices, int nTriangles, int nChunks,
+ * int vChunkSizes[nChunks], int tChunkSizes[nChunks], float xyz[3*nVertices], u8 rgb[3*nVertices], int tri[3*nTriangles].
+ * Returns the length, or -(needed) when cap is too small. */
+long orc_transfer_frame(const orc_vertex *v, int nv, const int *tri, int nt, uint8_t *out, long cap);
+
+/* Utils.saveToPly(..., binary = true) file bytes (LiveScanServer/Utils.cs:222-262): header (first line ends with the
+ * Windows StreamWriter.WriteLine "\r\n", every other line with "\n"), 15-byte vertex records {f32 x,y,z; u8 r,g,b},
+ * 13-byte face records {u8 3; i32 a,b,c}. */
+long orc_ply_binary(const orc_vertex *v, int nv, const int *tri, int nt, uint8_t *out, long cap);
+
+/* Frame message client -> server: LiveScanClient::SerializeFrame after the colour mapping
+ * (src/LiveScanClient/liveScanClient.cpp:209-290), read by KinectSocket.ReceiveFrame (LiveScanServer/KinectSocket.cs:211-304):
+ * 16-byte header {i32 payload bytes, i32 compressed, i32 w, i32 h} + payload {u16 depth[w*h], u8 rgb[3*w*h], bodies}.
+ * The oracle writes/reads the uncompressed form only (compressed = 0).  bodies = the serialized body block
+ * (i32 nBodies, then per body u8 tracked, i32 nJoints, nJoints x 28 bytes), at least the 4 bytes of nBodies. */
+long orc_frame_encode(const uint8_t *depth, const uint8_t *rgb, int w, int h, const uint8_t *bodies, int bodies_bytes,
+                      uint8_t *out, long cap);
+/* Returns 0 and pointers into msg, or -1 when the message is malformed (short, compressed, inconsistent body block). */
+int orc_frame_decode(const uint8_t *msg, long len, int *w, int *h, const uint8_t **depth, const uint8_t **rgb,
+                     const uint8_t **bodies, int *bodies_bytes, int *n_bodies);
+
+/* Recording file of the client (src/LiveScanClient/frameFileWriterReader.cpp:59-82 reader, :115-130 writer): records
+ * "bufferSize= %d\nframe_timestamp= %d\n" + bytes + "\n".  append returns the bytes written (or -(needed));
+ * next returns the position after the record (or -1 at the end / on a malformed record). */
+long orc_recording_append(uint8_t *out, long cap, const uint8_t *frame, int len, int timestamp_ms);
+long orc_recording_next(const uint8_t *file, long len, long pos, long *frame_off, int *frame_len, int *timestamp_ms);
+
 #ifdef __cplusplus
 }
 #endif

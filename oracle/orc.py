@@ -62,6 +62,20 @@ def lib():
         L.orc_refine.argtypes = [C.c_int, p, p, C.c_int, C.c_int, p, p, p, p, C.c_int, C.c_int]
         L.orc_kabsch_rotation.restype = None
         L.orc_kabsch_rotation.argtypes = [p, p]
+        L.orc_form_chunks.restype = C.c_int
+        L.orc_form_chunks.argtypes = [p, C.c_int, p, C.c_int, p, p, p, p, p]
+        L.orc_transfer_frame.restype = C.c_long
+        L.orc_transfer_frame.argtypes = [p, C.c_int, p, C.c_int, p, C.c_long]
+        L.orc_ply_binary.restype = C.c_long
+        L.orc_ply_binary.argtypes = [p, C.c_int, p, C.c_int, p, C.c_long]
+        L.orc_frame_encode.restype = C.c_long
+        L.orc_frame_encode.argtypes = [p, p, C.c_int, C.c_int, p, C.c_int, p, C.c_long]
+        L.orc_frame_decode.restype = C.c_int
+        L.orc_frame_decode.argtypes = [p, C.c_long, p, p, p, p, p, p, p]
+        L.orc_recording_append.restype = C.c_long
+        L.orc_recording_append.argtypes = [p, C.c_long, p, C.c_int, C.c_int]
+        L.orc_recording_next.restype = C.c_long
+        L.orc_recording_next.argtypes = [p, C.c_long, C.c_long, p, p, p]
         _lib = L
     return _lib
 
@@ -258,3 +272,94 @@ def ref_triangles(depth, pix_to_vert):
     out = np.zeros((2 * h * w, 3), dtype=np.int32)
     n = _ref_tri.ref_generate_triangles(_ptr(depth), _ptr(p2v), w, h, _ptr(out))
     return out[:n].copy()
+
+
+# ---- wire / disk formats ---------------------------------------------------------------------
+
+CHUNK_LIMIT = 65000 - 3
+
+
+def _verts(v):
+    v = np.ascontiguousarray(v)
+    assert v.dtype == VERTEX_DTYPE
+    return v
+
+
+def form_chunks(vertices, triangles):
+    """TransferServer.formMeshChunks / formVerticesChunks.  Returns (new_vertices, new_triangles [n,3], v_chunks, t_chunks)."""
+    v = _verts(vertices)
+    tri = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+    nv, nt = len(v), len(tri)
+    new_v = np.zeros(max(nv, 3 * nt, 1), dtype=VERTEX_DTYPE)
+    new_tri = np.zeros((max(nt, 1), 3), dtype=np.int32)
+    cap = 3 * nt // CHUNK_LIMIT + nv // CHUNK_LIMIT + 2
+    vc, tc = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+    n_new = C.c_int(0)
+    nc = lib().orc_form_chunks(_ptr(v), nv, _ptr(tri), nt, _ptr(new_v), _ptr(new_tri), _ptr(vc), _ptr(tc), C.byref(n_new))
+    return new_v[:n_new.value].copy(), new_tri[:nt].copy(), vc[:nc].copy(), tc[:nc].copy()
+
+
+def transfer_frame(vertices, triangles):
+    """The bytes of TransferSocket.SendFrame for this cloud / mesh."""
+    v = _verts(vertices)
+    tri = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+    cap = 12 + 8 * (3 * len(tri) // CHUNK_LIMIT + len(v) // CHUNK_LIMIT + 2) + 15 * max(len(v), 3 * len(tri)) + 12 * len(tri)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().orc_transfer_frame(_ptr(v), len(v), _ptr(tri), len(tri), _ptr(out), cap)
+    assert n >= 0, n
+    return out[:n].tobytes()
+
+
+def ply_binary(vertices, triangles):
+    v = _verts(vertices)
+    tri = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+    cap = 512 + 15 * len(v) + 13 * len(tri)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().orc_ply_binary(_ptr(v), len(v), _ptr(tri), len(tri), _ptr(out), cap)
+    assert n >= 0, n
+    return out[:n].tobytes()
+
+
+def frame_encode(depth, rgb, bodies=None):
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    h, w = depth.shape
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    b = np.frombuffer(bodies, dtype=np.uint8) if bodies else None
+    out = np.zeros(16 + 5 * w * h + (b.size if b is not None else 4), dtype=np.uint8)
+    n = lib().orc_frame_encode(_ptr(depth), _ptr(rgb), w, h, _ptr(b), 0 if b is None else b.size, _ptr(out), out.size)
+    assert n == out.size, (n, out.size)
+    return out.tobytes()
+
+
+def frame_decode(message):
+    msg = np.frombuffer(bytes(message), dtype=np.uint8)
+    w, h, bb, nb = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    d, c, b = C.c_void_p(0), C.c_void_p(0), C.c_void_p(0)
+    rc = lib().orc_frame_decode(_ptr(msg), msg.size, C.byref(w), C.byref(h), C.byref(d), C.byref(c), C.byref(b), C.byref(bb), C.byref(nb))
+    if rc != 0:
+        return None
+    base = msg.ctypes.data
+    P = w.value * h.value
+    depth = msg[d.value - base:d.value - base + 2 * P].view(np.uint16).reshape(h.value, w.value).copy()
+    rgb = msg[c.value - base:c.value - base + 3 * P].reshape(h.value, w.value, 3).copy()
+    return depth, rgb, msg[b.value - base:b.value - base + bb.value].tobytes(), nb.value
+
+
+def recording_append(frame, timestamp_ms):
+    f = np.frombuffer(bytes(frame), dtype=np.uint8)
+    out = np.zeros(f.size + 96, dtype=np.uint8)
+    n = lib().orc_recording_append(_ptr(out), out.size, _ptr(f) if f.size else None, f.size, int(timestamp_ms))
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def recording_frames(file_bytes):
+    buf = np.frombuffer(file_bytes, dtype=np.uint8)
+    pos, out = 0, []
+    off, ln, ts = C.c_long(0), C.c_int(0), C.c_int(0)
+    while True:
+        nxt = lib().orc_recording_next(_ptr(buf), buf.size, pos, C.byref(off), C.byref(ln), C.byref(ts))
+        if nxt < 0:
+            return out
+        out.append((ts.value, buf[off.value:off.value + ln.value].tobytes()))
+        pos = nxt

@@ -1,0 +1,130 @@
+"""GPU parity of the outbound formats against the CPU oracle, bit for bit: the TransferSocket.SendFrame
+stream with TransferServer's chunking (LiveScanServer/TransferServer.cs:177-270, TransferSocket.cs:50-104) and the
+binary PLY file image (LiveScanServer/Utils.cs:222-262), both built on the device through the C-ABI."""
+import numpy as np
+import pytest
+
+from livescan3d_amd import native, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, n):
+    v = np.zeros(n, dtype=native.VERTEX_DTYPE)
+    v["R"], v["G"], v["B"] = rng.integers(0, 256, n), rng.integers(0, 256, n), rng.integers(0, 256, n)
+    v["A"] = 255
+    v["X"], v["Y"], v["Z"] = rng.normal(size=n), rng.normal(size=n), rng.normal(size=n)
+    return v
+
+
+def _device(v, tri):
+    import torch
+    dv = torch.from_numpy(v.view(np.uint8).reshape(-1, 16).copy()).cuda() if len(v) else torch.zeros((1, 16), dtype=torch.uint8, device="cuda")
+    dt = torch.from_numpy(np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)).cuda() if len(tri) else None
+    return dv, dt
+
+
+def _pack(v, tri, packer=None):
+    import torch
+    dv, dt = _device(v, tri)
+    nt = 0 if dt is None else len(tri)
+    cap = native.transfer_frame_bound(len(v), nt)
+    out = torch.zeros(cap + 64, dtype=torch.uint8, device="cuda")
+    p = packer or native.TransferPacker(0, max(len(v), 1), max(nt, 1))
+    n = p.pack(dv.data_ptr(), len(v), 0 if dt is None else dt.data_ptr(), nt, out.data_ptr(), cap)
+    assert (out[n:] == 0).all()                                 # nothing written past the stream
+    return out[:n].cpu().numpy().tobytes()
+
+
+def _ply(v, tri, misalign=0):
+    import torch
+    dv, dt = _device(v, tri)
+    nt = 0 if dt is None else len(tri)
+    need = native.ply_binary_bytes(len(v), nt)
+    out = torch.zeros(need + 64 + misalign, dtype=torch.uint8, device="cuda")
+    n = native.ply_pack(0, dv.data_ptr(), len(v), 0 if dt is None else dt.data_ptr(), nt, out.data_ptr() + misalign, need)
+    torch.cuda.synchronize()
+    assert n == need and (out[:misalign] == 0).all() and (out[misalign + n:] == 0).all()
+    return out[misalign:misalign + n].cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1025, 64997, 64998, 2 * 64997 + 17])
+def test_vertices_only_stream(gpu, orc, n):
+    v = _cloud(np.random.default_rng(n), n)
+    none = np.zeros((0, 3), np.int32)
+    assert _pack(v, none) == orc.transfer_frame(v, none)
+    assert _ply(v, none) == orc.ply_binary(v, none)
+
+
+def _grid(rng, w, h, drop=0.03):
+    present = rng.random((h, w)) >= drop
+    ids = np.where(present.ravel(), np.cumsum(present.ravel()) - 1, -1).reshape(h, w)
+    p, u, ur, r = ids[1:, :-1], ids[:-1, :-1], ids[:-1, 1:], ids[1:, 1:]
+    a = np.stack([r, u, p], -1)
+    b = np.stack([r, ur, u], -1)
+    both = np.stack([a, b], 2).reshape(-1, 3)                   # per pixel: (R,U,P) then (R,UR,U), raster order
+    tri = both[(both >= 0).all(1)].astype(np.int32)
+    return _cloud(rng, int(present.sum())), tri
+
+
+@pytest.mark.parametrize("w,h", [(7, 3), (40, 30), (400, 300), (1024, 700)])
+def test_mesh_stream_matches_oracle(gpu, orc, w, h):
+    v, tri = _grid(np.random.default_rng(w * h), w, h)
+    got, want = _pack(v, tri), orc.transfer_frame(v, tri)
+    assert len(got) == len(want)
+    assert got == want
+    for mis in (0, 1, 3):
+        assert _ply(v, tri, mis) == orc.ply_binary(v, tri)
+
+
+def test_chunk_that_spans_several_windows_and_reuse(gpu, orc):
+    """Triangles that keep re-using a small vertex set never fill a chunk: the chunk must carry over many search windows
+    (one window = 196608 triangles), then a grid part closes chunks normally; one packer serves several calls."""
+    rng = np.random.default_rng(99)
+    v, grid = _grid(rng, 600, 500)
+    few = rng.integers(0, 1500, size=(450_000, 3)).astype(np.int32)
+    packer = native.TransferPacker(0, len(v), len(few) + len(grid))
+    for tri in (few, np.concatenate([few, grid]), np.concatenate([grid[:150_000], few[:250_000], grid[150_000:]]), grid[:10]):
+        assert _pack(v, tri, packer) == orc.transfer_frame(v, tri)
+
+
+def test_fused_mesh_of_eight_sensors(gpu, orc):
+    """The real thing: the merged mesh of 8 x 512x424 sensors (about 1 M vertices, 1.7 M triangles, ~25 chunks)."""
+    rig = synth.make_rig("scene", 8, 512, 424, seed=3)
+    v, tri = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    assert len(tri) > 1_000_000
+    got, want = _pack(v, tri), orc.transfer_frame(v, tri)
+    assert len(got) == len(want) and got == want
+    assert int(np.frombuffer(got, "<i4", 3)[2]) > 10
+    assert _ply(v, tri, 2) == orc.ply_binary(v, tri)
+
+
+def test_errors(gpu):
+    import torch
+    v = _cloud(np.random.default_rng(1), 100)
+    dv, _ = _device(v, np.zeros((0, 3), np.int32))
+    out = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    p = native.TransferPacker(0, 100, 10)
+    bad = torch.tensor([[0, 1, 2], [3, 100, 4]], dtype=torch.int32, device="cuda")
+    with pytest.raises(native.NativeUtilsError, match="outside"):
+        p.pack(dv.data_ptr(), 100, bad.data_ptr(), 2, out.data_ptr(), out.numel())
+    with pytest.raises(native.NativeUtilsError, match="capacity"):
+        p.pack(dv.data_ptr(), 101, 0, 0, out.data_ptr(), out.numel())
+    with pytest.raises(native.NativeUtilsError, match="needs"):
+        p.pack(dv.data_ptr(), 100, 0, 0, out.data_ptr(), 100)
+    with pytest.raises(native.NativeUtilsError):
+        native.ply_pack(0, dv.data_ptr(), 100, 0, 0, out.data_ptr(), 10)
+
+
+def test_last_mesh_exports_for_host_callers(gpu, orc):
+    """LiveScanServer's order of calls: generateMeshFromDepthMaps, then the stream / the file of that same mesh without
+    uploading it again (lsnLastMeshTransferFrame / lsnLastMeshPly read the copy that is still in HBM)."""
+    rig = synth.make_rig("scene", 3, 512, 424, seed=4)
+    v, tri = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    assert native.last_mesh_transfer_frame() == orc.transfer_frame(v, tri)
+    assert native.last_mesh_ply() == orc.ply_binary(v, tri)
+    # a single-sensor call has no triangles: vertices-only chunks (TransferServer.cs:152-157)
+    v1 = native.generate_vertices_from_depth_map(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, 1)
+    none = np.zeros((0, 3), np.int32)
+    assert native.last_mesh_transfer_frame() == orc.transfer_frame(v1, none)
+    assert native.last_mesh_ply() == orc.ply_binary(v1, none)
