@@ -68,8 +68,8 @@ def test_golden_replay_fixture_against_the_oracle(orc):
 
 
 def test_cpp_example_host_builds():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "replay"], stdout=subprocess.DEVNULL)
-    assert os.path.exists(os.path.join(ROOT, "examples", "replay"))
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "all"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(ROOT, "examples", "replay")) and os.path.exists(os.path.join(ROOT, "examples", "stream"))
 
 
 @pytest.mark.gpu
@@ -83,3 +83,38 @@ def test_cpp_example_host_replays_the_golden_fixture(gpu):
         out = subprocess.run([exe, os.path.join(GOLD, "replay_scene_2x96x80.bin"), "--bounds", *b, "--expect", os.path.join(GOLD, mesh), *extra],
                              capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and "Test PASSED" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_stream_host_from_recordings_to_wire_and_ply(gpu, orc, tmp_path):
+    """examples/stream.cpp: client recordings (one zstd-compressed, one raw) -> frame messages -> merge call -> the
+    TransferServer stream of every tick + the last tick's binary PLY, all through the C-ABI from a C++ process; the bytes
+    must equal the oracle's restatement of TransferServer/TransferSocket/Utils.saveToPly on the oracle's mesh."""
+    from livescan3d_amd import native
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "stream"], stdout=subprocess.DEVNULL)
+    n, w, h, ticks = 2, 96, 80, 3
+    rigs = [synth.make_rig("scene", n, w, h, seed=21, tick=k, bounds=synth.CROP_BOUNDS) for k in range(ticks)]
+    P = w * h
+    recs = []
+    for i in range(n):
+        blob = b""
+        for k, rig in enumerate(rigs):
+            depth = rig.depth_maps.view(np.uint16)[i * P:(i + 1) * P].reshape(h, w)
+            rgb = rig.depth_colors[3 * i * P:3 * (i + 1) * P].reshape(h, w, 3)
+            level = 3 if (i == 0 and native.zstd_available()) else 0
+            blob += native.recording_append(native.frame_encode(depth, rgb, None, level), 33 * k)
+        path = tmp_path / f"rec{i}.bin"
+        path.write_bytes(blob)
+        recs.append(str(path))
+    calib = np.concatenate([np.concatenate([rigs[0].intr[7 * i:7 * i + 7], rigs[0].wt[12 * i:12 * i + 12]]) for i in range(n)]).astype(np.float32)
+    (tmp_path / "calib.bin").write_bytes(calib.tobytes())
+    out = subprocess.run([os.path.join(ROOT, "examples", "stream"), "--calib", str(tmp_path / "calib.bin"),
+                          "--bounds", *[str(float(x)) for x in synth.CROP_BOUNDS], "--frames-out", str(tmp_path / "wire.bin"),
+                          "--ply", str(tmp_path / "mesh.ply"), *recs], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and f"{ticks} ticks" in out.stdout, out.stdout + out.stderr
+    want = b""
+    for rig in rigs:
+        v, _, t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rigs[0].intr, rigs[0].wt, rig.bounds)
+        want += orc.transfer_frame(v, t)
+    assert (tmp_path / "wire.bin").read_bytes() == want
+    assert (tmp_path / "mesh.ply").read_bytes() == orc.ply_binary(v, t)
