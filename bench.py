@@ -142,6 +142,7 @@ def main():
     elapsed = float(elapsed.item())
     kstats = fus.plan.kernel_stats(reset=True)
     fus.plan.profile(False)
+    thr_table, thr_build_ms = fus.plan.thresholds(copy=False)   # already built by the second warm-up run; reports its build time
 
     # algorithmic bytes of one launch of the dominant kernel on this rank: sum over its sensor-frames of 2P + 19V
     off = fus.offsets.cpu().numpy().astype(np.int64)
@@ -178,6 +179,9 @@ def main():
                 "sensors_per_gpu": S_loc,
                 "survivor_fraction": V_total / float(B * S * P),
                 "compaction": "two-pass" if args.mode == 0 else "look-back",
+                "count_pass": ("arithmetic (LSN_NO_THRESHOLDS=1)" if os.environ.get("LSN_NO_THRESHOLDS", "0") not in ("", "0")
+                               else "per-pixel depth thresholds"),
+                "threshold_build_ms_once_per_calibration": thr_build_ms,
                 "parallelism": f"sensor-shard{world}" + ("+allgather" if multi else ""),
                 "bounds": [float(x) for x in bounds],
             },

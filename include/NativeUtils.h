@@ -133,6 +133,13 @@ int lsnFusionRunStreamed(LsnFusion *plan, const void *d_depth_maps, const void *
 int lsnFusionRun(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_colors, void *d_vertices,
                  int *d_offsets, void *stream);
 
+/* The count pass needs no arithmetic once the calibration is fixed: from the second run with the same parameters on, the
+ * plan keeps, per pixel, the interval of depth values that survive the transform + crop (found by bisection with the
+ * pipeline's own roundings, exact by construction) and counts with two integer operations per pixel.  This call builds
+ * the table now, reports the build time and optionally copies the table out (lsnFusionTickCapacity() words,
+ * lo | count << 16; lo == 0: "evaluate arithmetically").  Returns 0, 1 when disabled ($LSN_NO_THRESHOLDS=1), -1 on error. */
+int lsnFusionThresholds(LsnFusion *plan, unsigned int *out_host, float *build_ms, void *stream);
+
 /* The complete merge call: vertices as lsnFusionRun plus the reference's always-on triangulation
  * (MeshGenerator::generateTrianglesGradients, src/NativeUtils/meshGenerator.cpp:14-181; index rebasing of formMesh,
  * src/NativeUtils/depthprocessing.cpp:1611-1627).  d_triangles: n_ticks x lsnFusionTickTriangleCapacity() x 3 ints

@@ -82,6 +82,7 @@ struct FuseArgs {
     const unsigned short *depth_next;  // streamed mode (MODE 3): the NEXT batch's depth, counted in the shadow of this write
     int *tile_counts_next;             // ... and where its per-tile counts go
     int *error_flag;                 // mode 1: set when a bounded spin gives up (sticky until read)
+    const unsigned int *thr;         // optional [pixels per tick]: the depth interval each pixel survives in (thresh_kernel), null = none
     int n_frames;
     int tiles_per_tick;
     int n_ticks;
@@ -345,6 +346,191 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
     }
 }
 
+// ---- per-pixel depth thresholds: the count pass without the arithmetic ------------------------------------------------------
+// With the calibration fixed (it only changes when the user recalibrates) a pixel's fate depends on its depth value alone.
+// thresh_kernel finds, per pixel, the set of d in [1, 65535] the reference keeps and stores it as {lo, count} when it is one
+// interval (it is, for every sane calibration); the count pass then is "(d - lo) < count" -- 3 VALU instructions per
+// pixel instead of ~38 -- and becomes what it should be: a depth-only, HBM-bound sweep.
+//
+// Exactness.  Every f32 operation of the reference's pipeline is monotone in each operand (rounding to nearest is
+// monotone), so evaluating the SAME operations on the two ends of a depth range [a, b] (ordinary interval arithmetic, but
+// with the pipeline's own roundings) encloses the result of every d in the range.  A range whose enclosure lies inside the
+// box is kept as a whole, one whose enclosure is beyond a face on some axis is rejected as a whole, anything else is
+// bisected down to single depths, which are evaluated exactly like the write pass does.  No analytic error bound is
+// involved.  Pixels whose survivors are not one interval, or whose parameters are not finite, get lo = 0 and are evaluated
+// arithmetically by the count pass as before.
+struct Iv { float lo, hi; };
+__device__ __forceinline__ Iv iv_scale(Iv a, float c) { const float x = a.lo * c, y = a.hi * c; return c >= 0.0f ? Iv{x, y} : Iv{y, x}; }
+__device__ __forceinline__ Iv iv_shift(Iv a, float c) { return Iv{a.lo + c, a.hi + c}; }
+__device__ __forceinline__ Iv iv_sum(Iv a, Iv b) { return Iv{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ bool iv_finite(Iv a) { return isfinite(a.lo) && isfinite(a.hi); }
+
+__device__ __forceinline__ float depth_to_metres1(float d)
+{
+    const f2 z = depth_to_metres2(f2{d, d});
+    return z.x;
+}
+
+// 0 = every depth in [a, b] is rejected, 1 = every depth is kept, 2 = undecided
+__device__ __forceinline__ int classify_range(int a, int b, float xfac, float yfac, const SensorParams &P, const float (&bx)[6])
+{
+    if (a == b) {
+        f2 ox, oy, oz;
+        unproject2(f2{(float)a, (float)a}, f2{xfac, xfac}, f2{yfac, yfac}, P, ox, oy, oz);
+        const bool rejected = (ox.x < bx[0]) | (ox.x > bx[3]) | (oy.x < bx[1]) | (oy.x > bx[4]) | (oz.x < bx[2]) | (oz.x > bx[5]);
+        return rejected ? 0 : 1;
+    }
+    const Iv z = {depth_to_metres1((float)a), depth_to_metres1((float)b)};
+    const Iv X = iv_shift(iv_scale(z, xfac), P.t0), Y = iv_shift(iv_scale(z, yfac), P.t1), Z = iv_shift(z, P.t2);
+    const Iv ox = iv_sum(iv_sum(iv_scale(X, P.r00), iv_scale(Y, P.r01)), iv_scale(Z, P.r02));
+    const Iv oy = iv_sum(iv_sum(iv_scale(X, P.r10), iv_scale(Y, P.r11)), iv_scale(Z, P.r12));
+    const Iv oz = iv_sum(iv_sum(iv_scale(X, P.r20), iv_scale(Y, P.r21)), iv_scale(Z, P.r22));
+    if (!(iv_finite(ox) && iv_finite(oy) && iv_finite(oz))) return 2;
+    if (ox.hi < bx[0] || ox.lo > bx[3] || oy.hi < bx[1] || oy.lo > bx[4] || oz.hi < bx[2] || oz.lo > bx[5]) return 0;
+    if (ox.lo >= bx[0] && ox.hi <= bx[3] && oy.lo >= bx[1] && oy.hi <= bx[4] && oz.lo >= bx[2] && oz.hi <= bx[5]) return 1;
+    return 2;
+}
+
+__global__ __launch_bounds__(kThreads) void thresh_kernel(const FrameDesc *frames, const SensorParams *params, int n_frames, const float *xtab,
+                                                          const float *ytab, unsigned int *thr, float minX, float minY, float minZ, float maxX,
+                                                          float maxY, float maxZ)
+{
+    const int f = blockIdx.y;
+    if (f >= n_frames) return;
+    const FrameDesc fd = frames[f];
+    const SensorParams P = params[f];
+    const float bx[6] = {minX, minY, minZ, maxX, maxY, maxZ};
+    const bool params_ok = isfinite(P.t0) && isfinite(P.t1) && isfinite(P.t2) && isfinite(P.r00) && isfinite(P.r01) && isfinite(P.r02) &&
+                           isfinite(P.r10) && isfinite(P.r11) && isfinite(P.r12) && isfinite(P.r20) && isfinite(P.r21) && isfinite(P.r22) &&
+                           !(isnan(minX) || isnan(minY) || isnan(minZ) || isnan(maxX) || isnan(maxY) || isnan(maxZ));
+    for (int p = blockIdx.x * kThreads + threadIdx.x; p < fd.npix; p += gridDim.x * kThreads) {
+        const int y = p / fd.w, x = p - y * fd.w;
+        const float xfac = xtab[fd.xtab_off + x], yfac = ytab[fd.ytab_off + y];
+        unsigned int code = 0;                                  // lo = 0: "evaluate arithmetically"
+        if (params_ok && isfinite(xfac) && isfinite(yfac)) {
+            int state = 0, lo = 1, hi = 0;                      // 0 = before the interval, 1 = inside, 2 = after, 3 = not an interval
+            int d = 1;
+            while (d <= 65535 && state != 3) {
+                int len = d & -d;                               // largest aligned power-of-two block that starts at d
+                while (d + len - 1 > 65535) len >>= 1;
+                int c = classify_range(d, d + len - 1, xfac, yfac, P, bx);
+                while (c == 2) {                                // len == 1 always decides
+                    len >>= 1;
+                    c = classify_range(d, d + len - 1, xfac, yfac, P, bx);
+                }
+                if (c == 1) {
+                    if (state == 0) { lo = d; state = 1; }
+                    else if (state == 2) state = 3;
+                    hi = d + len - 1;
+                } else if (state == 1) {
+                    state = 2;
+                }
+                d += len;
+            }
+            if (state != 3) code = (unsigned int)lo | ((unsigned int)(hi - lo + 1) << 16);   // empty: lo = 1, count = 0
+        }
+        thr[fd.depth_off + p] = code;
+    }
+}
+
+// Thresholds of a lane's 8 pixels; `flagged` = lanes/pixels that must be evaluated arithmetically.
+template <bool VEC>
+__device__ __forceinline__ void load_thresholds(const FuseArgs &a, const Tile &t, unsigned int (&lo)[kPxPerLane], unsigned int (&cnt)[kPxPerLane],
+                                                bool &any_flagged)
+{
+    const int p0 = t.px0 + threadIdx.x * kPxPerLane;
+    unsigned int c[kPxPerLane];
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) c[k] = 1u;             // past the frame end: lo = 1, count = 0 -> never kept
+    const unsigned int *tp = a.thr + t.pix_base + p0;
+    if (VEC) {
+        if (p0 < t.npix) {
+            const uint4 u = reinterpret_cast<const uint4 *>(tp)[0], v = reinterpret_cast<const uint4 *>(tp)[1];
+            c[0] = u.x; c[1] = u.y; c[2] = u.z; c[3] = u.w; c[4] = v.x; c[5] = v.y; c[6] = v.z; c[7] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++)
+            if (p0 + k < t.npix) c[k] = tp[k];
+    }
+    bool fl = false;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) {
+        lo[k] = c[k] & 0xFFFFu;
+        cnt[k] = c[k] >> 16;
+        fl |= lo[k] == 0;
+    }
+    any_flagged = __any(fl);
+}
+
+// Survivors of a lane's 8 pixels among the wave, from the thresholds (flagged pixels: from the arithmetic, keep_exact).
+__device__ __forceinline__ int wave_count_thr(const Inputs &in, const unsigned int (&lo)[kPxPerLane], const unsigned int (&cnt)[kPxPerLane])
+{
+    int wt = 0;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) {
+        const unsigned int d = (k & 1) ? in.dw[k >> 1] >> 16 : in.dw[k >> 1] & 0xFFFFu;
+        wt += __popcll(__ballot(d - lo[k] < cnt[k]));
+    }
+    return wt;
+}
+
+// Count pass from the thresholds: a workgroup owns one tile position for kTickGroup consecutive ticks, so the thresholds
+// are loaded once per 8 ticks and the 8 depth loads of a lane are in flight together.
+template <bool VEC, int kTickGroup>
+__global__ __launch_bounds__(kThreads) void count_thr_kernel(const FuseArgs a)
+{
+    __shared__ int s_cnt[4][kTickGroup];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tg = blockIdx.x / a.tiles_per_tick;
+    const int tile = blockIdx.x - tg * a.tiles_per_tick;
+    const int tick0 = tg * kTickGroup;
+    const int nt = min(kTickGroup, a.n_ticks - tick0);
+    const Tile t = locate(a, tick0, tile);
+    unsigned int lo[kPxPerLane], cnt[kPxPerLane];
+    bool any_flagged;
+    load_thresholds<VEC>(a, t, lo, cnt, any_flagged);
+    Inputs in[kTickGroup];
+#pragma unroll
+    for (int i = 0; i < kTickGroup; i++) {
+        Tile ti = t;
+        ti.dptr = t.dptr + (long long)(i < nt ? i : 0) * a.tick_depth_stride;
+        load_inputs<VEC, false>(ti, in[i]);
+    }
+    if (!any_flagged) {
+#pragma unroll
+        for (int i = 0; i < kTickGroup; i++) {
+            const int wt = wave_count_thr(in[i], lo, cnt);
+            if (lane == 0) s_cnt[wave][i] = wt;
+        }
+    } else {
+        // some pixel of this wave has no interval (non-finite calibration, ...): the arithmetic decides, as in fuse_kernel<0>
+        const SensorParams P = a.params[t.f];
+        float xf[kPxPerLane], yf[kPxPerLane];
+        tile_factors<VEC>(t, xf, yf);
+#pragma unroll 1
+        for (int i = 0; i < nt; i++) {
+            // reloaded here on purpose: indexing in[] with a run-time i would move the whole array to scratch memory
+            Tile ti = t;
+            ti.dptr = t.dptr + (long long)i * a.tick_depth_stride;
+            Inputs ix;
+            load_inputs<VEC, false>(ti, ix);
+            bool keep[kPxPerLane];
+            uint4 unused[kPxPerLane];
+            compute_pixels<false>(a, P, ix, xf, yf, keep, unused);
+            int wt = 0;
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) wt += __popcll(__ballot(keep[k]));
+            if (lane == 0) s_cnt[wave][i] = wt;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nt)
+        a.tile_counts[(long long)(tick0 + threadIdx.x) * a.tiles_per_tick + tile] =
+            s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+}
+
 // ---- mode 0: count kernel, scan kernel, write kernel ------------------------------------------------------------
 
 // MODE 0 = count only (writes tile_counts), 1 = write with offsets from tile_counts (exclusive prefixes by then),
@@ -379,13 +565,24 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     uint4 vert[kPxPerLane];
     compute_pixels<kWrite>(a, P, in, xf, yf, keep, vert);
     if (MODE == 3) {
-        // same sensor, same tile geometry: the column / row factors and the pose are shared with this batch's tile
-        bool keep_n[kPxPerLane];
-        uint4 unused[kPxPerLane];
-        compute_pixels<false>(a, P, nx, xf, yf, keep_n, unused);
         int wt = 0;
+        bool arithmetic = true;
+        if (a.thr) {
+            // the next batch's survivors straight from the per-pixel depth thresholds: no arithmetic at all
+            unsigned int lo[kPxPerLane], cnt[kPxPerLane];
+            bool any_flagged;
+            load_thresholds<VEC>(a, t, lo, cnt, any_flagged);
+            arithmetic = any_flagged;
+            if (!any_flagged) wt = wave_count_thr(nx, lo, cnt);
+        }
+        if (arithmetic) {
+            // same sensor, same tile geometry: the column / row factors and the pose are shared with this batch's tile
+            bool keep_n[kPxPerLane];
+            uint4 unused[kPxPerLane];
+            compute_pixels<false>(a, P, nx, xf, yf, keep_n, unused);
 #pragma unroll
-        for (int k = 0; k < kPxPerLane; k++) wt += __popcll(__ballot(keep_n[k]));
+            for (int k = 0; k < kPxPerLane; k++) wt += __popcll(__ballot(keep_n[k]));
+        }
         if (lane == 0) s_wave_next[wave] = wt;
     }
 
@@ -1196,6 +1393,13 @@ struct LsnFusion {
     const void *counted_for = nullptr;
     unsigned long long counted_gen = 0, params_gen = 1;
     int stream_half = 0;
+    // per-pixel depth thresholds (thresh_kernel): built once the same parameters are used for a second run
+    lsn::DevBuf thr;
+    bool thr_valid = false;
+    bool thr_enabled = true;             // $LSN_NO_THRESHOLDS=1 keeps the arithmetic count pass (ablation / tests)
+    int runs_with_params = 0;
+    std::vector<float> last_intr, last_wt;
+    float thr_build_ms = 0;
     // dominant-kernel timing
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1217,6 +1421,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
     if (!p) return nullptr;
     p->device = device;
     if (const char *env = getenv("LSN_TILES_PER_RUN")) p->tiles_per_run_override = atoi(env);
+    if (const char *env = getenv("LSN_NO_THRESHOLDS")) p->thr_enabled = atoi(env) == 0;
     p->n_ticks = n_ticks;
     p->n_maps = n_maps;
     std::vector<FrameDesc> fr(n_maps);
@@ -1326,6 +1531,14 @@ extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *
         return -1;
     }
     LSN_HIP(hipSetDevice(p->device));
+    {
+        // LiveScanServer passes the same calibration with every call (KinectServer.cs:470-490): nothing to do then
+        std::lock_guard<std::mutex> g(p->mu);
+        if (p->params_set && p->last_intr.size() == 7 * (size_t)p->n_maps &&
+            memcmp(p->last_intr.data(), intr, sizeof(float) * 7 * p->n_maps) == 0 &&
+            memcmp(p->last_wt.data(), wt, sizeof(float) * 12 * p->n_maps) == 0 && memcmp(p->bounds, bounds6, sizeof(p->bounds)) == 0)
+            return 0;
+    }
     std::vector<SensorParams> sp(p->n_maps);
     for (int i = 0; i < p->n_maps; i++) {
         // IntrinsicCameraParameters(float*) / WorldTranformation(float*), include/NativeUtils/depthprocessing.h:56-63,96-97
@@ -1344,9 +1557,14 @@ extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *
                        p->params.as<SensorParams>(), p->n_maps, p->xtab.as<float>(), p->ytab.as<float>());
     LSN_HIP(hipGetLastError());
     LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
+    std::lock_guard<std::mutex> g(p->mu);
     memcpy(p->bounds, bounds6, sizeof(p->bounds));
+    p->last_intr.assign(intr, intr + 7 * (size_t)p->n_maps);
+    p->last_wt.assign(wt, wt + 12 * (size_t)p->n_maps);
     p->params_set = true;
     p->params_gen++;  // counts made ahead with the old parameters are void
+    p->thr_valid = false;
+    p->runs_with_params = 0;
     return 0;
 }
 
@@ -1458,6 +1676,57 @@ static void fill_args(LsnFusion *p, FuseArgs &a, const void *d_depth, const void
 
     a.depth_next = nullptr;
     a.tile_counts_next = nullptr;
+    a.thr = p->thr_valid ? p->thr.as<unsigned int>() : nullptr;
+}
+
+// Called at the top of every run (p->mu held): from the second run with the same parameters on, the count pass uses the
+// per-pixel depth thresholds; they are built here, once, on the caller's stream.
+static int ensure_thresholds(LsnFusion *p, hipStream_t s)
+{
+    if (!p->thr_enabled || p->thr_valid) return 0;
+    if (++p->runs_with_params < 2) return 0;
+    if (p->thr.reserve(sizeof(unsigned int) * (size_t)p->cap)) return -1;
+    hipEvent_t e0, e1;
+    LSN_HIP(hipEventCreate(&e0));
+    LSN_HIP(hipEventCreate(&e1));
+    LSN_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(thresh_kernel, dim3(256, (unsigned)p->n_maps), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->params.as<SensorParams>(),
+                       p->n_maps, p->xtab.as<float>(), p->ytab.as<float>(), p->thr.as<unsigned int>(), p->bounds[0], p->bounds[1], p->bounds[2],
+                       p->bounds[3], p->bounds[4], p->bounds[5]);
+    LSN_HIP(hipGetLastError());
+    LSN_HIP(hipEventRecord(e1, s));
+    LSN_HIP(hipEventSynchronize(e1));
+    (void)hipEventElapsedTime(&p->thr_build_ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    p->thr_valid = true;
+    return 0;
+}
+
+// The count pass of one batch into a.tile_counts: from the thresholds when they exist, else arithmetically.
+static void launch_count(LsnFusion *p, bool vec, hipStream_t s, const FuseArgs &a)
+{
+    if (a.thr) {
+        static const int tune = getenv("LSN_TICK_GROUP") ? atoi(getenv("LSN_TICK_GROUP")) : 0;
+        int G = tune ? tune : (p->n_ticks >= 8 ? 8 : (p->n_ticks >= 4 ? 4 : 1));
+        if (G != 16 && G != 8 && G != 4 && G != 2) G = 1;
+        const int grid = p->tiles_per_tick * ((p->n_ticks + G - 1) / G);
+#define LSN_COUNT_THR(GG)                                                                                         \
+    do {                                                                                                          \
+        if (vec) hipLaunchKernelGGL((count_thr_kernel<true, GG>), dim3(grid), dim3(kThreads), 0, s, a);           \
+        else     hipLaunchKernelGGL((count_thr_kernel<false, GG>), dim3(grid), dim3(kThreads), 0, s, a);          \
+    } while (0)
+        if (G == 16) LSN_COUNT_THR(16);
+        else if (G == 8) LSN_COUNT_THR(8);
+        else if (G == 4) LSN_COUNT_THR(4);
+        else if (G == 2) LSN_COUNT_THR(2);
+        else LSN_COUNT_THR(1);
+#undef LSN_COUNT_THR
+    } else {
+        const int grid = p->tiles_per_tick * p->n_ticks;
+        if (vec) hipLaunchKernelGGL((fuse_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, a);
+        else     hipLaunchKernelGGL((fuse_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, a);
+    }
 }
 
 // Next HIP-event pair of the dominant-kernel timer (profiling on).
@@ -1506,6 +1775,7 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
     LSN_HIP(hipSetDevice(p->device));
     hipStream_t s = lsn::as_stream(stream);
 
+    if (ensure_thresholds(p, s)) return -1;
     FuseArgs a;
     fill_args(p, a, d_depth, d_colors, d_vertices, d_offsets);
 
@@ -1529,7 +1799,7 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         if (p->calls >= 2) LSN_HIP(hipStreamWaitEvent(p->side, p->ev_written[b], 0));  // the write that last read this half
         FuseArgs ac = a;
         ac.offsets = off_int;
-        launch<0>(vec, grid, p->side, ac);
+        launch_count(p, vec, p->side, ac);
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, p->side, ac.tile_counts, ac.tiles_per_tick, ac.frames,
                            ac.n_frames, off_int);
         LSN_HIP(hipEventRecord(p->ev_counted, p->side));
@@ -1541,7 +1811,7 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         LSN_HIP(hipEventRecord(p->ev_written[b], s));
         p->calls++;
     } else if (p->mode == 0 || p->want_pixmap) {
-        launch<0>(vec, grid, s, a);
+        launch_count(p, vec, s, a);
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
                            a.offsets);
         if (e0) LSN_HIP(hipEventRecord(e0, s));
@@ -1580,6 +1850,7 @@ extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const voi
     const size_t off_elems = (size_t)p->n_ticks * (p->n_maps + 1);
     if (p->tile_counts_b.reserve(sizeof(int) * n_tiles) || p->offs_int.reserve(sizeof(int) * 2 * off_elems)) return -1;
 
+    if (ensure_thresholds(p, s)) return -1;
     FuseArgs a;
     fill_args(p, a, d_depth, d_colors, d_vertices, d_offsets);
     const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && (p->tick_depth_elems % 8) == 0 &&
@@ -1593,7 +1864,7 @@ extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const voi
     if (p->counted_for != d_depth || p->counted_gen != p->params_gen) {
         // nothing (valid) was counted ahead for this batch: do it now, like mode 0
         a.offsets = off_cur;
-        launch<0>(vec, grid, s, a);
+        launch_count(p, vec, s, a);
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, cur, a.tiles_per_tick, a.frames, a.n_frames, off_cur);
     }
     LSN_HIP(hipMemcpyAsync(d_offsets, off_cur, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
@@ -1618,6 +1889,30 @@ extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const voi
         p->counted_for = nullptr;
     }
     LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+// Diagnostics / tests: builds the per-pixel depth thresholds now (if the plan uses them) and copies them out.
+extern "C" int lsnFusionThresholds(LsnFusion *p, unsigned int *out_host, float *build_ms, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !p->params_set) {
+        lsn::set_error("lsnFusionThresholds: no plan / lsnFusionSetParams has not been called");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    if (!p->thr_enabled) return 1;
+    hipStream_t s = lsn::as_stream(stream);
+    if (!p->thr_valid) {
+        p->runs_with_params = 1;
+        if (ensure_thresholds(p, s)) return -1;
+    }
+    if (build_ms) *build_ms = p->thr_build_ms;
+    if (out_host) {
+        LSN_HIP(hipMemcpyAsync(out_host, p->thr.p, sizeof(unsigned int) * (size_t)p->cap, hipMemcpyDeviceToHost, s));
+        LSN_HIP(hipStreamSynchronize(s));
+    }
     return 0;
 }
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
-    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnMergeShards",
+    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionThresholds", "lsnMergeShards",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
@@ -114,6 +114,8 @@ def lib():
     L.lsnFusionProfile.argtypes = [vp, C.c_int]
     L.lsnFusionKernelStats.restype = C.c_int
     L.lsnFusionKernelStats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_char_p, C.c_int, C.c_int]
+    L.lsnFusionThresholds.restype = C.c_int
+    L.lsnFusionThresholds.argtypes = [vp, vp, C.POINTER(C.c_float), vp]
     L.lsnFusionLookbackFailed.restype = C.c_int
     L.lsnFusionLookbackFailed.argtypes = [vp, vp]
     L.lsnMergeShards.restype = C.c_int
@@ -343,6 +345,16 @@ class FusionPlan:
         """Vertices + triangles (the reference's complete merge call); d_triangles: n_ticks x 2*capacity x 3 int32."""
         _check(lib().lsnFusionRunMesh(self._h, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream),
                "lsnFusionRunMesh")
+
+    def thresholds(self, capacity=None, stream=0, copy=True):
+        """Builds the per-pixel depth thresholds now.  Returns (table uint32[capacity] or None, build_ms); table is None when
+        the plan does not use thresholds ($LSN_NO_THRESHOLDS=1)."""
+        out = np.zeros(int(capacity or self.capacity), dtype=np.uint32) if copy else None
+        ms = C.c_float(0)
+        rc = lib().lsnFusionThresholds(self._h, _ptr(out) if copy else None, C.byref(ms), stream or None)
+        if rc < 0:
+            raise NativeUtilsError(f"lsnFusionThresholds failed: {last_error()}")
+        return (None if rc == 1 else out), ms.value
 
     def lookback_failed(self, stream=0):
         return int(lib().lsnFusionLookbackFailed(self._h, stream))
