@@ -16,7 +16,7 @@ for d in sorted(glob.glob("$out/*/")):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "fuse_kernel" not in k and "scan_kernel" not in k: continue
+            if "fuse_kernel" not in k and "scan_kernel" not in k and "count_thr" not in k: continue
             acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
             print(k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
