@@ -331,3 +331,41 @@ def test_triangles_match_reference_fixture(gpu):
     assert len(verts) == n0 + n1
     want = np.concatenate([z["scene0_96x80_tri"], z["scene1_96x80_tri"] + n0])
     assert tris.shape == want.shape and np.array_equal(tris, want)
+
+
+def test_exports_called_concurrently_like_the_two_background_workers(gpu, orc):
+    """LiveScanServer calls the merge export from updateWorker and single-sensor + ICP from refineWorker at the same time
+    (MainWindowForm.cs:266-300, 330-410).  ctypes drops the GIL during a call, so these threads really overlap."""
+    import threading
+    rig = synth.make_rig("scene", 3, 512, 424, seed=8, perturb=True)
+    want_v, counts, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    e = np.concatenate([[0], np.cumsum(counts)])
+    xyz = np.stack([want_v["X"], want_v["Y"], want_v["Z"]], axis=1).astype(np.float32)
+    target, source = np.ascontiguousarray(xyz[e[0]:e[1]]), np.ascontiguousarray(xyz[e[1]:e[2]])
+    ref_src, ref_R, ref_t = native.icp(target, source.copy(), max_iter=3)
+    errors = []
+
+    def merge_worker():
+        try:
+            for _ in range(6):
+                v, t = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+                assert v.tobytes() == want_v.tobytes() and np.array_equal(t, want_t)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    def refine_worker():
+        try:
+            for _ in range(6):
+                one = native.generate_vertices_from_depth_map(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, 1)
+                assert one.tobytes() == want_v[e[1]:e[2]].tobytes()
+                s2, R, t = native.icp(target, source.copy(), max_iter=3)
+                assert s2.tobytes() == ref_src.tobytes() and R.tobytes() == ref_R.tobytes() and t.tobytes() == ref_t.tobytes()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=merge_worker), threading.Thread(target=refine_worker)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
