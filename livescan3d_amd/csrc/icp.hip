@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64) void super_box_kernel(const GridParams *gp, con
 // (slack covers the rounding of the cell arithmetic).  Otherwise the query joins the far list, carrying what it found.
 __global__ __launch_bounds__(kThreads) void nn_grid_kernel(const float *queries, int n2, const GridParams *gp, const int *cell_start,
                                                            const float4 *sorted, int *idx, float *dist, unsigned long long *keys,
-                                                           int *far_list, int *n_far)
+                                                           int *far_list, int *n_far, const float *seed_targets, int n1)
 {
     const GridParams g = *gp;
     const int i = blockIdx.x * kThreads + threadIdx.x;
@@ -403,6 +403,20 @@ __global__ __launch_bounds__(kThreads) void nn_grid_kernel(const float *queries,
     const int cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
     float best = INFINITY;
     int best_i = 0x7FFFFFFF;
+    if (seed_targets) {
+        // ICP iterations after the first: the query moved a little, so its previous neighbour (idx[i], a real target
+        // point) is an excellent candidate.  Starting from it changes nothing in the result -- the answer is still the
+        // lexicographic (distance, index) minimum over every point that is not provably farther -- but the far pass
+        // begins with a tight bound and prunes almost the whole hierarchy at once.
+        const int k = idx[i];
+        if ((unsigned int)k < (unsigned int)n1) {
+            const float d = dist2(qx, qy, qz, seed_targets[3 * (size_t)k], seed_targets[3 * (size_t)k + 1], seed_targets[3 * (size_t)k + 2]);
+            if (d == d) {  // not NaN
+                best = d;
+                best_i = k;
+            }
+        }
+    }
     // This kernel is a chain of dependent memory round trips per query, not arithmetic: fetch all 27 cell ranges at once
     // (54 independent loads in flight), then walk them with the point loads issued four at a time.
     int rs[27], re[27];
@@ -506,8 +520,10 @@ __global__ __launch_bounds__(kThreads) void nn_far_kernel(const float *queries, 
         const int s = __shfl(mc, src, 64) * 64 + src;
         if (lane == src) md[s] = INFINITY;  // visited (only this lane ever reads the entry again)
 
-        // its 64 blocks, one per lane
+        // its 64 blocks, one per lane; every lane also fetches its block's point range now, so that the candidate loop
+        // below starts on the points without another dependent round trip per block
         const Box bb = boxes[s * 64 + lane];
+        const int range0 = cell_start[(s * 64 + lane) * 64], range1 = cell_start[(s * 64 + lane) * 64 + 64];
         const float mb = box_min_dist2(qx, qy, qz, bb);
         bound = fminf(bound, wave_min_f(box_max_dist2(qx, qy, qz, bb)));
         unsigned long long cand = __ballot(mb <= bound);
@@ -516,9 +532,8 @@ __global__ __launch_bounds__(kThreads) void nn_far_kernel(const float *queries, 
         while (cand) {
             const int b = __ffsll((long long)cand) - 1;
             cand &= cand - 1;
-            const int c0 = (s * 64 + b) * 64;
-            const int e = cell_start[c0 + 64];
-            for (int j = cell_start[c0] + lane; j < e; j += 64) {
+            const int e = __shfl(range1, b, 64);
+            for (int j = __shfl(range0, b, 64) + lane; j < e; j += 64) {
                 const float4 p = sorted[j];
                 const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
                 const int k = __float_as_int(p.w);
@@ -542,6 +557,72 @@ __global__ __launch_bounds__(kThreads) void nn_far_kernel(const float *queries, 
         idx[i] = best_i;
         dist[i] = best;
         if (keys) claim_target(keys, best_i, best, i);
+    }
+}
+
+// Far queries that come with a good candidate (ICP iterations after the first: the previous neighbour seeds the search):
+// the job is no longer to FIND a near point but to PROVE that nothing is nearer.  Still one wave per query (point scans
+// must stay 64 wide: a single lane walking a block's points is a chain of dependent loads), but without the machinery of
+// the exploring kernel above -- no nearest-first ordering, no LDS table, one reduction at the very end: the lanes test the
+// super-block boxes 64 at a time against the candidate's distance, the (few) boxes that do not exceed it are opened in
+// index order, lanes keep private (distance, index) minima and only the bound is refreshed per super-block.  Same pruning
+// rule as everywhere: a box is skipped only when its exact f32 minimum distance EXCEEDS the bound; ties go to the lowest index.
+__global__ __launch_bounds__(kThreads) void nn_far_seeded_kernel(const float *queries, const GridParams *gp, const int *cell_start,
+                                                                 const float4 *sorted, const Box *boxes, const Box *supers,
+                                                                 const int *far_list, const int *n_far, int *idx, float *dist,
+                                                                 unsigned long long *keys, int *far2_list, int *n_far2)
+{
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);  // one query per wave
+    if (slot >= *n_far) return;                                          // wave-uniform
+    const int i = far_list[slot];
+    const float qx = queries[3 * (size_t)i], qy = queries[3 * (size_t)i + 1], qz = queries[3 * (size_t)i + 2];
+    const float seed = dist[i];
+    const int seed_i = idx[i];
+    if (!(seed < INFINITY)) {  // inf / NaN: nothing to prove against -> the exploring kernel searches from scratch
+        if (lane == 0) far2_list[atomicAdd(n_far2, 1)] = i;
+        return;
+    }
+    float bound = seed;                 // wave-uniform
+    float lbest = seed;                 // per-lane running minimum, lexicographic with lbi
+    int lbi = seed_i;
+    const int n_supers = gp->ncells / 4096;
+    for (int c0 = 0; c0 < n_supers; c0 += 64) {
+        const int sl = c0 + lane;
+        float m = INFINITY;
+        if (sl < n_supers) m = box_min_dist2(qx, qy, qz, supers[sl]);
+        unsigned long long open = __ballot(m <= bound);
+        while (open) {
+            const int s = c0 + __ffsll((long long)open) - 1;
+            open &= open - 1;
+            // the super-block's 64 blocks, one per lane, with their point ranges
+            const Box bb = boxes[s * 64 + lane];
+            const int range0 = cell_start[(s * 64 + lane) * 64], range1 = cell_start[(s * 64 + lane) * 64 + 64];
+            unsigned long long cand = __ballot(box_min_dist2(qx, qy, qz, bb) <= bound);
+            while (cand) {
+                const int b = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const int e = __shfl(range1, b, 64);
+                for (int j = __shfl(range0, b, 64) + lane; j < e; j += 64) {
+                    const float4 p = sorted[j];
+                    const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
+                    const int k = __float_as_int(p.w);
+                    if (d < lbest || (d == lbest && k < lbi)) {
+                        lbest = d;
+                        lbi = k;
+                    }
+                }
+            }
+            bound = wave_min_f(lbest);
+            // super-blocks of this chunk that the tighter bound rules out need not be opened
+            open &= __ballot(m <= bound);
+        }
+    }
+    const unsigned long long key = wave_min_u64(((unsigned long long)__float_as_uint(lbest) << 32) | (unsigned int)lbi);
+    if (lane == 0) {
+        idx[i] = (int)(unsigned int)key;
+        dist[i] = __uint_as_float((unsigned int)(key >> 32));
+        if (keys) claim_target(keys, (int)(unsigned int)key, __uint_as_float((unsigned int)(key >> 32)), i);
     }
 }
 
@@ -847,8 +928,9 @@ struct LsnIcp {
     int max_n1 = 0, max_n2 = 0;
     float cell_override = 0.0f;
     lsn::DevBuf gp, bbox_part, cell_of, cell_cnt, cell_start, block_sums, sorted, boxes, supers;
-    lsn::DevBuf idx, dist, keys, unresolved, counters, part1, part2, part3, state, trace;
+    lsn::DevBuf idx, dist, keys, unresolved, unresolved2, counters, part1, part2, part3, state, trace;
     int trace_iters = 0;
+    bool seed_nn = true;   // $LSN_ICP_NO_SEED=1 turns the previous-neighbour seeding off (ablation)
     std::mutex mu;
 };
 
@@ -867,6 +949,7 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
     w->device = device;
     w->max_n1 = max_n1;
     w->max_n2 = max_n2;
+    if (const char *e2 = getenv("LSN_ICP_NO_SEED")) w->seed_nn = atoi(e2) == 0;
     const char *env = getenv("LSN_ICP_CELL");
     if (env) w->cell_override = (float)atof(env);
     bool bad = false;
@@ -883,6 +966,7 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
     bad |= w->dist.reserve(sizeof(float) * (size_t)max_n2) != 0;
     bad |= w->keys.reserve(sizeof(unsigned long long) * (size_t)max_n1) != 0;
     bad |= w->unresolved.reserve(sizeof(int) * (size_t)max_n2) != 0;
+    bad |= w->unresolved2.reserve(sizeof(int) * (size_t)max_n2) != 0;
     bad |= w->counters.reserve(64) != 0;
     bad |= w->part1.reserve(sizeof(double) * 2 * kMaxBlocks) != 0;
     bad |= w->part2.reserve(sizeof(double) * kMaxBlocks) != 0;
@@ -933,7 +1017,7 @@ static int build_grid(LsnIcp *w, const float *d_verts1, int n1, hipStream_t s)
 }
 
 static int run_nn(LsnIcp *w, const float *d_verts1, int n1, const float *d_verts2, int n2, int *d_idx, float *d_dist,
-                  unsigned long long *keys, int nn_mode, hipStream_t s)
+                  unsigned long long *keys, int nn_mode, hipStream_t s, bool seeded = false)
 {
     if (nn_mode == 0) {
         hipLaunchKernelGGL(nn_brute_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts1, n1, d_verts2, n2, (const int *)nullptr,
@@ -942,13 +1026,35 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, const float *d_verts
         int *n_unres = w->counters.as<int>();
         LSN_HIP(hipMemsetAsync(n_unres, 0, sizeof(int), s));
         hipLaunchKernelGGL(nn_grid_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts2, n2, w->gp.as<GridParams>(),
-                           w->cell_start.as<int>(), w->sorted.as<float4>(), d_idx, d_dist, keys, w->unresolved.as<int>(), n_unres);
-        // the queries the neighbourhood scan could not prove; workgroups beyond the list length exit at once
+                           w->cell_start.as<int>(), w->sorted.as<float4>(), d_idx, d_dist, keys, w->unresolved.as<int>(), n_unres,
+                           seeded ? d_verts1 : (const float *)nullptr, n1);
+        const int *far = w->unresolved.as<int>();
+        const int *n_far = n_unres;
+        if (seeded) {
+            // every far query carries its previous neighbour: the proving kernel takes them; only queries without a
+            // finite candidate go on to the exploring kernel
+            LSN_HIP(hipMemsetAsync(n_unres + 1, 0, sizeof(int), s));
+            hipLaunchKernelGGL(nn_far_seeded_kernel, dim3((n2 + 3) / 4), dim3(kThreads), 0, s, d_verts2, (const GridParams *)w->gp.as<GridParams>(),
+                               (const int *)w->cell_start.as<int>(), (const float4 *)w->sorted.as<float4>(), (const Box *)w->boxes.as<Box>(),
+                               (const Box *)w->supers.as<Box>(), far, n_far, d_idx, d_dist, keys, w->unresolved2.as<int>(), n_unres + 1);
+            far = w->unresolved2.as<int>();
+            n_far = n_unres + 1;
+        }
+        // the queries nothing above could prove; workgroups beyond the list length exit at once
         hipLaunchKernelGGL(nn_far_kernel, dim3((n2 + 3) / 4), dim3(kThreads), 0, s, d_verts2, (const GridParams *)w->gp.as<GridParams>(),
                            (const int *)w->cell_start.as<int>(), (const float4 *)w->sorted.as<float4>(), (const Box *)w->boxes.as<Box>(),
-                           (const Box *)w->supers.as<Box>(), (const int *)w->unresolved.as<int>(), (const int *)n_unres, d_idx, d_dist, keys);
+                           (const Box *)w->supers.as<Box>(), far, n_far, d_idx, d_dist, keys);
     }
     LSN_HIP(hipGetLastError());
+    static const bool debug = getenv("LSN_ICP_DEBUG") != nullptr;   // dev aid: synchronises, prints the far-list sizes and the grid
+    if (debug && nn_mode != 0) {
+        int c[2] = {0, 0};
+        GridParams g;
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(c, w->counters.p, sizeof(c), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&g, w->gp.p, sizeof(g), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[lsn icp] n2=%d far=%d far2=%d h=%g grid=%dx%dx%d\n", n2, c[0], seeded ? c[1] : -1, (double)g.h, g.nx, g.ny, g.nz);
+    }
     return 0;
 }
 
@@ -1003,7 +1109,8 @@ extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_vert
     IcpState *st = w->state.as<IcpState>();
     for (int iter = 0; iter < maxIter; iter++) {
         LSN_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)n1, s));
-        if (run_nn(w, d_verts1, n1, d_verts2, n2, w->idx.as<int>(), w->dist.as<float>(), keys, nn_mode, s)) return -1;
+        // from the second iteration on idx[] still holds every query's previous neighbour: the search is seeded with it
+        if (run_nn(w, d_verts1, n1, d_verts2, n2, w->idx.as<int>(), w->dist.as<float>(), keys, nn_mode, s, iter > 0 && w->seed_nn)) return -1;
         hipLaunchKernelGGL(stats1_kernel, dim3(nb), dim3(kThreads), 0, s, w->idx.as<int>(), w->dist.as<float>(), keys, n2,
                            w->part1.as<double>());
         hipLaunchKernelGGL(stats2_kernel, dim3(nb), dim3(kThreads), 0, s, w->idx.as<int>(), w->dist.as<float>(), keys, n2,
