@@ -155,3 +155,67 @@ def test_ragged_sizes_and_hostile_calibrations(gpu, orc):
         fus.set_params(r.intr, r.wt, r.bounds)
         for i in range(3):
             _run_and_compare(orc, fus, [r], f"{name}, run {i + 1}")
+
+
+def test_fuzzed_calibrations_at_every_interval_boundary(gpu, orc):
+    """Random (and some hostile) calibrations; the depth frames are built FROM the table so that every pixel sits exactly on
+    and next to both ends of its interval (lo-1, lo, lo+n-1, lo+n): the threshold count (plan A, table built) and the
+    arithmetic count (plan B, first run after SetParams) must agree on every tick, and both must equal the oracle."""
+    import torch
+    from livescan3d_amd.fusion import DeviceFusion
+    rng = np.random.default_rng(2026)
+    widths, heights = [64, 40, 57], [48, 56, 31]
+    n = len(widths)
+    P = [w * h for w, h in zip(widths, heights)]
+    T = 4
+
+    def rot(rng):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        a, b, c, d = q
+        return np.array([[a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c)], [2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b)],
+                         [2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d]], dtype=np.float32)
+
+    plan_a = DeviceFusion(T, widths, heights)
+    plan_b = DeviceFusion(T, widths, heights)
+    flagged_seen = 0
+    for trial in range(24):
+        intr = np.concatenate([synth.kinect_intrinsics(w, h) * np.float32(rng.uniform(0.8, 1.2)) for w, h in zip(widths, heights)]).astype(np.float32)
+        wt = np.concatenate([np.concatenate([rng.normal(scale=1.5, size=3).astype(np.float32), rot(rng).ravel()]) for _ in range(n)]).astype(np.float32)
+        c = rng.normal(scale=1.0, size=3)
+        half = rng.uniform(0.05, 3.0, size=3)
+        bounds = np.concatenate([c - half, c + half]).astype(np.float32)
+        if trial % 6 == 5:
+            wt[12 * (trial % n) + 3 + trial % 9] = [np.nan, np.inf, 1e30, -np.inf][(trial // 6) % 4]      # a hostile entry in one sensor's pose
+        if trial % 8 == 7:
+            bounds[[0, 3]] = bounds[[3, 0]]                                                   # inverted X range
+        plan_a.set_params(intr, wt, bounds)
+        table, _ = plan_a.plan.thresholds()
+        lo, cnt = (table & 0xFFFF).astype(np.int64), (table >> 16).astype(np.int64)
+        flagged_seen += int((lo == 0).any())
+        # ticks: lo-1, lo, lo+n-1, lo+n, clamped to u16; flagged / empty pixels get random depths
+        rnd = rng.integers(0, 65536, size=(T, lo.size))
+        d = np.stack([lo - 1, lo, lo + cnt - 1, lo + cnt])
+        d = np.where((lo == 0)[None, :] | (cnt == 0)[None, :], rnd, d)
+        d = np.clip(d, 0, 65535).astype(np.uint16)
+        rgb = rng.integers(0, 256, size=(T, 3 * lo.size)).astype(np.uint8)
+        depth_t, rgb_t = torch.from_numpy(d.view(np.int16)).cuda(), torch.from_numpy(rgb).cuda()
+        va, oa = plan_a.run(depth_t, rgb_t)                        # table in use
+        plan_b.set_params(intr, wt, bounds)
+        vb, ob = plan_b.run(depth_t, rgb_t)                        # first run with these parameters: arithmetic count
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob), f"trial {trial}: per-sensor offsets differ between the two count passes"
+        oa_h = oa.cpu().numpy()
+        for k in range(T):
+            nv = int(oa_h[k, -1])
+            assert torch.equal(va[k, :nv], vb[k, :nv]), f"trial {trial} tick {k}"
+        if trial % 4 == 0:
+            pos = np.concatenate([[0], np.cumsum(P)])
+            for k in range(T):
+                r = synth.Rig([d[k, pos[i]:pos[i + 1]].reshape(heights[i], widths[i]) for i in range(n)],
+                              [rgb[k, 3 * pos[i]:3 * pos[i + 1]].reshape(heights[i], widths[i], 3) for i in range(n)], intr, wt, bounds)
+                want, counts = _oracle(orc, r)
+                assert list(np.diff(oa_h[k])) == list(counts), f"trial {trial} tick {k}: counts vs oracle"
+                got = va[k, :len(want)].cpu().numpy().view(native.VERTEX_DTYPE).reshape(-1)
+                assert got.tobytes() == want.tobytes(), f"trial {trial} tick {k}: vertices vs oracle"
+    assert flagged_seen >= 3
