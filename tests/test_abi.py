@@ -51,6 +51,13 @@ def test_compute_fails_loudly_without_gpu():
         native.icp(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32))
     with pytest.raises(native.NativeUtilsError):
         native.FusionPlan(0, 1, [16], [8])
+    # the outbound formats are built on the device as well: no GPU, no bytes
+    with pytest.raises(native.NativeUtilsError):
+        native.TransferPacker(0, 16, 16)
+    with pytest.raises(native.NativeUtilsError):
+        native.last_mesh_ply()
+    with pytest.raises(native.NativeUtilsError):
+        native.last_mesh_transfer_frame()
     # the raw export leaves an empty mesh and an error message instead of throwing across the ABI
     L = native.lib()
     mesh = native.Mesh()
