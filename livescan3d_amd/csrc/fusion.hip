@@ -1126,6 +1126,84 @@ __global__ __launch_bounds__(kThreads) void radial_gather_kernel(const FrameDesc
     }
 }
 
+// The warp target of a pixel depends on the intrinsics only, not on the depth values: per calibration, every destination
+// pixel gets the (at most four) source pixels that map onto it, highest index first -- the reference's raster-order loop
+// lets the LAST valid source win (:200-218).  A tick then needs no atomics, no winner array and no memset: the corrected
+// pixel is the first candidate whose depth is not zero.  Destinations with more than four sources (a pathologically
+// contracting calibration) raise the overflow flag and the batch takes the atomicMax path above instead.
+__global__ __launch_bounds__(kThreads) void radial_cand_fill_kernel(const FrameDesc *frames, const TileDesc *tiles, const RadialParams *rp,
+                                                                    unsigned int *count, unsigned int *cand, int *overflow)
+{
+    const int tile = blockIdx.x;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const RadialParams P = rp[td.frame];
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        const int y = p / fd.w, x = p - y * fd.w;
+        const float u = ((float)x - P.cx) / P.fx;                              // :204
+        const float v = ((float)y - P.cy) / P.fy;                              // :205
+        const float r = u * u + v * v;                                         // :206
+        const float d = 1 - P.r2 * r - P.r4 * r * r - P.r6 * r * r * r;        // :207
+        const int x_corr = f2i_x86(u * d * P.fx + P.cx);                       // :209
+        const int y_corr = f2i_x86(v * d * P.fy + P.cy);                       // :210
+        if (x_corr >= 0 && y_corr >= 0 && x_corr < fd.w && y_corr < fd.h) {    // :212
+            const long long dst = fd.depth_off + x_corr + (long long)y_corr * fd.w;
+            const unsigned int slot = atomicAdd(&count[dst], 1u);
+            if (slot < 4) cand[4 * dst + slot] = (unsigned int)p + 1u;
+            else atomicOr(overflow, 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void radial_cand_sort_kernel(uint4 *cand, long long n)
+{
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    uint4 c = cand[i];
+    // descending, empty slots (0) last: a 4-element sorting network
+    auto cswap = [](unsigned int &a, unsigned int &b) { const unsigned int hi = max(a, b), lo = min(a, b); a = hi; b = lo; };
+    cswap(c.x, c.y); cswap(c.z, c.w); cswap(c.x, c.z); cswap(c.y, c.w); cswap(c.y, c.z);
+    cand[i] = c;
+}
+
+__global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const FrameDesc *frames, const TileDesc *tiles, const unsigned short *depth,
+                                                                      const unsigned char *rgb, const uint4 *cand, unsigned short *map_copy,
+                                                                      unsigned char *colors_copy, int tiles_per_tick, long long tick_pix_stride)
+{
+    const int tick = blockIdx.x / tiles_per_tick;
+    const int tile = blockIdx.x - tick * tiles_per_tick;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const long long fb = tick * tick_pix_stride + fd.depth_off;
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        const uint4 c = cand[fd.depth_off + p];
+        // all four candidate depths are fetched at once (independent loads); the first non-zero one wins
+        const unsigned short d0 = c.x ? depth[fb + (c.x - 1u)] : 0, d1 = c.y ? depth[fb + (c.y - 1u)] : 0;
+        const unsigned short d2 = c.z ? depth[fb + (c.z - 1u)] : 0, d3 = c.w ? depth[fb + (c.w - 1u)] : 0;
+        unsigned int src = 0;
+        unsigned short d = 0;
+        if (d0) { src = c.x; d = d0; }
+        else if (d1) { src = c.y; d = d1; }
+        else if (d2) { src = c.z; d = d2; }
+        else if (d3) { src = c.w; d = d3; }
+        unsigned char c0 = 0, c1 = 0, c2 = 0;
+        if (src) {
+            const long long sidx = fb + (long long)(src - 1u);
+            c0 = rgb[3 * sidx]; c1 = rgb[3 * sidx + 1]; c2 = rgb[3 * sidx + 2];
+        }
+        map_copy[fb + p] = d;
+        colors_copy[3 * (fb + p)] = c0;
+        colors_copy[3 * (fb + p) + 1] = c1;
+        colors_copy[3 * (fb + p) + 2] = c2;
+    }
+}
+
 // One workgroup per sensor-frame, one thread per row (bands of blockDim rows when h is larger).  At step t the thread of
 // row y handles column x = 1 + t - 2 (y - band0): the pixels it reads from row y-1 (x-1, x, x+1) were finished at least
 // one barrier ago, its own left neighbour one step ago, everything to the right and below is still original -- exactly
@@ -1392,6 +1470,9 @@ struct LsnFusion {
     lsn::DevBuf xtab, ytab;
     lsn::DevBuf pixmap, tri_counts, tri_codes;  // triangulation scratch, allocated on first use
     lsn::DevBuf winner, map_copy, colors_copy, radial;  // radial-correction scratch, allocated on first use
+    lsn::DevBuf cand;                                   // [pixels per tick][4] warp candidates of the current intrinsics
+    std::vector<float> radial_intr;                     // the intrinsics `cand` was built for
+    bool cand_valid = false, cand_overflow = false;
     // pipelined mode: the count + scan of call k+1 run on a side stream while the write kernel of call k is still busy
     bool pipelined = false;
     hipStream_t side = nullptr;
@@ -1992,17 +2073,43 @@ extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, vo
         const float *ip = intr_params + 7 * i;  // IntrinsicCameraParameters(float*), include/NativeUtils/depthprocessing.h:96-97
         rp[i] = RadialParams{ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], 0.0f};
     }
-    LSN_HIP(hipMemcpyAsync(p->radial.p, rp.data(), sizeof(RadialParams) * p->n_maps, hipMemcpyHostToDevice, s));
-    LSN_HIP(hipStreamSynchronize(s));  // rp is a local
-    LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * npix, s));
     const int grid = p->tiles_per_tick * p->n_ticks;
-    hipLaunchKernelGGL(radial_warp_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
-                       p->radial.as<RadialParams>(), static_cast<const unsigned short *>(d_depth), p->winner.as<unsigned int>(),
-                       p->tiles_per_tick, p->cap);
-    hipLaunchKernelGGL(radial_gather_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
-                       static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors),
-                       (const unsigned int *)p->winner.as<unsigned int>(), p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(),
-                       p->tiles_per_tick, p->cap);
+    const bool same_intr = p->cand_valid && p->radial_intr.size() == 7 * (size_t)p->n_maps &&
+                           memcmp(p->radial_intr.data(), intr_params, sizeof(float) * 7 * p->n_maps) == 0;
+    if (!same_intr) {
+        LSN_HIP(hipMemcpyAsync(p->radial.p, rp.data(), sizeof(RadialParams) * p->n_maps, hipMemcpyHostToDevice, s));
+        LSN_HIP(hipStreamSynchronize(s));  // rp is a local
+        // the warp candidates of this calibration (one tick's worth of pixels; `winner` serves as the per-destination counter)
+        if (p->cand.reserve(16 * (size_t)p->cap)) return -1;
+        LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * (size_t)p->cap, s));
+        LSN_HIP(hipMemsetAsync(p->cand.p, 0, 16 * (size_t)p->cap, s));
+        LSN_HIP(hipMemsetAsync(p->misc.as<char>() + 64, 0, sizeof(int), s));
+        int *overflow = reinterpret_cast<int *>(p->misc.as<char>() + 64);
+        hipLaunchKernelGGL(radial_cand_fill_kernel, dim3(p->tiles_per_tick), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(),
+                           p->tile_frame.as<TileDesc>(), p->radial.as<RadialParams>(), p->winner.as<unsigned int>(), p->cand.as<unsigned int>(), overflow);
+        hipLaunchKernelGGL(radial_cand_sort_kernel, dim3((unsigned)((p->cap + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p->cand.as<uint4>(),
+                           p->cap);
+        int ov = 0;
+        LSN_HIP(hipMemcpyAsync(&ov, overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+        LSN_HIP(hipStreamSynchronize(s));
+        p->cand_overflow = ov != 0;
+        p->radial_intr.assign(intr_params, intr_params + 7 * (size_t)p->n_maps);
+        p->cand_valid = true;
+    }
+    if (!p->cand_overflow) {
+        hipLaunchKernelGGL(radial_gather_cand_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                           static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors), (const uint4 *)p->cand.as<uint4>(),
+                           p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->tiles_per_tick, p->cap);
+    } else {
+        LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * npix, s));
+        hipLaunchKernelGGL(radial_warp_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                           p->radial.as<RadialParams>(), static_cast<const unsigned short *>(d_depth), p->winner.as<unsigned int>(),
+                           p->tiles_per_tick, p->cap);
+        hipLaunchKernelGGL(radial_gather_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                           static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors),
+                           (const unsigned int *)p->winner.as<unsigned int>(), p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(),
+                           p->tiles_per_tick, p->cap);
+    }
     int max_h = 1;
     for (int v : p->h) max_h = v > max_h ? v : max_h;
     int rows = max_h - 2 < 64 ? 64 : ((max_h - 2 + 63) / 64) * 64;

@@ -59,7 +59,10 @@ def test_warp_edge_cases(gpu, orc):
     w, h = 64, 48
     rgb = synth.noise_frame(5, 0, 0, w, h)[1]
     depth = synth.noise_frame(5, 0, 1, w, h)[0]
-    for r in ([0.5, 0.0, 0.0], [-0.8, 0.3, 0.0], [3.0, -5.0, 9.0], [np.nan, 0, 0], [1e30, 0, 0]):
+    # [0.5..] / [0.7..] / [3..]: the radial map folds inside the frame (1 - 3 r2 r = 0), so far more than four sources pile up
+    # on the destinations along the fold -> the per-calibration candidate table overflows and the atomicMax path runs;
+    # [0, 0, 0] is the identity (exactly one candidate everywhere), [-0.8..] expands (gaps, at most one candidate)
+    for r in ([0.5, 0.0, 0.0], [0.7, 0.0, 0.0], [0.0, 0.0, 0.0], [-0.8, 0.3, 0.0], [3.0, -5.0, 9.0], [np.nan, 0, 0], [1e30, 0, 0]):
         intr = synth.kinect_intrinsics(w, h).copy()
         intr[4:7] = r
         _check(orc, _rig([depth], [rgb], [intr]), f"r={r}")
