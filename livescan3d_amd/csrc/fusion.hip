@@ -2096,7 +2096,8 @@ extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, vo
         p->radial_intr.assign(intr_params, intr_params + 7 * (size_t)p->n_maps);
         p->cand_valid = true;
     }
-    if (!p->cand_overflow) {
+    const char *force = getenv("LSN_RADIAL_FORCE_ATOMIC");  // tests: take the atomicMax path even when the table did not overflow
+    if (!p->cand_overflow && !(force && atoi(force) != 0)) {
         hipLaunchKernelGGL(radial_gather_cand_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
                            static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors), (const uint4 *)p->cand.as<uint4>(),
                            p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->tiles_per_tick, p->cap);

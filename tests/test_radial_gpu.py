@@ -95,3 +95,14 @@ def test_device_resident_batch_then_fusion(gpu, orc):
         want_v, _ = orc.generate_mesh_vertices(want_d, want_c, rigs[k].widths, rigs[k].heights, rigs[0].intr, rigs[0].wt, rigs[0].bounds)
         n = int(off[k, -1])
         assert verts[k, :n].cpu().numpy().tobytes() == want_v.tobytes()
+
+
+def test_both_warp_paths_agree_with_the_oracle(gpu, orc, monkeypatch):
+    """The per-calibration candidate table and the atomicMax path it falls back to (forced here) on the same frames."""
+    rig = synth.make_rig("scene", 2, 512, 424, seed=12)
+    want_d, want_c = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+    for forced in ("0", "1"):
+        monkeypatch.setenv("LSN_RADIAL_FORCE_ATOMIC", forced)
+        got_d, got_c = native.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+        assert np.array_equal(np.asarray(got_d).view(np.uint8).ravel(), np.asarray(want_d).view(np.uint8).ravel()), forced
+        assert np.array_equal(np.asarray(got_c).ravel(), np.asarray(want_c).ravel()), forced
