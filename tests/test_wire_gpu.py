@@ -128,3 +128,37 @@ def test_last_mesh_exports_for_host_callers(gpu, orc):
     none = np.zeros((0, 3), np.int32)
     assert native.last_mesh_transfer_frame() == orc.transfer_frame(v1, none)
     assert native.last_mesh_ply() == orc.ply_binary(v1, none)
+
+
+def test_handles_release_their_device_memory(gpu):
+    """Creating and destroying plans / workspaces / packers repeatedly must not leak HBM (the server re-creates its plan
+    whenever a client with another frame size connects)."""
+    import torch
+    from livescan3d_amd.fusion import DeviceFusion
+    rig = synth.make_rig("noise", 2, 512, 424, seed=2)
+
+    def cycle():
+        fus = DeviceFusion(2, rig.widths, rig.heights)
+        fus.set_params(rig.intr, rig.wt, rig.bounds)
+        d = torch.from_numpy(np.stack([rig.depth_maps.view(np.int16)] * 2)).cuda()
+        c = torch.from_numpy(np.stack([rig.depth_colors] * 2)).cuda()
+        for _ in range(3):
+            fus.run(d, c)                                           # third run: thresholds exist
+        st = int(torch.cuda.current_stream().cuda_stream)
+        fus.plan.radial_correct(rig.intr, d.data_ptr(), c.data_ptr(), st)
+        ws = native.IcpWorkspace(0, 50_000, 50_000)
+        pk = native.TransferPacker(0, 100_000, 200_000)
+        torch.cuda.synchronize()
+        ws.close(); pk.close(); fus.plan.close()
+        del fus, d, c
+
+    cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of HBM lost over 8 create/destroy cycles"
