@@ -199,6 +199,29 @@ def main():
             },
         }
 
+    # ---- ablation (extra field): the same steps with the arithmetic count pass (no per-pixel depth thresholds) ------------
+    if rank == 0 and not multi and args.mode == 0 and not args.core_only and os.environ.get("LSN_NO_THRESHOLDS", "0") in ("", "0"):
+        os.environ["LSN_NO_THRESHOLDS"] = "1"          # read when a plan is created
+        try:
+            fus_a = DeviceFusion(B, [w] * S_loc, [h] * S_loc, device=dev_index, mode=0)
+        finally:
+            del os.environ["LSN_NO_THRESHOLDS"]
+        fus_a.set_params(intr_all[7 * s0:7 * (s0 + S_loc)], wt_all[12 * s0:12 * (s0 + S_loc)], bounds)
+        for _ in range(args.warmup + 1):
+            fus_a.run(depth, rgb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fus_a.run(depth, rgb)
+        torch.cuda.synchronize()
+        dta = time.perf_counter() - t0
+        same = bool(torch.equal(fus_a.offsets, fus.offsets))
+        result["arithmetic_count_pass"] = {"value": B * args.steps / dta, "unit": "frames/s", "ms_per_step": 1e3 * dta / args.steps,
+                                           "offsets_identical": same,
+                                           "note": "LSN_NO_THRESHOLDS=1: the count pass re-evaluates unproject + transform + crop per pixel "
+                                                   "(fuse_kernel<0>) instead of comparing the depth with the per-pixel interval"}
+        del fus_a
+
     # ---- pipelined calls (extra field): count(k+1) beside write(k) on an internal side stream -------------------------
     if rank == 0 and not multi and args.mode == 0 and not args.core_only:
         fus.plan.set_pipelined(True)
