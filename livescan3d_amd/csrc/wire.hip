@@ -648,7 +648,11 @@ long long lsnFrameDecode(const unsigned char *payload, int payload_bytes, int co
         Zstd &z = zstd();
         if (!z.ok) { lsn::set_error("lsnFrameDecode: compressed frame but libzstd.so.1 could not be loaded"); return -1; }
         const unsigned long long out = z.decompressed_size(payload, (size_t)payload_bytes);     // ZSTDDecompressor.cs:28
-        if (out == 0 || out > (1ull << 31)) { lsn::set_error("lsnFrameDecode: not a zstd frame with a known size"); return -1; }
+        // a frame is w*h*5 bytes plus a few KB of body joints: anything else is a corrupted length field, not worth allocating
+        if (out < (unsigned long long)(5 * P + 4) || out > (unsigned long long)(5 * P) + (1ull << 20)) {
+            lsn::set_error("lsnFrameDecode: the zstd frame announces %llu bytes, a %d x %d frame has %lld + bodies", out, width, height, 5 * P);
+            return -1;
+        }
         tmp.resize((size_t)out);
         const size_t got = z.decompress(tmp.data(), tmp.size(), payload, (size_t)payload_bytes);
         if (z.is_error(got) || got != out) { lsn::set_error("lsnFrameDecode: zstd decompression failed"); return -1; }

@@ -177,3 +177,53 @@ def test_frame_message_and_recording(orc):
     assert list(native.recording_frames(rec)) == want
     with pytest.raises(native.NativeUtilsError):
         list(native.recording_frames(rec[:-50]))
+
+
+def test_inbound_parsers_survive_corrupted_input():
+    """The frame message and the recording file come from the network / from disk: truncated, bit-flipped or random input
+    must end in NativeUtilsError (or a clean end of iteration), never in a crash or an out-of-bounds read."""
+    rng = np.random.default_rng(77)
+    w, h = 32, 24
+    depth = rng.integers(0, 6000, size=(h, w)).astype(np.uint16)
+    rgb = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+    bodies = bodies_block(rng, 1, 25)
+    msgs = [native.frame_encode(depth, rgb, bodies, 0)]
+    if native.zstd_available():
+        msgs.append(native.frame_encode(depth, rgb, bodies, 3))
+    outcomes = {"ok": 0, "error": 0, "end": 0}
+    for trial in range(1500):
+        m = bytearray(msgs[trial % len(msgs)])
+        kind = trial % 5
+        if kind == 0:
+            m = m[:int(rng.integers(0, len(m)))]                              # truncated
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 8))):
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))   # bit flips anywhere
+        elif kind == 2:
+            m[:16] = rng.integers(0, 256, 16, dtype=np.uint8).tobytes()       # random header
+        elif kind == 3:
+            m[0:4] = struct.pack("<i", int(rng.integers(-2**31, 2**31)))      # absurd payload length
+        else:
+            m = bytearray(rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8).tobytes())
+        try:
+            r = native.frame_decode(bytes(m))
+            outcomes["end" if r is None else "ok"] += 1
+        except native.NativeUtilsError:
+            outcomes["error"] += 1
+    assert outcomes["error"] > 300 and outcomes["ok"] > 0
+    rec = native.recording_append(msgs[0], 1) + native.recording_append(msgs[0], 2)
+    for trial in range(300):
+        r = bytearray(rec)
+        if trial % 2:
+            r = r[:int(rng.integers(0, len(r)))]
+        else:
+            for _ in range(3):
+                r[int(rng.integers(0, 60))] = int(rng.integers(0, 256))       # mangle the first record's text header
+        try:
+            for _, frame in native.recording_frames(bytes(r)):
+                try:
+                    native.frame_decode(frame)
+                except native.NativeUtilsError:
+                    pass
+        except native.NativeUtilsError:
+            pass
