@@ -106,3 +106,22 @@ def test_both_warp_paths_agree_with_the_oracle(gpu, orc, monkeypatch):
         got_d, got_c = native.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
         assert np.array_equal(np.asarray(got_d).view(np.uint8).ravel(), np.asarray(want_d).view(np.uint8).ravel()), forced
         assert np.array_equal(np.asarray(got_c).ravel(), np.asarray(want_c).ravel()), forced
+
+
+def test_more_frames_than_compute_units(gpu, orc):
+    """With more than 256 sensor-frames in a batch the hole-closing kernel switches to 256-row bands (two bands for h = 424,
+    three frames per CU); a 1024-row frame needs two 768-row bands.  Every frame against the oracle."""
+    import torch
+    T, N, w, h = 33, 8, 512, 424                                 # 264 frames
+    rigs = [synth.make_rig("noise" if k % 3 else "scene", N, w, h, seed=14, tick=k) for k in range(T)]
+    plan = native.FusionPlan(0, T, rigs[0].widths, rigs[0].heights)
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda()
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()
+    plan.radial_correct(rigs[0].intr, depth.data_ptr(), rgb.data_ptr(), int(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got_d, got_c = depth.cpu().numpy().view(np.uint8), rgb.cpu().numpy()
+    for k in range(T):
+        want_d, want_c = orc.radial_correction(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, rigs[0].intr)
+        assert np.array_equal(got_d[k], want_d), f"tick {k}: depth"
+        assert np.array_equal(got_c[k], want_c), f"tick {k}: colour"
+    _check(orc, synth.make_rig("noise", 1, 1024, 1024, seed=15), "1024x1024")
