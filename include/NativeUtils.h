@@ -206,7 +206,8 @@ int lsnIcpTrace(LsnIcp *icp, float *out16_per_iter, int max_iters, void *stream)
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct LsnTransfer LsnTransfer;
 
-/* Workspace for clouds of at most max_vertices vertices / max_triangles triangles. */
+/* Workspace for clouds of at most max_vertices vertices / max_triangles triangles.  Like LsnFusion and LsnIcp a handle
+ * serialises its own calls (internal mutex); independent handles run concurrently. */
 LsnTransfer *lsnTransferCreate(int device, int max_vertices, int max_triangles);
 void lsnTransferDestroy(LsnTransfer *t);
 

@@ -395,6 +395,7 @@ struct LsnTransfer {
     ChunkState *h_state = nullptr;      // pinned
     int max_chunks = 0;
     int last_chunks = 0, last_send = 0;
+    std::mutex mu;
     ~LsnTransfer() { if (h_state) (void)hipHostFree(h_state); }
 };
 
@@ -456,6 +457,7 @@ long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices
     }
     if ((n_vertices && !d_vertices) || (n_triangles && !d_triangles) || !d_out) { lsn::set_error("lsnTransferPack: null buffer"); return -1; }
     if (n_triangles > 0 && n_vertices == 0) { lsn::set_error("lsnTransferPack: triangles without vertices"); return -1; }
+    std::lock_guard<std::mutex> guard(t->mu);
     LSN_HIP(hipSetDevice(t->device));
     hipStream_t s = lsn::as_stream(stream);
     const uint4 *src_v = static_cast<const uint4 *>(d_vertices);
