@@ -487,6 +487,25 @@ def bench_icp(args, torch, native, synth, dev, stream, with_cpu):
     return out
 
 
+def host_description():
+    """CPU model, core count and how the CPU port was built (BASELINE.md asks for these beside every CPU figure)."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    flags = "unknown"
+    try:
+        mk = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "Makefile")).read()
+        flags = [l.split("=", 1)[1].strip() for l in mk.splitlines() if l.startswith("CFLAGS")][0]
+    except (OSError, IndexError):
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "compiler": "gcc " + flags}
+
+
 def cpu_baseline(args, synth, S, w, h, bounds):
     """The CPU oracle (port of createVertices/formMesh, one thread per sensor like the reference's std::thread fan-out)
     on the same tick shape, for about --cpu-seconds of wall time."""
@@ -508,7 +527,7 @@ def cpu_baseline(args, synth, S, w, h, bounds):
     dt1 = time.perf_counter() - t1
     return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{n} merge calls of {S} x {w}x{h} (same generator, tick 0) in {dt:.1f} s, {threads} threads (one per sensor), host has {cores} cores",
-            "single_thread_value": n1 / dt1}
+            "single_thread_value": n1 / dt1, "host": host_description()}
 
 
 if __name__ == "__main__":
