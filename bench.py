@@ -525,7 +525,17 @@ def cpu_baseline(args, synth, S, w, h, bounds):
         orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, n_threads=1)
         n1 += 1
     dt1 = time.perf_counter() - t1
-    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+    # BASELINE configs[0]: one 512x424 frame, unproject + transform + crop on one CPU thread
+    rig0 = synth.make_rig("noise", 1, 512, 424, seed=1, bounds=bounds)
+    v0, _ = orc.generate_mesh_vertices(rig0.depth_maps, rig0.depth_colors, rig0.widths, rig0.heights, rig0.intr, rig0.wt, rig0.bounds, n_threads=1)
+    n0, t2 = 0, time.perf_counter()
+    while time.perf_counter() - t2 < 1.0:
+        orc.generate_mesh_vertices(rig0.depth_maps, rig0.depth_colors, rig0.widths, rig0.heights, rig0.intr, rig0.wt, rig0.bounds, n_threads=1)
+        n0 += 1
+    ms0 = 1e3 * (time.perf_counter() - t2) / n0
+    config0 = {"workload": "configs[0]: 1 x 512x424, CPU port, 1 thread", "ms_per_frame": ms0, "frames_per_s": 1e3 / ms0,
+               "algorithmic_GBps": (2 * 512 * 424 + 19 * len(v0)) / (ms0 * 1e-3) / 1e9}
+    return {"config0": config0, "value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{n} merge calls of {S} x {w}x{h} (same generator, tick 0) in {dt:.1f} s, {threads} threads (one per sensor), host has {cores} cores",
             "single_thread_value": n1 / dt1, "host": host_description()}
 
