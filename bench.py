@@ -483,6 +483,15 @@ def bench_icp(args, torch, native, synth, dev, stream, with_cpu):
         out["cpu_iter_ms"] = 1e3 * (time.perf_counter() - t0) / 2
         out["cpu_cores"] = cores
         out["cpu_kind"] = "port (oracle kd-tree NN with OpenMP queries like icp.cpp:25-31, 2 iterations timed)"
+        if orc.have_ref_nn():
+            # the reference's OWN nearest-neighbour step (its vendored nanoflann 1.1.9 + PointCloud adaptor, compiled from the
+            # reference's headers into oracle/_ref): tree build + all queries = the dominant cost of a reference ICP iteration
+            t_np, s_np = tgt.cpu().numpy(), src0.cpu().numpy()
+            orc.ref_nn(t_np[:1000], s_np[:1000])
+            t0 = time.perf_counter()
+            orc.ref_nn(t_np, s_np)
+            out["cpu_reference_nn_ms"] = 1e3 * (time.perf_counter() - t0)
+            out["cpu_reference_nn_kind"] = "reference (kd-tree build + OpenMP queries of icp.cpp:18-32 on the same clouds, one iteration's worth)"
     ws.close()
     return out
 
