@@ -369,3 +369,52 @@ def test_exports_called_concurrently_like_the_two_background_workers(gpu, orc):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_soak_of_mixed_export_calls(gpu, orc):
+    """A few hundred export calls in random order with changing sensor counts, frame sizes, calibrations and crop boxes --
+    what a long LiveScanServer session does to the library's plan cache, pinned-buffer pool and per-calibration tables
+    (thresholds are built on the second call with an unchanged calibration, so repeats matter).  Every result against the oracle."""
+    rng = np.random.default_rng(99)
+    shapes = [(64, 48), (40, 56), (57, 31), (128, 96)]
+    rigs = []
+    for i in range(6):
+        n = int(rng.integers(1, 4))
+        w, h = shapes[int(rng.integers(len(shapes)))]
+        rigs.append(synth.make_rig("scene" if i % 2 else "noise", n, w, h, seed=50 + i, perturb=bool(i % 3 == 0),
+                                   bounds=[synth.CROP_BOUNDS, synth.DEFAULT_BOUNDS, [-0.6, -0.4, -0.9, 0.7, 0.5, 0.4]][i % 3]))
+    expect = {}
+    for step in range(240):
+        i = int(rng.integers(len(rigs)))
+        rig = rigs[i]
+        op = int(rng.integers(4))
+        if op == 0 or op == 3:
+            key = (i, "mesh")
+            if key not in expect:
+                v, _, t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+                expect[key] = (v.tobytes(), t)
+            verts, tris = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+            assert verts.tobytes() == expect[key][0] and np.array_equal(tris, expect[key][1]), f"step {step}: merge call, rig {i}"
+            if op == 3:
+                assert native.last_mesh_ply() == orc.ply_binary(verts, tris), f"step {step}: PLY of rig {i}"
+        elif op == 1:
+            s = int(rng.integers(rig.n))
+            key = (i, "one", s)
+            if key not in expect:
+                v, counts = orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+                e = np.concatenate([[0], np.cumsum(counts)])
+                expect[key] = v[e[s]:e[s + 1]].tobytes()
+            one = native.generate_vertices_from_depth_map(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, s)
+            assert one.tobytes() == expect[key], f"step {step}: single sensor {s} of rig {i}"
+        else:
+            key = (i, "radial")
+            if key not in expect:
+                expect[key] = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+            d, c = native.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+            assert np.array_equal(np.asarray(d).view(np.uint8).ravel(), np.asarray(expect[key][0]).view(np.uint8).ravel()), f"step {step}: radial depth, rig {i}"
+            assert np.array_equal(np.asarray(c).ravel(), np.asarray(expect[key][1]).ravel()), f"step {step}: radial colour, rig {i}"
+        if step % 40 == 39:                                         # a recalibration of one rig in the middle of the session
+            j = int(rng.integers(len(rigs)))
+            rigs[j].wt = (rigs[j].wt + rng.normal(scale=0.01, size=rigs[j].wt.shape)).astype(np.float32)
+            for k in [k for k in expect if k[0] == j and k[1] != "radial"]:
+                del expect[k]
