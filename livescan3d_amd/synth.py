@@ -149,8 +149,8 @@ def scene_frame(seed, tick, sensor, n_sensors, w=512, h=424, radius=2.0):
     # floor y = -0.6 within radius 2.5
     with np.errstate(divide="ignore", invalid="ignore"):
         tf = (-0.6 - o[1]) / d[..., 1]
-    pf = o + tf[..., None] * d
-    tf = np.where((tf > 0) & (pf[..., 0] ** 2 + pf[..., 2] ** 2 <= 2.5 ** 2), tf, np.inf)
+        pf = o + tf[..., None] * d                                              # inf * 0 for rays parallel to the floor
+        tf = np.where((tf > 0) & (pf[..., 0] ** 2 + pf[..., 2] ** 2 <= 2.5 ** 2), tf, np.inf)
     # box
     tb = _ray_box(o, d, np.array([0.25, -0.6, -0.55]), np.array([0.65, 0.15, -0.15]))
     tb2 = _ray_box(o, d, np.array([-0.8, -0.6, 0.3]), np.array([-0.5, 0.4, 0.5]))
