@@ -365,6 +365,10 @@ def main():
     if rank == 0 and not args.no_icp:
         result["icp"] = bench_icp(args, torch, native, synth, dev, stream, with_cpu=(world == 1 and not args.no_cpu))
 
+    # ---- the whole pose-refinement pass (H2 / f-3): N sensors x 2 refine passes x 10 ICP iterations in one call ---------
+    if rank == 0 and not multi and not args.no_icp:
+        result["refine"] = bench_refine(args, native, synth, S, w, h, with_cpu=not args.no_cpu)
+
     # ---- CPU baseline (rank 0, N = 1 only) ------------------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args, synth, S, w, h, bounds)
@@ -493,6 +497,36 @@ def bench_icp(args, torch, native, synth, dev, stream, with_cpu):
             out["cpu_reference_nn_ms"] = 1e3 * (time.perf_counter() - t0)
             out["cpu_reference_nn_kind"] = "reference (kd-tree build + OpenMP queries of icp.cpp:18-32 on the same clouds, one iteration's worth)"
     ws.close()
+    return out
+
+
+def bench_refine(args, native, synth, S, w, h, with_cpu):
+    """refineWorker_DoWork (LiveScanServer/MainWindowForm.cs:330-410) as one native call: host clouds in, host clouds out,
+    everything in between resident in HBM.  Clouds = the S sensors' cropped clouds of one scene tick (CPU-made here)."""
+    from oracle import orc
+    rig = synth.make_rig("scene", S, w, h, seed=4, perturb=True)
+    v, counts = orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds,
+                                           n_threads=min(S, os.cpu_count() or 1))
+    e = np.concatenate([[0], np.cumsum(counts)])
+    xyz = np.stack([v["X"], v["Y"], v["Z"]], axis=1).astype(np.float32)
+    clouds = [np.ascontiguousarray(xyz[e[i]:e[i + 1]]) for i in range(S)]
+    wR = np.stack([rig.wt[12 * i + 3:12 * i + 12].reshape(3, 3) for i in range(S)])
+    wt = np.stack([rig.wt[12 * i:12 * i + 3] for i in range(S)])
+    refine_iters, icp_iters = 2, 10                                  # KinectSettings.cs:45-46
+    native.refine(clouds, wR, wt, 1, 1)                              # warm-up (workspace allocation)
+    t0 = time.perf_counter()
+    native.refine(clouds, wR, wt, refine_iters, icp_iters)
+    dt = time.perf_counter() - t0
+    n_icp = S * refine_iters * icp_iters
+    out = {"workload": f"{S} sensors x {w}x{h} scene clouds ({int(e[-1])} points), {refine_iters} refine passes x {icp_iters} ICP iterations, host clouds in/out",
+           "total_ms": 1e3 * dt, "ms_per_icp_iteration": 1e3 * dt / n_icp}
+    if with_cpu:
+        t0 = time.perf_counter()
+        orc.refine(clouds, wR, wt, n_refine_iters=1, n_icp_iters=1, nn_mode="kdtree",
+                   n_threads=os.cpu_count() or 1)
+        dtc = time.perf_counter() - t0
+        out["cpu_port_ms_per_icp_iteration"] = 1e3 * dtc / S
+        out["cpu_sample"] = f"one refine pass with one ICP iteration per sensor ({S} ICP iterations) on {os.cpu_count()} threads"
     return out
 
 
