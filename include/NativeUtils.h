@@ -165,6 +165,23 @@ int lsnFusionKernelStats(LsnFusion *plan, double *avg_ms, long long *launches, c
 int lsnMergeShards(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap,
                    const int *d_shard_offsets, void *d_merged, long long merged_cap, int *d_merged_offsets, void *stream);
 
+/* Survivor exchange for the multi-GPU path: a vertex is 16 bytes, what it is computed from is 5 (u16 depth + RGB8) plus
+ * one bit per pixel.  lsnFusionPackSurvivors fuses like lsnFusionRun but writes, per tick, the survivors' depth and colour
+ * as compact streams in vertex order (d_depth_c [n_ticks][capacity] u16, d_rgb_c [n_ticks][capacity][3]), the survivor
+ * mask (d_mask [n_ticks][capacity/8], bit p&7 of byte p>>3 = pixel p of the tick), the tiles' exclusive prefixes
+ * (d_tile_prefix [n_ticks][lsnFusionTilesPerTick()]) and the usual offsets table.  After an all-gather of these arrays
+ * lsnFusionReconstruct, called on a plan that covers the WHOLE rig (all sensors' parameters set, same n_ticks), rebuilds
+ * every shard's vertices with the same arithmetic -- bit-identical to fusing all sensors in one plan -- directly into the
+ * merged cloud d_merged [n_ticks][lsnFusionTickCapacity(all)] and fills d_merged_offsets [n_ticks][n_maps+1].  The
+ * gathered arrays are [n_shards][n_ticks][...] with the per-tick vertex capacity of the streams cut to `slab`.
+ * Needs identically sized sensors whose width is a multiple of 8; otherwise exchange vertices (lsnMergeShards). */
+int lsnFusionTilesPerTick(const LsnFusion *plan);
+int lsnFusionPackSurvivors(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_colors, void *d_mask, void *d_depth_c,
+                           void *d_rgb_c, int *d_tile_prefix, int *d_offsets, void *stream);
+int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
+                         const void *d_rgb_c, long long slab, const int *d_tile_prefix, const int *d_shard_offsets, void *d_merged,
+                         int *d_merged_offsets, void *stream);
+
 /* 1 when the last look-back launch (mode 1) gave up on a bounded spin (outputs invalid), else 0; synchronises. */
 int lsnFusionLookbackFailed(LsnFusion *plan, void *stream);
 

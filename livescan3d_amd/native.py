@@ -24,6 +24,7 @@ EXPORTS = [
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionThresholds", "lsnMergeShards",
+    "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
@@ -116,6 +117,12 @@ def lib():
     L.lsnFusionKernelStats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_char_p, C.c_int, C.c_int]
     L.lsnFusionThresholds.restype = C.c_int
     L.lsnFusionThresholds.argtypes = [vp, vp, C.POINTER(C.c_float), vp]
+    L.lsnFusionTilesPerTick.restype = C.c_int
+    L.lsnFusionTilesPerTick.argtypes = [vp]
+    L.lsnFusionPackSurvivors.restype = C.c_int
+    L.lsnFusionPackSurvivors.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.lsnFusionReconstruct.restype = C.c_int
+    L.lsnFusionReconstruct.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_longlong, vp, vp, vp, vp, vp]
     L.lsnFusionLookbackFailed.restype = C.c_int
     L.lsnFusionLookbackFailed.argtypes = [vp, vp]
     L.lsnMergeShards.restype = C.c_int
@@ -355,6 +362,20 @@ class FusionPlan:
         if rc < 0:
             raise NativeUtilsError(f"lsnFusionThresholds failed: {last_error()}")
         return (None if rc == 1 else out), ms.value
+
+    @property
+    def tiles_per_tick(self):
+        return int(lib().lsnFusionTilesPerTick(self._h))
+
+    def pack_survivors(self, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, stream=0):
+        _check(lib().lsnFusionPackSurvivors(self._h, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, stream or None),
+               "lsnFusionPackSurvivors")
+
+    def reconstruct(self, n_shards, maps_per_shard, d_masks, d_depth_c, d_rgb_c, slab, d_tile_prefix, d_shard_offsets, d_merged, d_merged_offsets,
+                    stream=0):
+        """Called on the whole-rig plan: rebuilds all shards' vertices from the gathered survivor streams."""
+        _check(lib().lsnFusionReconstruct(self._h, int(n_shards), int(maps_per_shard), d_masks, d_depth_c, d_rgb_c, int(slab), d_tile_prefix,
+                                          d_shard_offsets, d_merged, d_merged_offsets, stream or None), "lsnFusionReconstruct")
 
     def lookback_failed(self, stream=0):
         return int(lib().lsnFusionLookbackFailed(self._h, stream))

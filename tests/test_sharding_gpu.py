@@ -64,3 +64,61 @@ def test_rccl_exchange_world1(gpu, tmp_path, compact):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(_free_port(), compact, out), nprocs=1, join=True)
     assert open(out).read() == "ok"
+
+
+@pytest.mark.parametrize("S,G,w,h", [(4, 2, 512, 424), (8, 8, 64, 48), (6, 3, 128, 96)])
+def test_survivor_exchange_kernels_on_one_gpu(gpu, S, G, w, h):
+    """The survivor exchange with the all-gather played by hand: every shard packs its sensors (compact depth / colour
+    streams + survivor mask), the arrays are laid out like an all-gather result, and the whole-rig plan reconstructs
+    the merged cloud -- which must equal fusing all sensors in one plan (and therefore the oracle) bit for bit."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    from livescan3d_amd import synth
+    from livescan3d_amd.fusion import DeviceFusion
+    from oracle import orc
+    T, mpr, P = 3, S // G, w * h
+    rigs = [synth.make_rig("noise" if k % 2 else "scene", S, w, h, seed=23, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+    intr, wt, bounds = rigs[0].intr, rigs[0].wt, rigs[0].bounds
+    depth_all = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda()          # [T, S*P]
+    rgb_all = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()                          # [T, S*P*3]
+    st = int(torch.cuda.current_stream().cuda_stream)
+    whole = DeviceFusion(T, [w] * S, [h] * S)
+    whole.set_params(intr, wt, bounds)
+    cap_loc = mpr * P
+    tiles_loc = None
+    masks, dcs, ccs, tps, offs = [], [], [], [], []
+    for r in range(G):
+        s0, s1 = r * mpr, (r + 1) * mpr
+        local = DeviceFusion(T, [w] * mpr, [h] * mpr)
+        local.set_params(intr[7 * s0:7 * s1], wt[12 * s0:12 * s1], bounds)
+        d = depth_all[:, s0 * P:s1 * P].contiguous()
+        c = rgb_all[:, 3 * s0 * P:3 * s1 * P].contiguous()
+        tiles_loc = local.plan.tiles_per_tick
+        mask = torch.zeros((T, cap_loc // 8), dtype=torch.uint8, device="cuda")
+        dc = torch.zeros((T, cap_loc), dtype=torch.int16, device="cuda")
+        cc = torch.zeros((T, cap_loc, 3), dtype=torch.uint8, device="cuda")
+        tp = torch.zeros((T, tiles_loc), dtype=torch.int32, device="cuda")
+        off = torch.zeros((T, mpr + 1), dtype=torch.int32, device="cuda")
+        for _ in range(2 if r == 0 else 1):                      # shard 0 twice: the second pack counts from the depth thresholds
+            local.plan.pack_survivors(d.data_ptr(), c.data_ptr(), mask.data_ptr(), dc.data_ptr(), cc.data_ptr(), tp.data_ptr(), off.data_ptr(), st)
+        masks.append(mask); dcs.append(dc); ccs.append(cc); tps.append(tp); offs.append(off)
+    torch.cuda.synchronize()
+    g_off = torch.stack(offs)                                     # [G, T, mpr+1]
+    m = int(g_off[:, :, mpr].max().item())
+    assert 0 < m < cap_loc
+    g_mask, g_tp = torch.stack(masks), torch.stack(tps)
+    g_dc = torch.stack([x[:, :m] for x in dcs]).contiguous()     # [G, T, m]
+    g_cc = torch.stack([x[:, :m] for x in ccs]).contiguous()     # [G, T, m, 3]
+    merged = torch.zeros((T, whole.capacity, 16), dtype=torch.uint8, device="cuda")
+    moff = torch.zeros((T, S + 1), dtype=torch.int32, device="cuda")
+    whole.plan.reconstruct(G, mpr, g_mask.data_ptr(), g_dc.data_ptr(), g_cc.data_ptr(), m, g_tp.data_ptr(), g_off.data_ptr(),
+                           merged.data_ptr(), moff.data_ptr(), st)
+    want_v, want_o = whole.run(depth_all, rgb_all)
+    torch.cuda.synchronize()
+    assert torch.equal(moff, want_o)
+    for k in range(T):
+        n = int(want_o[k, -1])
+        assert n > 0 and torch.equal(merged[k, :n], want_v[k, :n]), f"tick {k}"
+        ov, _ = orc.generate_mesh_vertices(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, intr, wt, bounds)
+        assert merged[k, :n].cpu().numpy().tobytes() == ov.tobytes(), f"tick {k} vs oracle"
