@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--exchange", choices=["survivors", "vertices"], default="survivors",
+                    help="N > 1: what the all-gathers carry (survivors: 5 B + 1 bit per pixel, rebuilt on every GPU; vertices: 16 B)")
     ap.add_argument("--no-mesh", action="store_true")
     ap.add_argument("--core-only", action="store_true", help="only the timed region behind `value` (for rocprofv3 summaries): no extra legs")
     ap.add_argument("--padded-exchange", action="store_true", help="N > 1: all-gather full-capacity slabs (no host sync)")
@@ -110,16 +112,28 @@ def main():
     fus.set_params(intr_all[7 * s0:7 * (s0 + S_loc)], wt_all[12 * s0:12 * (s0 + S_loc)], bounds)
     stream = int(torch.cuda.current_stream().cuda_stream)
 
-    xch = None
+    # N > 1: one exchange step per step forms the merged cloud on every GPU (sensor order = rank order).  Default: the
+    # all-gathers carry the survivors' inputs (5 B + a 1-bit/pixel mask) and every GPU rebuilds all vertices with the same
+    # arithmetic; --exchange vertices (and rigs whose widths are not multiples of 8) all-gather the 16-byte vertices.
+    xch = sx = whole = None
+    use_sx = multi and args.exchange == "survivors" and w % 8 == 0 and args.mode == 0
     if multi:
-        xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
+        from livescan3d_amd.sharding import SurvivorExchange
+        if use_sx:
+            whole = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
+            whole.set_params(intr_all, wt_all, bounds)
+            sx = SurvivorExchange(world, fus, whole, via_host=share)
+        else:
+            xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
+    prof_plan = whole.plan if use_sx else fus.plan
 
     def step():
-        fus.run(depth, rgb)
-        if xch is not None:
-            # the exchange step: all-gather of the per-GPU sensor shards over xGMI + local packing into one
-            # contiguous cloud per tick, so that every GPU holds the merged cloud (sensor order = rank order)
-            xch.exchange(fus.vertices, fus.offsets)
+        if use_sx:
+            sx.exchange(depth, rgb, stream)
+        else:
+            fus.run(depth, rgb)
+            if xch is not None:
+                xch.exchange(fus.vertices, fus.offsets)
 
     def sync():
         if multi:
@@ -129,8 +143,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    fus.plan.profile(True)
-    fus.plan.kernel_stats(reset=True)
+    prof_plan.profile(True)
+    prof_plan.kernel_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -140,18 +154,20 @@ def main():
     if multi:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
-    kstats = fus.plan.kernel_stats(reset=True)
-    fus.plan.profile(False)
+    kstats = prof_plan.kernel_stats(reset=True)
+    prof_plan.profile(False)
     thr_table, thr_build_ms = fus.plan.thresholds(copy=False)   # already built by the second warm-up run; reports its build time
 
-    # algorithmic bytes of one launch of the dominant kernel on this rank: sum over its sensor-frames of 2P + 19V
-    off = fus.offsets.cpu().numpy().astype(np.int64)
+    # algorithmic bytes of one launch of the dominant kernel on this rank
+    off = (sx.offsets if use_sx else fus.offsets).cpu().numpy().astype(np.int64)
     V_local = int(off[:, -1].sum())
-    alg_bytes = 2 * P * S_loc * B + 19 * V_local
-    if multi:
-        V_total = int(xch.merged_off[:, -1].sum().item())
+    if use_sx:
+        # recon_kernel rebuilds the WHOLE merged cloud on every GPU: 5 B read + 16 B written per vertex, 1 bit per pixel of mask
+        V_total = int(sx.merged_off[:, -1].sum().item())
+        alg_bytes = 21 * V_total + (B * S * P) // 8
     else:
-        V_total = V_local
+        alg_bytes = 2 * P * S_loc * B + 19 * V_local            # fuse_kernel<1>: sum over its sensor-frames of 2P + 19V
+        V_total = int(xch.merged_off[:, -1].sum().item()) if multi else V_local
     if args.mode == 1 and fus.plan.lookback_failed(stream):
         raise SystemExit("look-back compaction gave up on a bounded spin: results invalid")
 
@@ -182,7 +198,7 @@ def main():
                 "count_pass": ("arithmetic (LSN_NO_THRESHOLDS=1)" if os.environ.get("LSN_NO_THRESHOLDS", "0") not in ("", "0")
                                else "per-pixel depth thresholds"),
                 "threshold_build_ms_once_per_calibration": thr_build_ms,
-                "parallelism": f"sensor-shard{world}" + ("+allgather" if multi else ""),
+                "parallelism": f"sensor-shard{world}" + (("+allgather(survivors)" if use_sx else "+allgather(vertices)") if multi else ""),
                 "bounds": [float(x) for x in bounds],
             },
             "roofline": {
@@ -192,7 +208,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args, S_loc, B, w, h),
+                "traffic": None if use_sx else pmc_traffic(args, S_loc, B, w, h),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_avg_ms": kstats["avg_ms"],
                 "kernel_launches": kstats["launches"],
@@ -265,6 +281,34 @@ def main():
                               "note": "lsnFusionRunStreamed: one kernel writes batch k (HBM-bound) and counts the resident batch k+1 "
                                       "(VALU-bound); same work per step as the default path, no separate count launch"}
         del d2
+
+    # ---- N > 1, extra leg: the exchange step carrying 16-byte vertices (what the survivor exchange is compared with) ------
+    if use_sx and not args.no_tick_parallel:
+        vx = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
+
+        def vstep():
+            fus.run(depth, rgb)
+            vx.exchange(fus.vertices, fus.offsets)
+        for _ in range(max(1, args.warmup)):
+            vstep()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            vstep()
+        sync()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(sx.merged_off, vx.merged_off))
+        for k in (0, B - 1):
+            n_chk = int(sx.merged_off[k, -1].item())
+            same = same and bool(torch.equal(sx.merged[k, :n_chk], vx.merged[k, :n_chk]))
+        if rank == 0:
+            result["vertex_exchange"] = {
+                "value": B * args.steps / float(el.item()), "unit": "frames/s", "scaling": "strong", "ms_per_step": 1e3 * float(el.item()) / args.steps,
+                "merged_cloud_identical_to_survivor_exchange": same, "slab_vertices": vx.last_slab,
+                "note": "the same step with all-gathers of the 16-byte vertices + lsnMergeShards (bench.py --exchange vertices makes it `value`)"}
+            result["config"]["exchange_slab_survivors"] = sx.last_slab
+        del vx
 
     # ---- N > 1, extra leg: the same ticks spread over the GPUs instead of the sensors (no exchange step at all) ------
     if multi and not args.no_tick_parallel:

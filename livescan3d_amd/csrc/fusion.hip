@@ -1678,6 +1678,7 @@ struct LsnFusion {
     size_t ev_used = 0;
     double acc_ms = 0;
     long long launches = 0;
+    const char *timed_kernel = nullptr;  // which kernel the event pairs bracket (set by the entry point that records them)
     std::mutex mu;
 };
 
@@ -1900,7 +1901,8 @@ extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *lau
     if (drain_events(p)) return -1;
     if (avg_ms) *avg_ms = p->launches ? p->acc_ms / (double)p->launches : 0.0;
     if (launches) *launches = p->launches;
-    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", p->mode == 0 ? "fuse_kernel<1>" : "run_kernel");
+    if (name && name_len > 0)
+        snprintf(name, (size_t)name_len, "%s", p->timed_kernel ? p->timed_kernel : (p->mode == 0 ? "fuse_kernel<1>" : "run_kernel"));
     if (reset) {
         p->acc_ms = 0;
         p->launches = 0;
@@ -2410,7 +2412,14 @@ extern "C" int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_s
     r.tiles_loc = all->tiles_per_tick / n_shards;
     r.n_shards = n_shards;
     r.maps_per_shard = maps_per_shard;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (all->profile) {
+        if (next_event_pair(all, e0, e1)) return -1;
+        all->timed_kernel = "recon_kernel";
+        LSN_HIP(hipEventRecord(e0, lsn::as_stream(stream)));
+    }
     hipLaunchKernelGGL(recon_kernel, dim3((unsigned)(all->tiles_per_tick * all->n_ticks)), dim3(kThreads), 0, lsn::as_stream(stream), a, r);
+    if (e1) LSN_HIP(hipEventRecord(e1, lsn::as_stream(stream)));
     LSN_HIP(hipGetLastError());
     return 0;
 }

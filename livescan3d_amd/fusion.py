@@ -29,6 +29,10 @@ class DeviceFusion:
         self.vertices = torch.empty((n_ticks, self.capacity, 16), dtype=torch.uint8, device=self.device)
         self.offsets = torch.zeros((n_ticks, self.n_maps + 1), dtype=torch.int32, device=self.device)
 
+    @property
+    def tiles_per_tick(self):
+        return self.plan.tiles_per_tick
+
     def set_params(self, intr, wt, bounds):
         self.plan.set_params(intr, wt, bounds, _stream_handle())
 

@@ -79,3 +79,75 @@ class MergedCloudExchange:
             native.merge_shards(self.device.index, W, T, self.mpr, g.data_ptr(), m, self.g_off.data_ptr(), self.merged.data_ptr(),
                                 self.shard_cap * W, self.merged_off.data_ptr(), int(torch.cuda.current_stream().cuda_stream))
         return self.merged, self.merged_off
+
+
+class SurvivorExchange:
+    """The same exchange step with three times fewer bytes on xGMI: a vertex is 16 bytes, what it is computed from is 5
+    (u16 depth + RGB8) plus one bit per pixel.  Rank r packs its sensors' survivors as compact depth / colour streams in
+    vertex order (lsnFusionPackSurvivors), five all-gathers move the offset tables, the tile prefixes, the survivor masks
+    and the two streams (cut to the largest shard of the step), and every rank rebuilds ALL sensors' vertices with the
+    same arithmetic straight into the merged cloud (lsnFusionReconstruct on a plan over the whole rig) -- bit-identical
+    to fusing every sensor on one GPU.  Needs identically sized sensors whose width is a multiple of 8.
+
+    local: the rank's DeviceFusion (its block of sensors); whole: a DeviceFusion over all sensors with all parameters set.
+    pack_fn / recon_fn replace the two HIP entry points in CPU tests (gloo); via_host as in MergedCloudExchange."""
+
+    def __init__(self, world, local, whole, group=None, via_host=False, pack_fn=None, recon_fn=None):
+        self.world, self.local, self.whole, self.group, self.via_host = world, local, whole, group, via_host
+        self.pack_fn, self.recon_fn = pack_fn, recon_fn
+        self.T, self.mpr = local.n_ticks, local.n_maps
+        self.cap_loc, self.tiles_loc = int(local.capacity), int(local.tiles_per_tick)
+        dev = torch.device(local.device)
+        T, W = self.T, world
+        self.mask = torch.zeros((T, self.cap_loc // 8), dtype=torch.uint8, device=dev)
+        self.depth_c = torch.zeros((T, self.cap_loc), dtype=torch.int16, device=dev)
+        self.rgb_c = torch.zeros((T, self.cap_loc, 3), dtype=torch.uint8, device=dev)
+        self.tile_prefix = torch.zeros((T, self.tiles_loc), dtype=torch.int32, device=dev)
+        self.offsets = torch.zeros((T, self.mpr + 1), dtype=torch.int32, device=dev)
+        self.g_off = torch.empty((W, T, self.mpr + 1), dtype=torch.int32, device=dev)
+        self.g_tp = torch.empty((W, T, self.tiles_loc), dtype=torch.int32, device=dev)
+        self.g_mask = torch.empty((W, T, self.cap_loc // 8), dtype=torch.uint8, device=dev)
+        self.g_dc = torch.empty((W * T * self.cap_loc,), dtype=torch.int16, device=dev)
+        self.g_cc = torch.empty((W * T * self.cap_loc * 3,), dtype=torch.uint8, device=dev)
+        self.stage_d = torch.empty((T * self.cap_loc,), dtype=torch.int16, device=dev)
+        self.stage_c = torch.empty((T * self.cap_loc * 3,), dtype=torch.uint8, device=dev)
+        self.merged = torch.empty((T, int(whole.capacity), 16), dtype=torch.uint8, device=dev)
+        self.merged_off = torch.zeros((T, W * self.mpr + 1), dtype=torch.int32, device=dev)
+        self.last_slab = self.cap_loc
+
+    def _all_gather(self, out, inp):
+        if self.via_host:
+            o = out.cpu()
+            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def exchange(self, depth, rgb, stream=0):
+        """depth [T, mpr*P] u16, rgb [T, mpr*P*3] u8 (the rank's resident inputs).  Returns (merged, merged_offsets)."""
+        T, W = self.T, self.world
+        if self.pack_fn is not None:
+            self.pack_fn(depth, rgb, self.mask, self.depth_c, self.rgb_c, self.tile_prefix, self.offsets)
+        else:
+            self.local.plan.pack_survivors(depth.data_ptr(), rgb.data_ptr(), self.mask.data_ptr(), self.depth_c.data_ptr(), self.rgb_c.data_ptr(),
+                                           self.tile_prefix.data_ptr(), self.offsets.data_ptr(), stream)
+        self._all_gather(self.g_off.view(W * T, self.mpr + 1), self.offsets)
+        m = max(1, int(self.g_off[:, :, self.mpr].max().item()))          # largest shard of any rank / tick
+        self.last_slab = m
+        self._all_gather(self.g_tp.view(W * T, self.tiles_loc), self.tile_prefix)
+        self._all_gather(self.g_mask.view(W * T, self.cap_loc // 8), self.mask)
+        sd = self.stage_d[: T * m].view(T, m)
+        sd.copy_(self.depth_c[:, :m])
+        sc = self.stage_c[: T * m * 3].view(T, m, 3)
+        sc.copy_(self.rgb_c[:, :m])
+        gd = self.g_dc[: W * T * m].view(W * T, m)
+        gc = self.g_cc[: W * T * m * 3].view(W * T, m, 3)
+        # collectives move bytes: neither RCCL nor gloo all-gathers 16-bit integers
+        self._all_gather(gd.view(torch.uint8), sd.view(torch.uint8))
+        self._all_gather(gc, sc)
+        if self.recon_fn is not None:
+            self.recon_fn(self.g_mask, gd.view(W, T, m), gc.view(W, T, m, 3), self.g_tp, self.g_off, self.merged, self.merged_off)
+        else:
+            self.whole.plan.reconstruct(W, self.mpr, self.g_mask.data_ptr(), gd.data_ptr(), gc.data_ptr(), m, self.g_tp.data_ptr(),
+                                        self.g_off.data_ptr(), self.merged.data_ptr(), self.merged_off.data_ptr(), stream)
+        return self.merged, self.merged_off

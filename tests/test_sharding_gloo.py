@@ -92,3 +92,97 @@ def test_sensor_blocks():
     assert sensor_block(8, 1, 0) == (0, 8) and sensor_block(8, 8, 7) == (7, 8)
     with pytest.raises(ValueError):
         sensor_block(8, 3, 0)
+
+
+# ---- the survivor exchange (5 bytes per survivor + a mask instead of 16-byte vertices) on two gloo ranks -----------------
+
+KTILE = 2048      # pixels per tile in the library (only the packed tile prefixes depend on it)
+
+
+def _survivor_worker(rank, world, port, S, T, w, h, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from livescan3d_amd import synth
+    from livescan3d_amd.sharding import SurvivorExchange, sensor_block
+    from oracle import orc
+    s0, s1 = sensor_block(S, world, rank)
+    mpr, P = s1 - s0, w * h
+    tiles_per_frame = (P + KTILE - 1) // KTILE
+    rigs = [synth.make_rig("scene" if k % 2 == 0 else "noise", S, w, h, seed=13, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+    intr, wt, bounds = rigs[0].intr, rigs[0].wt, rigs[0].bounds
+
+    def pack_fn(depth, rgb, mask, depth_c, rgb_c, tile_prefix, offsets):
+        """Contract of lsnFusionPackSurvivors, restated with the oracle."""
+        for k in range(T):
+            bits = np.zeros(mpr * P, dtype=bool)
+            base, tile_counts, offs = 0, [], [0]
+            for j in range(mpr):
+                d = depth[k, j * P:(j + 1) * P].numpy().view(np.uint16).reshape(h, w)
+                c = rgb[k, 3 * j * P:3 * (j + 1) * P].numpy().reshape(h, w, 3)
+                s = s0 + j
+                v, v2p, p2v = orc.create_vertices(d, c, intr[7 * s:7 * s + 7], wt[12 * s:12 * s + 12], bounds, want_maps=True)
+                n = len(v)
+                depth_c[k, base:base + n] = torch.from_numpy(d.ravel()[v2p].view(np.int16).copy())
+                rgb_c[k, base:base + n] = torch.from_numpy(c.reshape(-1, 3)[v2p].copy())
+                bits[j * P:(j + 1) * P] = p2v >= 0
+                keep = (p2v >= 0).astype(np.int64)
+                tile_counts += [int(keep[t * KTILE:(t + 1) * KTILE].sum()) for t in range(tiles_per_frame)]
+                base += n
+                offs.append(base)
+            mask[k] = torch.from_numpy(np.packbits(bits, bitorder="little"))
+            tile_prefix[k] = torch.from_numpy(np.concatenate([[0], np.cumsum(tile_counts)[:-1]]).astype(np.int32))
+            offsets[k] = torch.tensor(offs, dtype=torch.int32)
+
+    def recon_fn(g_mask, gd, gc, g_tp, g_off, merged, merged_off):
+        """Contract of lsnFusionReconstruct: expand every shard's streams back into frames and apply the reference arithmetic."""
+        W = g_mask.shape[0]
+        for k in range(T):
+            pos, moff = 0, [0]
+            for r in range(W):
+                bits = np.unpackbits(g_mask[r, k].numpy(), bitorder="little")[:mpr * P].astype(bool)
+                go = g_off[r, k].numpy()
+                for j in range(mpr):
+                    sel = bits[j * P:(j + 1) * P]
+                    n = int(go[j + 1] - go[j])
+                    assert int(sel.sum()) == n
+                    d = np.zeros(P, dtype=np.uint16)
+                    c = np.zeros((P, 3), dtype=np.uint8)
+                    d[sel] = gd[r, k, go[j]:go[j + 1]].numpy().view(np.uint16)
+                    c[sel] = gc[r, k, go[j]:go[j + 1]].numpy()
+                    s = r * mpr + j
+                    v, _, _ = orc.create_vertices(d.reshape(h, w), c.reshape(h, w, 3), intr[7 * s:7 * s + 7], wt[12 * s:12 * s + 12], bounds, want_maps=True)
+                    assert len(v) == n
+                    merged[k, pos:pos + n] = torch.from_numpy(v.view(np.uint8).reshape(-1, 16).copy())
+                    pos += n
+                    moff.append(pos)
+            merged_off[k] = torch.tensor(moff, dtype=torch.int32)
+
+    local = SimpleNamespace(n_ticks=T, n_maps=mpr, capacity=mpr * P, tiles_per_tick=mpr * tiles_per_frame, device="cpu", plan=None)
+    whole = SimpleNamespace(capacity=S * P, plan=None)
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16)[s0 * P:s1 * P] for r in rigs]))
+    rgb = torch.from_numpy(np.stack([r.depth_colors[3 * s0 * P:3 * s1 * P] for r in rigs]))
+    xch = SurvivorExchange(world, local, whole, pack_fn=pack_fn, recon_fn=recon_fn)
+    merged, merged_off = xch.exchange(depth, rgb)
+    assert xch.last_slab < mpr * P
+    np.save(os.path.join(out_dir, f"merged_{rank}.npy"), merged.numpy())
+    np.save(os.path.join(out_dir, f"off_{rank}.npy"), merged_off.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_survivor_exchange_equals_single_process_merge(tmp_path, orc):
+    from livescan3d_amd import synth
+    world, S, T, w, h = 2, 4, 2, 64, 48
+    mp.spawn(_survivor_worker, args=(world, _free_port(), S, T, w, h, str(tmp_path)), nprocs=world, join=True)
+    m0, m1 = np.load(tmp_path / "merged_0.npy"), np.load(tmp_path / "merged_1.npy")
+    o0, o1 = np.load(tmp_path / "off_0.npy"), np.load(tmp_path / "off_1.npy")
+    assert np.array_equal(o0, o1)
+    for k in range(T):
+        rig = synth.make_rig("scene" if k % 2 == 0 else "noise", S, w, h, seed=13, tick=k, bounds=synth.CROP_BOUNDS)
+        want, counts = orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        n = int(o0[k, -1])
+        assert n == len(want) and list(np.diff(o0[k])) == list(counts)
+        for m in (m0, m1):
+            assert m[k, :n].tobytes() == want.tobytes()

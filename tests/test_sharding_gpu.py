@@ -122,3 +122,49 @@ def test_survivor_exchange_kernels_on_one_gpu(gpu, S, G, w, h):
         assert n > 0 and torch.equal(merged[k, :n], want_v[k, :n]), f"tick {k}"
         ov, _ = orc.generate_mesh_vertices(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, intr, wt, bounds)
         assert merged[k, :n].cpu().numpy().tobytes() == ov.tobytes(), f"tick {k} vs oracle"
+
+
+def _survivor_worker(rank, port, out):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from livescan3d_amd import synth
+    from livescan3d_amd.fusion import DeviceFusion
+    from livescan3d_amd.sharding import SurvivorExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    T, S, w, h = 4, 2, 512, 424
+    P = w * h
+    depth, rgb = synth.noise_frames_torch(dev, 1, T, S, w, h)
+    depth, rgb = depth.view(T, S * P), rgb.view(T, S * P * 3)
+    intr = np.concatenate([synth.kinect_intrinsics(w, h)] * S)
+    wt = np.concatenate([synth.pack_pose(*synth.ring_pose(s, S)) for s in range(S)])
+    local = DeviceFusion(T, [w] * S, [h] * S, device=0)
+    local.set_params(intr, wt, synth.CROP_BOUNDS)
+    whole = DeviceFusion(T, [w] * S, [h] * S, device=0)
+    whole.set_params(intr, wt, synth.CROP_BOUNDS)
+    xch = SurvivorExchange(1, local, whole)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    merged, merged_off = xch.exchange(depth, rgb, st)
+    want_v, want_o = whole.run(depth, rgb)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(merged_off, want_o)) and xch.last_slab < local.capacity
+    for k in range(T):
+        n = int(want_o[k, -1])
+        ok = ok and n > 0 and bool(torch.equal(merged[k, :n], want_v[k, :n]))
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(out, "w") as f:
+        f.write("ok" if ok else "mismatch")
+
+
+def test_rccl_survivor_exchange_world1(gpu, tmp_path):
+    """The survivor exchange through RCCL (one rank): the five all-gathers on device tensors (uint8 / int32 only --
+    collectives do not move 16-bit integers) + pack and reconstruct kernels; the result must equal a plain fusion."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_survivor_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert open(out).read() == "ok"
