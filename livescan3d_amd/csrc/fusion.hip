@@ -882,47 +882,65 @@ __device__ __forceinline__ unsigned int pixel_triangles(const int (&W)[4][4], in
 // undirected edge has ONE metric = their minimum and passes for a triangle iff metric < that triangle's threshold.  The four
 // candidate triangles of a pixel share 5 edges (and the vertical one with the next pixel): 5 metrics per pixel instead
 // of 12 edge walks, no branches.  D: depth rows y-2 .. y+1, columns x0-1 .. x0+9; M: vertex indices of rows y-1, y.
-__device__ __forceinline__ int edge_metric(int vA, int vB, int beyondB, int beyondA)
+__device__ __forceinline__ int tri_threshold(int s) { return (272 * s + 2181900) / 300000; }   // :26, in integers
+
+// edge_metric with the probes pre-biased: Z = depth + 2^17 for a valid probe pixel, 2^30 for an invalid one (depth 0), so
+// that |x - probe| becomes one v_sad_u32 on non-negative operands and an invalid probe yields a difference no threshold
+// can reach -- no select per edge.  (2 vB - vA) + 2^17 and (2 vA - vB) + 2^17 lie in [65537, 262142].
+constexpr unsigned int kProbeBias = 1u << 17, kProbeInvalid = 1u << 30;
+
+__device__ __forceinline__ unsigned int abs_diff_u32(unsigned int a, unsigned int b)
 {
-    const int d = vB - vA;
-    const int f = beyondB != 0 ? abs(d - (beyondB - vB)) : 0x7FFFFFFF;       // :39-47
-    const int b = beyondA != 0 ? abs(d - (vA - beyondA)) : 0x7FFFFFFF;       // :50-56
-    return min(abs(d), min(f, b));                                             // :35
+    unsigned int r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));   // |a - b| in one VALU slot (the compiler has no pattern for it here)
+    return r;
 }
 
-__device__ __forceinline__ int tri_threshold(int s) { return (272 * s + 2181900) / 300000; }   // :26, in integers
+__device__ __forceinline__ unsigned int edge_metric_biased(unsigned int vA, unsigned int vB, unsigned int zBeyondB, unsigned int zBeyondA)
+{
+    const unsigned int a = abs_diff_u32(vA, vB);                                         // |vB - vA|                 (:35)
+    const unsigned int f = abs_diff_u32(2u * vB + kProbeBias - vA, zBeyondB);            // |d - (beyondB - vB)|      (:39-47)
+    const unsigned int b = abs_diff_u32(2u * vA + kProbeBias - vB, zBeyondA);            // |d - (vA - beyondA)|      (:50-56)
+    return min(a, min(f, b));
+}
 
 __device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerLane + 3], const int (&M)[2][kPxPerLane + 1], int x0, int w)
 {
-    int ev[kPxPerLane + 1];   // P-U of window column c = 1 .. 9
+    unsigned int Z[4][kPxPerLane + 3];
 #pragma unroll
-    for (int c = 1; c <= kPxPerLane + 1; c++) ev[c - 1] = edge_metric(D[2][c], D[1][c], D[0][c], D[3][c]);
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < kPxPerLane + 3; c++) Z[r][c] = D[r][c] != 0 ? (unsigned int)D[r][c] + kProbeBias : kProbeInvalid;
+    unsigned int ev[kPxPerLane + 1];   // P-U of window column c = 1 .. 9
+#pragma unroll
+    for (int c = 1; c <= kPxPerLane + 1; c++) ev[c - 1] = edge_metric_biased(D[2][c], D[1][c], Z[0][c], Z[3][c]);
     unsigned int code = 0;
 #pragma unroll
     for (int k = 0; k < kPxPerLane; k++) {
         const int c = k + 1, x = x0 + k;
-        const int vP = D[2][c], vU = D[1][c], vUR = D[1][c + 1], vR = D[2][c + 1];
-        const int hP = edge_metric(vP, vR, D[2][c + 2], D[2][c - 1]);         // P - R
-        const int hU = edge_metric(vU, vUR, D[1][c + 2], D[1][c - 1]);        // U - UR
-        const int d1 = edge_metric(vU, vR, D[3][c + 2], D[0][c - 1]);         // U - R   (down-right)
-        const int d2 = edge_metric(vP, vUR, D[0][c + 2], D[3][c - 1]);        // P - UR  (up-right)
-        const int pu = ev[c - 1], ru = ev[c];                                  // P - U, R - UR
-        const bool zP = vP != 0, zU = vU != 0, zUR = vUR != 0, zR = vR != 0;  // :22-23
-        const int th0 = tri_threshold(vR + vU + vP), th1 = tri_threshold(vR + vUR + vU);
-        const int th2 = tri_threshold(vP + vUR + vU), th3 = tri_threshold(vP + vR + vUR);
-        const bool t0 = zR & zU & zP & (d1 < th0) & (pu < th0) & (hP < th0);  // R,U,P   (:117)
-        const bool t1 = zR & zUR & zU & (ru < th1) & (hU < th1) & (d1 < th1); // R,UR,U  (:118)
-        const bool alt = !(t0 | t1);                                          // :120
-        const bool t2 = alt & zP & zUR & zU & (d2 < th2) & (hU < th2) & (pu < th2);   // P,UR,U (:122)
-        const bool t3 = alt & zP & zR & zUR & (hP < th3) & (ru < th3) & (d2 < th3);   // P,R,UR (:123)
+        const unsigned int vP = D[2][c], vU = D[1][c], vUR = D[1][c + 1], vR = D[2][c + 1];
+        const unsigned int hP = edge_metric_biased(vP, vR, Z[2][c + 2], Z[2][c - 1]);   // P - R
+        const unsigned int hU = edge_metric_biased(vU, vUR, Z[1][c + 2], Z[1][c - 1]);  // U - UR
+        const unsigned int d1 = edge_metric_biased(vU, vR, Z[3][c + 2], Z[0][c - 1]);   // U - R   (down-right)
+        const unsigned int d2 = edge_metric_biased(vP, vUR, Z[0][c + 2], Z[3][c - 1]);  // P - UR  (up-right)
+        const unsigned int pu = ev[c - 1], ru = ev[c];                                   // P - U, R - UR
+        const bool zP = vP != 0, zU = vU != 0, zUR = vUR != 0, zR = vR != 0;            // :22-23
+        const unsigned int sPR = vP + vR, sUUR = vU + vUR;
+        const unsigned int th0 = (unsigned int)tri_threshold((int)(sPR + vU)), th1 = (unsigned int)tri_threshold((int)(sUUR + vR));
+        const unsigned int th2 = (unsigned int)tri_threshold((int)(sUUR + vP)), th3 = (unsigned int)tri_threshold((int)(sPR + vUR));
+        const bool t0 = zR & zU & zP & (d1 < th0) & (pu < th0) & (hP < th0);            // R,U,P   (:117)
+        const bool t1 = zR & zUR & zU & (ru < th1) & (hU < th1) & (d1 < th1);           // R,UR,U  (:118)
+        const bool alt = !(t0 | t1);                                                    // :120
+        const bool t2 = alt & zP & zUR & zU & (d2 < th2) & (hU < th2) & (pu < th2);     // P,UR,U (:122)
+        const bool t3 = alt & zP & zR & zUR & (hP < th3) & (ru < th3) & (d2 < th3);     // P,R,UR (:123)
         const bool mP = M[1][k] != -1, mU = M[0][k] != -1, mUR = M[0][k + 1] != -1, mR = M[1][k + 1] != -1;
-        const bool in_cols = (x >= 1) & (x < w - 2);                          // :87-90
+        const bool in_cols = (x >= 1) & (x < w - 2);                                    // :87-90
         unsigned int m = 0;
-        m |= (t0 & mR & mU) ? 1u : 0u;                                        // :133-134
+        m |= (t0 & mR & mU) ? 1u : 0u;                                                  // :133-134
         m |= (t1 & mR & mUR & mU) ? 2u : 0u;
         m |= (t2 & mUR & mU) ? 4u : 0u;
         m |= (t3 & mR & mUR) ? 8u : 0u;
-        code |= ((in_cols & mP) ? m : 0u) << (4 * k);                         // :113-114
+        code |= ((in_cols & mP) ? m : 0u) << (4 * k);                                   // :113-114
     }
     return code;
 }
