@@ -78,3 +78,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "lsn_oracle" not in text and "from oracle" not in text and "import oracle" not in text and "orc_" not in text, f
+
+
+def test_public_header_is_plain_c_and_cpp():
+    """include/NativeUtils.h is the drop-in boundary: it must compile as C99 and as C++11 on its own (no HIP, no torch types)."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "NativeUtils.h")
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", hdr])
+    subprocess.check_call(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", hdr])
+    includes = [l for l in open(hdr).read().splitlines() if l.strip().startswith("#include")]
+    assert not includes, f"the boundary header pulls in other headers: {includes}"
