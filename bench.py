@@ -127,11 +127,18 @@ def main():
             xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
     prof_plan = whole.plan if use_sx else fus.plan
 
+    # Two resident input sets, used alternately: a real stream brings new frames every step, so nothing a step leaves in
+    # L2 / Infinity Cache may serve the next one (the same buffer every step would let the count pass hit the cache).
+    depth_b, rgb_b = depth.clone(), rgb.clone()
+    step_no = [0]
+
     def step():
+        d_in, c_in = (depth, rgb) if step_no[0] & 1 == 0 else (depth_b, rgb_b)
+        step_no[0] += 1
         if use_sx:
-            sx.exchange(depth, rgb, stream)
+            sx.exchange(d_in, c_in, stream)
         else:
-            fus.run(depth, rgb)
+            fus.run(d_in, c_in)
             if xch is not None:
                 xch.exchange(fus.vertices, fus.offsets)
 

@@ -43,6 +43,10 @@ constexpr int kThreads = 256;
 constexpr int kPxPerLane = 8;
 constexpr int kTile = kThreads * kPxPerLane;  // 2048 pixels per workgroup step
 constexpr int kWin = 1152;                    // survivors staged per LDS round (9/16 of a tile)
+// The merged cloud is written once and not read again by the launch sequence: streaming (nt) stores keep the 15 MB per tick
+// out of L2 / Infinity Cache, where the depth frames and the threshold table live between the count and the write pass
+// (measured: 0.335 -> 0.310 ms per 64-tick step; nt loads of the inputs in the write pass changed nothing).
+constexpr bool kNontemporalStores = true;
 
 struct FrameDesc {
     int w, h, npix, tile_start;  // tile_start: first tile of this frame inside its tick
@@ -341,7 +345,17 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
         }
         __syncthreads();
         const int n = min(kWin, tile_tot - w0);
-        for (int i = threadIdx.x; i < n; i += kThreads) dst[w0 + i] = stage[i + (i >> 3)];
+        for (int i = threadIdx.x; i < n; i += kThreads) {
+            const uint4 v = stage[i + (i >> 3)];
+            if (kNontemporalStores) {   // written once, never read again by this launch sequence
+                __builtin_nontemporal_store(v.x, &dst[w0 + i].x);
+                __builtin_nontemporal_store(v.y, &dst[w0 + i].y);
+                __builtin_nontemporal_store(v.z, &dst[w0 + i].z);
+                __builtin_nontemporal_store(v.w, &dst[w0 + i].w);
+            } else {
+                dst[w0 + i] = v;
+            }
+        }
         __syncthreads();
     }
 }
@@ -1103,7 +1117,7 @@ __global__ __launch_bounds__(kThreads) void tri_kernel(const TriArgs a)
         }
         __syncthreads();
         const int n = 3 * min(kTriWin, tile_tot - w0);
-        for (int i = threadIdx.x; i < n; i += kThreads) dst[3 * w0 + i] = stage[i];
+        for (int i = threadIdx.x; i < n; i += kThreads) __builtin_nontemporal_store(stage[i], &dst[3 * w0 + i]);   // written once
         __syncthreads();
     }
 }
