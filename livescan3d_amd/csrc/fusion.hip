@@ -1511,7 +1511,13 @@ __global__ __launch_bounds__(kThreads) void merge_shards_kernel(const MergeArgs 
     const int count = my_off[a.maps_per_shard];
     const uint4 *src = a.shards + ((long long)shard * a.n_ticks + tick) * a.shard_cap;
     uint4 *dst = a.merged + (long long)tick * a.merged_cap + base;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < count; i += gridDim.x * kThreads) dst[i] = src[i];
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < count; i += gridDim.x * kThreads) {
+        const uint4 v = src[i];                               // streaming stores, like the write kernel (kNontemporalStores)
+        __builtin_nontemporal_store(v.x, &dst[i].x);
+        __builtin_nontemporal_store(v.y, &dst[i].y);
+        __builtin_nontemporal_store(v.z, &dst[i].z);
+        __builtin_nontemporal_store(v.w, &dst[i].w);
+    }
     if (blockIdx.x == 0 && threadIdx.x <= a.maps_per_shard) {
         int *mo = a.merged_off + (long long)tick * (a.n_shards * a.maps_per_shard + 1);
         if (threadIdx.x < a.maps_per_shard) mo[shard * a.maps_per_shard + threadIdx.x] = base + my_off[threadIdx.x];
