@@ -720,11 +720,24 @@ __global__ __launch_bounds__(kThreads) void run_kernel(const FuseArgs a)
                 tn = locate(a, tick, tile + 1);
                 load_inputs<VEC, false>(tn, nx);
             }
-            bool keep[kPxPerLane];
-            uint4 unused[kPxPerLane];
-            compute_tile<VEC, false>(a, t, in, keep, unused);
+            bool counted = false;
+            if (a.thr) {
+                // the per-pixel depth thresholds make the run's count a handful of integer compares (see count_thr_kernel)
+                unsigned int lo[kPxPerLane], cnt[kPxPerLane];
+                bool any_flagged;
+                load_thresholds<VEC>(a, t, lo, cnt, any_flagged);
+                if (!any_flagged) {
+                    wave_total += wave_count_thr(in, lo, cnt);
+                    counted = true;
+                }
+            }
+            if (!counted) {
+                bool keep[kPxPerLane];
+                uint4 unused[kPxPerLane];
+                compute_tile<VEC, false>(a, t, in, keep, unused);
 #pragma unroll
-            for (int k = 0; k < kPxPerLane; k++) wave_total += __popcll(__ballot(keep[k]));  // SALU: lane mask popcount
+                for (int k = 0; k < kPxPerLane; k++) wave_total += __popcll(__ballot(keep[k]));  // SALU: lane mask popcount
+            }
             t = tn;
             in = nx;
         }
