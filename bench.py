@@ -14,6 +14,7 @@ kernel time vs 8 TB/s), "cpu_baseline" (the CPU oracle = port of the reference p
 a bounded sample, rank 0 at N = 1 only), "icp" (configs[1]: 2 sensors x 512x424, ICP(maxIter=10) ms per iteration).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -53,6 +54,15 @@ def parse():
     if args.core_only:
         args.no_icp = args.no_cpu = args.no_host_path = args.no_mesh = args.no_tick_parallel = True
     return args
+
+
+@contextlib.contextmanager
+def leg(result, name):
+    """An extra leg of the bench line must never cost the headline: a failure is recorded under its name instead."""
+    try:
+        yield
+    except Exception as ex:  # noqa: BLE001
+        result[name] = {"error": f"{type(ex).__name__}: {ex}"}
 
 
 def main():
@@ -228,70 +238,73 @@ def main():
 
     # ---- ablation (extra field): the same steps with the arithmetic count pass (no per-pixel depth thresholds) ------------
     if rank == 0 and not multi and args.mode == 0 and not args.core_only and os.environ.get("LSN_NO_THRESHOLDS", "0") in ("", "0"):
-        os.environ["LSN_NO_THRESHOLDS"] = "1"          # read when a plan is created
-        try:
-            fus_a = DeviceFusion(B, [w] * S_loc, [h] * S_loc, device=dev_index, mode=0)
-        finally:
-            del os.environ["LSN_NO_THRESHOLDS"]
-        fus_a.set_params(intr_all[7 * s0:7 * (s0 + S_loc)], wt_all[12 * s0:12 * (s0 + S_loc)], bounds)
-        for _ in range(args.warmup + 1):
-            fus_a.run(depth, rgb)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fus_a.run(depth, rgb)
-        torch.cuda.synchronize()
-        dta = time.perf_counter() - t0
-        same = bool(torch.equal(fus_a.offsets, fus.offsets))
-        result["arithmetic_count_pass"] = {"value": B * args.steps / dta, "unit": "frames/s", "ms_per_step": 1e3 * dta / args.steps,
-                                           "offsets_identical": same,
-                                           "note": "LSN_NO_THRESHOLDS=1: the count pass re-evaluates unproject + transform + crop per pixel "
-                                                   "(fuse_kernel<0>) instead of comparing the depth with the per-pixel interval"}
-        del fus_a
+        with leg(result, "arithmetic_count_pass"):
+            os.environ["LSN_NO_THRESHOLDS"] = "1"          # read when a plan is created
+            try:
+                fus_a = DeviceFusion(B, [w] * S_loc, [h] * S_loc, device=dev_index, mode=0)
+            finally:
+                del os.environ["LSN_NO_THRESHOLDS"]
+            fus_a.set_params(intr_all[7 * s0:7 * (s0 + S_loc)], wt_all[12 * s0:12 * (s0 + S_loc)], bounds)
+            for _ in range(args.warmup + 1):
+                fus_a.run(depth, rgb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fus_a.run(depth, rgb)
+            torch.cuda.synchronize()
+            dta = time.perf_counter() - t0
+            same = bool(torch.equal(fus_a.offsets, fus.offsets))
+            result["arithmetic_count_pass"] = {"value": B * args.steps / dta, "unit": "frames/s", "ms_per_step": 1e3 * dta / args.steps,
+                                               "offsets_identical": same,
+                                               "note": "LSN_NO_THRESHOLDS=1: the count pass re-evaluates unproject + transform + crop per pixel "
+                                                       "(fuse_kernel<0>) instead of comparing the depth with the per-pixel interval"}
+            del fus_a
 
     # ---- pipelined calls (extra field): count(k+1) beside write(k) on an internal side stream -------------------------
     if rank == 0 and not multi and args.mode == 0 and not args.core_only:
-        fus.plan.set_pipelined(True)
-        for _ in range(args.warmup + 1):
-            fus.run(depth, rgb)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fus.run(depth, rgb)
-        torch.cuda.synchronize()
-        dtp = time.perf_counter() - t0
-        ok = bool(torch.equal(fus.offsets.cpu(), torch.from_numpy(off.astype(np.int32))))
-        fus.plan.set_pipelined(False)
-        result["pipelined"] = {"value": B * args.steps / dtp, "unit": "frames/s", "ms_per_step": 1e3 * dtp / args.steps, "offsets_identical": ok,
-                               "note": "same steps with lsnFusionSetPipelined: the VALU-bound count pass of call k+1 overlaps the "
-                                       "HBM-bound write kernel of call k (inputs resident, double-buffered scratch)"}
+        with leg(result, "pipelined"):
+            fus.plan.set_pipelined(True)
+            for _ in range(args.warmup + 1):
+                fus.run(depth, rgb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fus.run(depth, rgb)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t0
+            ok = bool(torch.equal(fus.offsets.cpu(), torch.from_numpy(off.astype(np.int32))))
+            fus.plan.set_pipelined(False)
+            result["pipelined"] = {"value": B * args.steps / dtp, "unit": "frames/s", "ms_per_step": 1e3 * dtp / args.steps, "offsets_identical": ok,
+                                   "note": "same steps with lsnFusionSetPipelined: the VALU-bound count pass of call k+1 overlaps the "
+                                           "HBM-bound write kernel of call k (inputs resident, double-buffered scratch)"}
 
     # ---- streamed calls (extra field): write(k) and count(k+1) inside one kernel -----------------------------------------
     if rank == 0 and not multi and args.mode == 0 and not args.core_only:
-        d2 = depth.clone()                       # a second resident batch, so that "next" is a different buffer
-        bufs = [depth, d2]
-        fus.plan.profile(True)
-        fus.plan.kernel_stats(reset=True)
-        def sstep(i):
-            fus.plan.run_streamed(bufs[i & 1].data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(),
-                                  bufs[(i + 1) & 1].data_ptr(), stream)
-        for i in range(args.warmup + 1):
-            sstep(i)
-        torch.cuda.synchronize()
-        fus.plan.kernel_stats(reset=True)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            sstep(i + args.warmup + 1)
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - t0
-        ks = fus.plan.kernel_stats(reset=True)
-        fus.plan.profile(False)
-        ok = bool(torch.equal(fus.offsets.cpu(), torch.from_numpy(off.astype(np.int32))))
-        result["streamed"] = {"value": B * args.steps / dts, "unit": "frames/s", "ms_per_step": 1e3 * dts / args.steps, "offsets_identical": ok,
-                              "kernel_avg_ms": ks["avg_ms"], "achieved_GBps": alg_bytes / (ks["avg_ms"] * 1e-3) / 1e9 if ks["avg_ms"] > 0 else 0.0,
-                              "note": "lsnFusionRunStreamed: one kernel writes batch k (HBM-bound) and counts the resident batch k+1 "
-                                      "(VALU-bound); same work per step as the default path, no separate count launch"}
-        del d2
+        with leg(result, "streamed"):
+            d2 = depth.clone()                       # a second resident batch, so that "next" is a different buffer
+            bufs = [depth, d2]
+            fus.plan.profile(True)
+            fus.plan.kernel_stats(reset=True)
+            def sstep(i):
+                fus.plan.run_streamed(bufs[i & 1].data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(),
+                                      bufs[(i + 1) & 1].data_ptr(), stream)
+            for i in range(args.warmup + 1):
+                sstep(i)
+            torch.cuda.synchronize()
+            fus.plan.kernel_stats(reset=True)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                sstep(i + args.warmup + 1)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            ks = fus.plan.kernel_stats(reset=True)
+            fus.plan.profile(False)
+            ok = bool(torch.equal(fus.offsets.cpu(), torch.from_numpy(off.astype(np.int32))))
+            result["streamed"] = {"value": B * args.steps / dts, "unit": "frames/s", "ms_per_step": 1e3 * dts / args.steps, "offsets_identical": ok,
+                                  "kernel_avg_ms": ks["avg_ms"], "achieved_GBps": alg_bytes / (ks["avg_ms"] * 1e-3) / 1e9 if ks["avg_ms"] > 0 else 0.0,
+                                  "note": "lsnFusionRunStreamed: one kernel writes batch k (HBM-bound) and counts the resident batch k+1 "
+                                          "(VALU-bound); same work per step as the default path, no separate count launch"}
+            del d2
 
     # ---- N > 1, extra leg: the exchange step carrying 16-byte vertices (what the survivor exchange is compared with) ------
     if use_sx and not args.no_tick_parallel:
@@ -351,82 +364,89 @@ def main():
 
     # ---- the complete merge call incl. the reference's always-on triangulation (extra field, never `value`) --------
     if rank == 0 and not multi and not args.no_mesh:
-        cap = fus.capacity
-        tri = torch.empty((B, 2 * cap, 3), dtype=torch.int32, device=dev)
-        toff = torch.zeros((B, S_loc + 1), dtype=torch.int32, device=dev)
+        with leg(result, "mesh"):
+            cap = fus.capacity
+            tri = torch.empty((B, 2 * cap, 3), dtype=torch.int32, device=dev)
+            toff = torch.zeros((B, S_loc + 1), dtype=torch.int32, device=dev)
 
-        def mesh_step():
-            fus.plan.run_mesh(depth.data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(), tri.data_ptr(),
-                              toff.data_ptr(), stream)
-        for _ in range(2):
-            mesh_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(max(3, args.steps // 4)):
-            mesh_step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        result["mesh"] = {"frames_per_s": B * max(3, args.steps // 4) / dt,
-                          "triangles_per_tick": float(toff[:, -1].float().mean().item()),
-                          "note": "vertices + triangulation (meshGenerator.cpp) per tick on the same noise inputs; hash-noise depth "
-                                  "exercises every rejection branch but yields few triangles"}
-        del tri, toff
+            def mesh_step():
+                fus.plan.run_mesh(depth.data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(), tri.data_ptr(),
+                                  toff.data_ptr(), stream)
+            for _ in range(2):
+                mesh_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(3, args.steps // 4)):
+                mesh_step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            result["mesh"] = {"frames_per_s": B * max(3, args.steps // 4) / dt,
+                              "triangles_per_tick": float(toff[:, -1].float().mean().item()),
+                              "note": "vertices + triangulation (meshGenerator.cpp) per tick on the same noise inputs; hash-noise depth "
+                                      "exercises every rejection branch but yields few triangles"}
+            del tri, toff
 
     # ---- radial correction, the step before the merge call on every tick (extra field) ---------------------------
     if rank == 0 and not multi and not args.no_mesh:
-        d2, c2 = depth.clone(), rgb.clone()
-        intr_loc = intr_all[7 * s0:7 * (s0 + S_loc)]
-        fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
-        torch.cuda.synchronize()
-        d2.copy_(depth); c2.copy_(rgb)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
-        torch.cuda.synchronize()
-        result["radial_correction"] = {"frames_per_s": B / (time.perf_counter() - t0),
-                                       "note": "depthMapAndColorSetRadialCorrection on the same ticks, HBM resident, one pass"}
-        del d2, c2
+        with leg(result, "radial_correction"):
+            d2, c2 = depth.clone(), rgb.clone()
+            intr_loc = intr_all[7 * s0:7 * (s0 + S_loc)]
+            fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
+            torch.cuda.synchronize()
+            d2.copy_(depth); c2.copy_(rgb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
+            torch.cuda.synchronize()
+            result["radial_correction"] = {"frames_per_s": B / (time.perf_counter() - t0),
+                                           "note": "depthMapAndColorSetRadialCorrection on the same ticks, HBM resident, one pass"}
+            del d2, c2
 
     # ---- outbound formats of one tick's mesh, built in HBM (extra field) -----------------------------------------
     if rank == 0 and not multi and not args.no_mesh:
-        result["wire"] = bench_wire(args, torch, native, synth, dev, stream, S, w, h, bounds, with_cpu=not args.no_cpu)
+        with leg(result, "wire"):
+            result["wire"] = bench_wire(args, torch, native, synth, dev, stream, S, w, h, bounds, with_cpu=not args.no_cpu)
 
     # ---- drop-in export on host buffers (PCIe-inclusive; never `value`) -----------------------------------------
     if rank == 0 and not args.no_host_path:
-        import ctypes as C
-        rig = synth.make_rig("noise", S, w, h, seed=1, bounds=bounds)
-        L = native.lib()
-        vp = C.c_void_p
-        argv = [S, rig.depth_maps.ctypes.data_as(vp), rig.depth_colors.ctypes.data_as(vp), rig.widths.ctypes.data_as(vp),
-                rig.heights.ctypes.data_as(vp), rig.intr.ctypes.data_as(vp), rig.wt.ctypes.data_as(vp)]
-        mesh = native.Mesh()
+        with leg(result, "host_path"):
+            import ctypes as C
+            rig = synth.make_rig("noise", S, w, h, seed=1, bounds=bounds)
+            L = native.lib()
+            vp = C.c_void_p
+            argv = [S, rig.depth_maps.ctypes.data_as(vp), rig.depth_colors.ctypes.data_as(vp), rig.widths.ctypes.data_as(vp),
+                    rig.heights.ctypes.data_as(vp), rig.intr.ctypes.data_as(vp), rig.wt.ctypes.data_as(vp)]
+            mesh = native.Mesh()
 
-        def call():   # exactly what KinectServer.GenerateMesh does around the P/Invoke, minus the managed copies
-            L.generateMeshFromDepthMaps(*argv, C.byref(mesh), False, *[float(x) for x in bounds], False)
-            n = mesh.nVertices
-            L.deleteMesh(C.byref(mesh))
-            return n
-        for _ in range(3):
-            nv = call()
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 2.0:
-            call()
-            n += 1
-        result["host_path_frames_per_s"] = n / (time.perf_counter() - t0)
-        result["host_path_note"] = (f"generateMeshFromDepthMaps + deleteMesh on host arrays ({S} x {w}x{h}, {nv} vertices back, "
-                                    "triangulation included): H2D from pageable memory + kernels + D2H into pinned memory")
+            def call():   # exactly what KinectServer.GenerateMesh does around the P/Invoke, minus the managed copies
+                L.generateMeshFromDepthMaps(*argv, C.byref(mesh), False, *[float(x) for x in bounds], False)
+                n = mesh.nVertices
+                L.deleteMesh(C.byref(mesh))
+                return n
+            for _ in range(3):
+                nv = call()
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 2.0:
+                call()
+                n += 1
+            result["host_path_frames_per_s"] = n / (time.perf_counter() - t0)
+            result["host_path_note"] = (f"generateMeshFromDepthMaps + deleteMesh on host arrays ({S} x {w}x{h}, {nv} vertices back, "
+                                        "triangulation included): H2D from pageable memory + kernels + D2H into pinned memory")
 
     # ---- ICP, configs[1] ------------------------------------------------------------------------------------------
     if rank == 0 and not args.no_icp:
-        result["icp"] = bench_icp(args, torch, native, synth, dev, stream, with_cpu=(world == 1 and not args.no_cpu))
+        with leg(result, "icp"):
+            result["icp"] = bench_icp(args, torch, native, synth, dev, stream, with_cpu=(world == 1 and not args.no_cpu))
 
     # ---- the whole pose-refinement pass (H2 / f-3): N sensors x 2 refine passes x 10 ICP iterations in one call ---------
     if rank == 0 and not multi and not args.no_icp:
-        result["refine"] = bench_refine(args, native, synth, S, w, h, with_cpu=not args.no_cpu)
+        with leg(result, "refine"):
+            result["refine"] = bench_refine(args, native, synth, S, w, h, with_cpu=not args.no_cpu)
 
     # ---- CPU baseline (rank 0, N = 1 only) ------------------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu:
-        result["cpu_baseline"] = cpu_baseline(args, synth, S, w, h, bounds)
+        with leg(result, "cpu_baseline"):
+            result["cpu_baseline"] = cpu_baseline(args, synth, S, w, h, bounds)
 
     if multi:
         dist.barrier()
