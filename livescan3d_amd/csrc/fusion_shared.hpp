@@ -1,0 +1,443 @@
+// fusion_shared.hpp -- what the translation units of the fusion plan share: the device-side building blocks of the fused
+// unproject + transform + crop + compaction kernels (fusion.hip holds the design notes), the scan kernel, and the host-side
+// plan object behind the opaque LsnFusion handle.  Device code lives in an anonymous namespace: every .hip file gets its own copy.
+#pragma once
+
+#include "lsn_common.hpp"
+
+#include <mutex>
+#include <vector>
+
+namespace lsn {
+
+struct FrameDesc {
+    int w, h, npix, tile_start;  // tile_start: first tile of this frame inside its tick
+    long long depth_off;         // u16 elements from the tick's depth base
+    long long rgb_off;           // bytes from the tick's colour base
+    int xtab_off, ytab_off;      // this sensor's rows of the unprojection tables (floats)
+    float inv_w;                 // 1 / w, for the (corrected, exact) float division of small pixel offsets
+    int pad1;
+};
+
+struct TileDesc {  // one per tile of a tick
+    int frame;     // sensor-frame the tile belongs to
+    int x0, y0;    // column / row of the tile's first pixel (host-computed: no integer division on the device)
+    int pad;
+};
+
+struct SensorParams {  // 16 floats, wave-uniform -> scalar loads
+    float cx, cy, fx, fy;
+    float t0, t1, t2;
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+};
+
+struct FuseArgs {
+    const FrameDesc *frames;
+    const TileDesc *tiles;             // tile (within tick) -> frame and first-pixel coordinates
+    const SensorParams *params;
+    const float *xtab;  // [(x - cx) / fx] per sensor column
+    const float *ytab;  // [(cy - y) / fy] per sensor row
+    const unsigned short *depth;
+    const unsigned char *rgb;
+    uint4 *out;
+    int *tile_counts;                // mode 0: [n_ticks * tiles_per_tick] counts, then exclusive prefixes
+    unsigned long long *run_state;   // mode 1: [n_ticks * tiles_per_tick] {flag:2 | value}, indexed by run
+    unsigned int *ticket;            // mode 1: per-tick run tickets, 32 words apart
+    int *offsets;                    // [n_ticks][n_frames + 1]
+    int *pixmap;                     // optional [n_ticks][pixels per tick]: vertex index inside the tick's cloud, -1 = none
+    const unsigned short *depth_next;  // streamed mode (MODE 3): the NEXT batch's depth, counted in the shadow of this write
+    int *tile_counts_next;             // ... and where its per-tile counts go
+    int *error_flag;                 // mode 1: set when a bounded spin gives up (sticky until read)
+    const unsigned int *thr;         // optional [pixels per tick]: the depth interval each pixel survives in (thresh_kernel), null = none
+    int n_frames;
+    int tiles_per_tick;
+    int n_ticks;
+    int tiles_per_run;               // mode 1
+    int runs_per_tick;               // mode 1
+    long long tick_depth_stride;  // u16 elements
+    long long tick_rgb_stride;    // bytes
+    long long tick_vert_stride;   // vertices
+    float minX, minY, minZ, maxX, maxY, maxZ;
+};
+
+}  // namespace lsn
+using lsn::FrameDesc;
+using lsn::FuseArgs;
+using lsn::SensorParams;
+using lsn::TileDesc;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPxPerLane = 8;
+constexpr int kTile = kThreads * kPxPerLane;  // 2048 pixels per workgroup step
+constexpr int kWin = 1152;                    // survivors staged per LDS round (9/16 of a tile)
+// The merged cloud is written once and not read again by the launch sequence: streaming (nt) stores keep the 15 MB per tick
+// out of L2 / Infinity Cache, where the depth frames and the threshold table live between the count and the write pass
+// (measured: 0.335 -> 0.310 ms per 64-tick step; nt loads of the inputs in the write pass changed nothing).
+constexpr bool kNontemporalStores = true;
+
+// (FrameDesc, TileDesc, SensorParams and FuseArgs are declared above, in namespace lsn: they appear in the signatures of
+// the host helpers shared between the translation units and therefore need external linkage)
+
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Z = float(d) / 1000.0f (depthprocessing.cpp:149-150) for two pixels without the ~13-instruction IEEE division:
+// with r = fl32(1/1000) = 0x3a83126f, q0 = d*r, e = fma(-q0, 1000, d), q = fma(e, r, q0) is the correctly rounded
+// quotient for EVERY u16 d -- proven exhaustively with exact rational arithmetic in tests/test_fast_division.py.
+__device__ __forceinline__ f2 depth_to_metres2(f2 d)
+{
+    const f2 r = {0x1.0624dep-10f, 0x1.0624dep-10f};
+    const f2 k = {1000.0f, 1000.0f};
+    const f2 q0 = d * r;
+    const f2 e = __builtin_elementwise_fma(-q0, k, d);
+    return __builtin_elementwise_fma(e, r, q0);
+}
+
+// createVertices' per-pixel arithmetic (depthprocessing.cpp:149-163) on TWO pixels at once, one rounding per
+// operation (contraction is off, so a*b+c stays a packed multiply and a packed add: v_pk_mul_f32 / v_pk_add_f32 do two
+// f32 lanes' worth per issue slot, which halves the VALU time of this VALU-heavy kernel).
+// xfac = (float(x) - cx) / fx and yfac = (cy - float(y)) / fy (:151-152) depend on the column / row only; they come
+// from per-sensor tables filled on the device with the same IEEE operations (table_kernel), so the per-pixel work
+// has no division left.
+__device__ __forceinline__ void unproject2(f2 d, f2 xfac, f2 yfac, const SensorParams &P, f2 &ox, f2 &oy, f2 &oz)
+{
+    f2 Z = depth_to_metres2(d);
+    f2 X = xfac * Z;
+    f2 Y = yfac * Z;
+    X = X + P.t0;
+    Y = Y + P.t1;
+    Z = Z + P.t2;
+    ox = X * P.r00 + Y * P.r01 + Z * P.r02;
+    oy = X * P.r10 + Y * P.r11 + Z * P.r12;
+    oz = X * P.r20 + Y * P.r21 + Z * P.r22;
+}
+
+// The inclusive AABB test with the reference's own comparisons (:162), so that a NaN coordinate is kept exactly like
+// the reference keeps it (non-short-circuit '|': six compares and lane-mask ORs, no divergent branches).
+__device__ __forceinline__ bool inside_box(float ox, float oy, float oz, const FuseArgs &a)
+{
+    const bool rejected = (ox < a.minX) | (ox > a.maxX) | (oy < a.minY) | (oy > a.maxY) | (oz < a.minZ) | (oz > a.maxZ);
+    return !rejected;
+}
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+// Number of survivors among the lower lanes of the wave, and in the whole wave, straight from the keep predicates'
+// lane masks: v_mbcnt per mask for the lanes below, s_bcnt1 (SALU) for the total -- no shuffles, no per-lane counters.
+__device__ __forceinline__ void rank_from_masks(const bool (&keep)[kPxPerLane], int &below, int &wave_total)
+{
+    below = 0;
+    wave_total = 0;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) {
+        const unsigned long long m = __ballot(keep[k]);
+        below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, below));
+        wave_total += __popcll(m);
+    }
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- one tile: where it is, its inputs, its arithmetic --------------------------------------------------------
+
+struct Tile {  // wave-uniform (SGPRs)
+    long long pix_base;      // index of the frame's first pixel inside its tick (= depth_off)
+    int f, w, h, npix, px0;  // frame, its size, first pixel of the tile inside the frame
+    int x0, y0;              // that pixel's column / row
+    float inv_w;
+    bool frame_start;
+    const unsigned short *dptr;
+    const unsigned char *cptr;
+    const float *xt, *yt;
+};
+
+__device__ __forceinline__ Tile locate(const FuseArgs &a, int tick, int tile)
+{
+    Tile t;
+    const TileDesc td = a.tiles[tile];
+    t.f = td.frame;
+    t.x0 = td.x0;
+    t.y0 = td.y0;
+    const FrameDesc fd = a.frames[t.f];
+    t.inv_w = fd.inv_w;
+    t.pix_base = fd.depth_off;
+    t.w = fd.w;
+    t.h = fd.h;
+    t.npix = fd.npix;
+    t.px0 = (tile - fd.tile_start) * kTile;
+    t.frame_start = tile == fd.tile_start;
+    t.dptr = a.depth + tick * a.tick_depth_stride + fd.depth_off;
+    t.cptr = a.rgb + tick * a.tick_rgb_stride + fd.rgb_off;
+    t.xt = a.xtab + fd.xtab_off;
+    t.yt = a.ytab + fd.ytab_off;
+    return t;
+}
+
+struct Inputs {  // one lane's 8 pixels
+    unsigned int dw[4];  // 8 x u16 depth
+    unsigned int cw[6];  // 8 x RGB8
+};
+
+// VEC: every frame has w % 8 == 0 and the buffers are 16-B aligned -> one 16-B depth load, 24 B of colour per lane.
+template <bool VEC, bool RGB>
+__device__ __forceinline__ void load_inputs(const Tile &t, Inputs &in)
+{
+    const int p0 = t.px0 + threadIdx.x * kPxPerLane;
+#pragma unroll
+    for (int i = 0; i < 4; i++) in.dw[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.cw[i] = 0;
+    if (VEC) {
+        if (p0 < t.npix) {
+            const uint4 dv = *reinterpret_cast<const uint4 *>(t.dptr + p0);
+            in.dw[0] = dv.x; in.dw[1] = dv.y; in.dw[2] = dv.z; in.dw[3] = dv.w;
+            if (RGB) {
+                const uint2 *cp = reinterpret_cast<const uint2 *>(t.cptr + 3ll * p0);
+                const uint2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+                in.cw[0] = c0.x; in.cw[1] = c0.y; in.cw[2] = c1.x; in.cw[3] = c1.y; in.cw[4] = c2.x; in.cw[5] = c2.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            if (p0 + k < t.npix) {
+                const unsigned int d = t.dptr[p0 + k];
+                in.dw[k >> 1] |= d << ((k & 1) * 16);
+                if (RGB) {
+                    const unsigned char *c = t.cptr + 3ll * (p0 + k);
+                    const unsigned int rgb = c[0] | (c[1] << 8) | (c[2] << 16);
+                    const int b = 3 * k;  // the pixel's 3 bytes start at byte 3k of the lane's 24-byte group
+                    in.cw[b >> 2] |= rgb << ((b & 3) * 8);
+                    if ((b & 3) > 1) in.cw[(b >> 2) + 1] |= rgb >> ((4 - (b & 3)) * 8);
+                }
+            }
+        }
+    }
+}
+
+// Keep predicates (wave-wide lane masks in SGPR pairs) and, when WRITE, the assembled vertices of a lane's 8 pixels.
+// Branch-free: a zero depth (invalid pixel, :144, or a lane past the frame end) is computed and then dropped.
+// The column / row factors of a lane's 8 pixels (they depend on the tile geometry only, not on the tick or the batch).
+template <bool VEC>
+__device__ __forceinline__ void tile_factors(const Tile &t, float (&xf)[kPxPerLane], float (&yf)[kPxPerLane])
+{
+    const int p0 = t.px0 + threadIdx.x * kPxPerLane;
+    const bool in_frame = p0 < t.npix;
+    // (x, y) of the lane's first pixel: the tile starts at (x0, y0) and the lane is v = x0 + 8*tid < w + 2048 columns
+    // further; v / w by a float multiply and an exact +-1 correction (v < 2^23, so the estimate is off by at most one).
+    const int v = t.x0 + (int)threadIdx.x * kPxPerLane;
+    int q = (int)((float)v * t.inv_w);
+    int x = v - q * t.w;
+    if (x < 0) { q--; x += t.w; }
+    if (x >= t.w) { q++; x -= t.w; }
+    int y = t.y0 + q;
+    if (!in_frame) { x = 0; y = 0; }
+    float yfac = t.yt[y];
+    if (VEC) {
+        // w % 8 == 0: the lane's 8 pixels share a row and their columns are 8 consecutive, 32-B aligned table entries
+        const float4 x0 = *reinterpret_cast<const float4 *>(t.xt + x);
+        const float4 x1 = *reinterpret_cast<const float4 *>(t.xt + x + 4);
+        xf[0] = x0.x; xf[1] = x0.y; xf[2] = x0.z; xf[3] = x0.w;
+        xf[4] = x1.x; xf[5] = x1.y; xf[6] = x1.z; xf[7] = x1.w;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) yf[k] = yfac;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            xf[k] = t.xt[x];
+            yf[k] = yfac;
+            // rows may end inside a lane's 8 pixels when w % 8 != 0
+            x++;
+            if (x == t.w) {
+                x = 0;
+                y = y + 1 < t.h ? y + 1 : y;
+                yfac = t.yt[y];
+            }
+        }
+    }
+}
+
+template <bool WRITE>
+__device__ __forceinline__ void compute_pixels(const FuseArgs &a, const SensorParams &P, const Inputs &in, const float (&xf)[kPxPerLane],
+                                               const float (&yf)[kPxPerLane], bool (&keep)[kPxPerLane], uint4 (&vert)[kPxPerLane])
+{
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k += 2) {
+        const unsigned int d0 = in.dw[k >> 1] & 0xFFFFu, d1 = in.dw[k >> 1] >> 16;
+        f2 ox, oy, oz;
+        unproject2(f2{(float)d0, (float)d1}, f2{xf[k], xf[k + 1]}, f2{yf[k], yf[k + 1]}, P, ox, oy, oz);
+        keep[k] = inside_box(ox.x, oy.x, oz.x, a) && d0 != 0;
+        keep[k + 1] = inside_box(ox.y, oy.y, oz.y, a) && d1 != 0;
+        if (WRITE) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int b = 3 * (k + j);
+                const unsigned int lo = in.cw[b >> 2];
+                const unsigned int hi = in.cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
+                vert[k + j].x = (__funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu) | 0xFF000000u;  // A = 255 (:1601)
+                vert[k + j].y = __float_as_uint(j ? ox.y : ox.x);
+                vert[k + j].z = __float_as_uint(j ? oy.y : oy.x);
+                vert[k + j].w = __float_as_uint(j ? oz.y : oz.x);
+            }
+        }
+    }
+}
+
+template <bool VEC, bool WRITE>
+__device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, const Inputs &in, bool (&keep)[kPxPerLane],
+                                             uint4 (&vert)[kPxPerLane])
+{
+    const SensorParams P = a.params[t.f];
+    float xf[kPxPerLane], yf[kPxPerLane];
+    tile_factors<VEC>(t, xf, yf);
+    compute_pixels<WRITE>(a, P, in, xf, yf, keep, vert);
+}
+
+// Stages a tile's survivors in LDS in rank order, window by window, and copies them out with consecutive lanes writing
+// consecutive 16-B vertices.  Rank q of a window lives at slot q + q/8: a lane's 8 consecutive ranks then start 9 slots
+// (144 B) apart, which keeps the 16-B LDS writes of neighbouring lanes on different bank groups (stride 128 B is an
+// 8-way conflict).  A typical tile (crop + invalid pixels) fits in one window of kWin; the 20.7 KB footprint (instead of
+// 36.9 KB for a whole tile) lets 7 workgroups share a CU.  Every thread must call this (barriers inside); rank0 is the
+// lane's first rank inside the tile, tile_tot is uniform.  On return the LDS window is free again.
+__device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)[kPxPerLane], const uint4 (&vert)[kPxPerLane], int rank0,
+                                                int tile_tot, uint4 *dst)
+{
+    for (int w0 = 0; w0 < tile_tot; w0 += kWin) {
+        int r = rank0 - w0;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            if (keep[k]) {
+                if ((unsigned int)r < (unsigned int)kWin) stage[r + (r >> 3)] = vert[k];
+                r++;
+            }
+        }
+        __syncthreads();
+        const int n = min(kWin, tile_tot - w0);
+        for (int i = threadIdx.x; i < n; i += kThreads) {
+            const uint4 v = stage[i + (i >> 3)];
+            if (kNontemporalStores) {   // written once, never read again by this launch sequence
+                __builtin_nontemporal_store(v.x, &dst[w0 + i].x);
+                __builtin_nontemporal_store(v.y, &dst[w0 + i].y);
+                __builtin_nontemporal_store(v.z, &dst[w0 + i].z);
+                __builtin_nontemporal_store(v.w, &dst[w0 + i].w);
+            } else {
+                dst[w0 + i] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Mode 0, between the count and the write launch: one workgroup per tick turns that tick's tile counts into exclusive
+// prefixes in place and fills the per-sensor offset table (offsets[tick][f] = first vertex of sensor f, [n_frames] = total).
+__attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(int *tile_counts, int tiles_per_tick, const FrameDesc *frames, int n_frames,
+                                                        int *offsets)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_carry;
+    const int tick = blockIdx.x;
+    int *tc = tile_counts + (long long)tick * tiles_per_tick;
+    int *off = offsets + (long long)tick * (n_frames + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < tiles_per_tick; c0 += kThreads) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < tiles_per_tick ? tc[i] : 0;
+        const int incl = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int pre = s_carry;
+        for (int w = 0; w < wave; w++) pre += s_wave[w];
+        if (i < tiles_per_tick) tc[i] = pre + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kThreads - 1) s_carry = pre + incl;
+        __syncthreads();
+    }
+    // frames are few: thread f looks up the prefix at its first tile (written above by this workgroup)
+    for (int f = threadIdx.x; f <= n_frames; f += kThreads) off[f] = f < n_frames ? tc[frames[f].tile_start] : s_carry;
+}
+
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------------------
+// host side: the plan
+// -------------------------------------------------------------------------------------------------------------
+
+struct LsnFusion {
+    int device = 0;
+    int n_ticks = 0, n_maps = 0;
+    std::vector<int> w, h;
+    long long cap = 0;  // vertices per tick
+    long long tick_depth_elems = 0, tick_rgb_bytes = 0;
+    int tiles_per_tick = 0;
+    bool vec_ok = false;
+    bool params_set = false;
+    int mode = 0;
+    int tiles_per_run_override = 0;  // $LSN_TILES_PER_RUN (tuning / tests)
+    bool want_pixmap = false;        // set by lsnFusionRunMesh around its vertex pass
+    float bounds[6] = {0, 0, 0, 0, 0, 0};
+    lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: error flag (word 0) + tickets
+    lsn::DevBuf xtab, ytab;
+    lsn::DevBuf pixmap, tri_counts, tri_codes;  // triangulation scratch, allocated on first use
+    lsn::DevBuf winner, map_copy, colors_copy, radial;  // radial-correction scratch, allocated on first use
+    lsn::DevBuf cand;                                   // [pixels per tick][4] warp candidates of the current intrinsics
+    std::vector<float> radial_intr;                     // the intrinsics `cand` was built for
+    bool cand_valid = false, cand_overflow = false;
+    // pipelined mode: the count + scan of call k+1 run on a side stream while the write kernel of call k is still busy
+    bool pipelined = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_counted = nullptr, ev_written[2] = {nullptr, nullptr};
+    lsn::DevBuf tile_counts_b, offs_int;  // second count buffer, internal offsets [2][n_ticks][n_maps+1]
+    unsigned long long calls = 0;
+    // streamed mode: which batch the "other" half of the count scratch was counted for
+    const void *counted_for = nullptr;
+    unsigned long long counted_gen = 0, params_gen = 1;
+    int stream_half = 0;
+    // per-pixel depth thresholds (thresh_kernel): built once the same parameters are used for a second run
+    lsn::DevBuf thr;
+    bool thr_valid = false;
+    bool thr_enabled = true;             // $LSN_NO_THRESHOLDS=1 keeps the arithmetic count pass (ablation / tests)
+    int runs_with_params = 0;
+    std::vector<float> last_intr, last_wt;
+    float thr_build_ms = 0;
+    // dominant-kernel timing
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t ev_used = 0;
+    double acc_ms = 0;
+    long long launches = 0;
+    const char *timed_kernel = nullptr;  // which kernel the event pairs bracket (set by the entry point that records them)
+    std::mutex mu;
+};
+
+namespace lsn {
+// Kernel arguments of one call (everything but the per-mode scratch selection).
+void fill_args(LsnFusion *p, FuseArgs &a, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets);
+// Called at the top of every run (p->mu held): builds the per-pixel depth thresholds on the second run with unchanged parameters.
+int ensure_thresholds(LsnFusion *p, hipStream_t s);
+// The count pass of one batch into a.tile_counts: from the thresholds when they exist, else arithmetically.
+void launch_count(LsnFusion *p, bool vec, hipStream_t s, const FuseArgs &a);
+// Next HIP-event pair of the dominant-kernel timer (profiling on).
+int next_event_pair(LsnFusion *p, hipEvent_t &e0, hipEvent_t &e1);
+}  // namespace lsn
+using lsn::ensure_thresholds;
+using lsn::fill_args;
+using lsn::launch_count;
+using lsn::next_event_pair;

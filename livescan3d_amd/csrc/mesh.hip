@@ -1,0 +1,359 @@
+// mesh.hip -- the always-on triangulation of the merge call: tri_kernel<0/1> + lsnFusionRunMesh.
+// Shares the plan and the tile machinery of fusion.hip (fusion_shared.hpp).
+#include "fusion_shared.hpp"
+
+namespace {
+
+// ---- triangulation (the "next" row after the vertex path) --------------------------------------------------------
+//
+// Replaces MeshGenerator::generateTrianglesGradients (src/NativeUtils/meshGenerator.cpp:14-181, driver
+// depthprocessing.cpp:1659-1691) and formMesh's triangle part (:1611-1627).  Per pixel with a vertex, a 2x2 stencil
+// (P, U = up, UR = up-right, R = right) yields up to two triangles after depth-continuity tests that also look one
+// step further along every edge; the reference's 4 row-band threads concatenated in order are plain raster order over
+// y in [2, h-2), x in [1, w-2).  Same structure as the vertex path: count -> scan_kernel -> write, 8 pixels per lane,
+// the 4 x 11 depth window and the 2 x 9 index window of a lane live in registers.  All integer arithmetic.
+
+struct TriArgs {
+    const FrameDesc *frames;
+    const TileDesc *tiles;
+    const unsigned short *depth;
+    const int *pixmap;   // [n_ticks][pixels per tick]
+    int *tri;            // [n_ticks][tri_cap][3]
+    int *tile_counts;    // [n_ticks * tiles_per_tick] counts, then exclusive prefixes (scan_kernel)
+    unsigned int *codes; // [n_ticks * tiles_per_tick * 256] per-lane 4-bit-per-pixel triangle codes: count pass -> write pass
+    int tiles_per_tick;
+    long long tick_pix_stride;  // pixels per tick
+    long long tick_tri_stride;  // triangles per tick (capacity)
+};
+
+constexpr int kTriWin = 1536;  // triangles staged per LDS round (18 KB)
+
+// MeshGenerator::checkTriangleConstraints (meshGenerator.cpp:14-61) on a pixel's 4 x 4 depth window W[dy + 2][dx + 1],
+// dx in [-1, 2], dy in [-2, 1]; the three corners are compile-time offsets, so are the forward / backward probes.
+// depth_thr = (int)((v0 + v1 + v2) / 3.0 * 0.00272 + 7.273) (:26, double) equals (272 s + 2181900) / 300000 in integers
+// for EVERY possible sum s of three u16 -- proven exhaustively in tests/test_fast_division.py.
+template <int X1, int Y1, int X2, int Y2>
+__device__ __forceinline__ bool edge_ok(const int (&W)[4][4], int thr)
+{
+    const int val1 = W[Y1 + 2][X1 + 1], val2 = W[Y2 + 2][X2 + 1];
+    if (abs(val1 - val2) < thr) return true;                                  // :35-36
+    constexpr int SX = X2 - X1, SY = Y2 - Y1;
+    const int val_forward = W[Y2 + SY + 2][X2 + SX + 1];                      // :39-40
+    if (val_forward != 0 && abs(val2 - val1 - (val_forward - val2)) < thr) return true;    // :42-47
+    const int val_backward = W[Y1 - SY + 2][X1 - SX + 1];                     // :50
+    if (val_backward != 0 && abs(val2 - val1 - (val1 - val_backward)) < thr) return true;  // :51-56
+    return false;
+}
+
+template <int X1, int Y1, int X2, int Y2, int X3, int Y3>
+__device__ __forceinline__ bool tri_ok(const int (&W)[4][4])
+{
+    const int v0 = W[Y1 + 2][X1 + 1], v1 = W[Y2 + 2][X2 + 1], v2 = W[Y3 + 2][X3 + 1];
+    if (v0 == 0 || v1 == 0 || v2 == 0) return false;                          // :22-23
+    const int thr = (272 * (v0 + v1 + v2) + 2181900) / 300000;
+    return edge_ok<X1, Y1, X2, Y2>(W, thr) && edge_ok<X2, Y2, X3, Y3>(W, thr) && edge_ok<X3, Y3, X1, Y1>(W, thr);
+}
+
+// Which of the four candidate triangles of a pixel are emitted: bit i = triangle i of meshGenerator.cpp:101-104
+// (0: R,U,P  1: R,UR,U  2: P,UR,U  3: P,R,UR), after the vertex-index checks of :133-134.
+__device__ __forceinline__ unsigned int pixel_triangles(const int (&W)[4][4], int mP, int mU, int mUR, int mR)
+{
+    if (mP == -1) return 0;                                                   // :113-114
+    const bool t0 = tri_ok<0, 0, 0, -1, 1, 0>(W);                             // :117
+    const bool t1 = tri_ok<1, 0, 0, -1, 1, -1>(W);                            // :118
+    bool t2 = false, t3 = false;
+    if (!t0 && !t1) {
+        t2 = tri_ok<0, 0, 0, -1, 1, -1>(W);                                   // :122
+        t3 = tri_ok<0, 0, 1, -1, 1, 0>(W);                                    // :123
+    }
+    unsigned int m = 0;
+    if (t0 && mR != -1 && mU != -1) m |= 1u;
+    if (t1 && mR != -1 && mUR != -1 && mU != -1) m |= 2u;
+    if (t2 && mUR != -1 && mU != -1) m |= 4u;
+    if (t3 && mR != -1 && mUR != -1) m |= 8u;
+    return m;
+}
+
+// The same verdicts for a lane's 8 consecutive pixels of one row, with every edge evaluated once.  checkTriangleConstraints
+// accepts an edge when ANY of three differences is below the triangle's threshold (:35-56), and the three differences do not
+// depend on the direction the edge is walked in (walking B->A swaps the roles of the forward and the backward probe), so an
+// undirected edge has ONE metric = their minimum and passes for a triangle iff metric < that triangle's threshold.  The four
+// candidate triangles of a pixel share 5 edges (and the vertical one with the next pixel): 5 metrics per pixel instead
+// of 12 edge walks, no branches.  D: depth rows y-2 .. y+1, columns x0-1 .. x0+9; M: vertex indices of rows y-1, y.
+__device__ __forceinline__ int tri_threshold(int s) { return (272 * s + 2181900) / 300000; }   // :26, in integers
+
+// edge_metric with the probes pre-biased: Z = depth + 2^17 for a valid probe pixel, 2^30 for an invalid one (depth 0), so
+// that |x - probe| becomes one v_sad_u32 on non-negative operands and an invalid probe yields a difference no threshold
+// can reach -- no select per edge.  (2 vB - vA) + 2^17 and (2 vA - vB) + 2^17 lie in [65537, 262142].
+constexpr unsigned int kProbeBias = 1u << 17, kProbeInvalid = 1u << 30;
+
+__device__ __forceinline__ unsigned int abs_diff_u32(unsigned int a, unsigned int b)
+{
+    unsigned int r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));   // |a - b| in one VALU slot (the compiler has no pattern for it here)
+    return r;
+}
+
+__device__ __forceinline__ unsigned int edge_metric_biased(unsigned int vA, unsigned int vB, unsigned int zBeyondB, unsigned int zBeyondA)
+{
+    const unsigned int a = abs_diff_u32(vA, vB);                                         // |vB - vA|                 (:35)
+    const unsigned int f = abs_diff_u32(2u * vB + kProbeBias - vA, zBeyondB);            // |d - (beyondB - vB)|      (:39-47)
+    const unsigned int b = abs_diff_u32(2u * vA + kProbeBias - vB, zBeyondA);            // |d - (vA - beyondA)|      (:50-56)
+    return min(a, min(f, b));
+}
+
+__device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerLane + 3], const int (&M)[2][kPxPerLane + 1], int x0, int w)
+{
+    unsigned int Z[4][kPxPerLane + 3];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < kPxPerLane + 3; c++) Z[r][c] = D[r][c] != 0 ? (unsigned int)D[r][c] + kProbeBias : kProbeInvalid;
+    unsigned int ev[kPxPerLane + 1];   // P-U of window column c = 1 .. 9
+#pragma unroll
+    for (int c = 1; c <= kPxPerLane + 1; c++) ev[c - 1] = edge_metric_biased(D[2][c], D[1][c], Z[0][c], Z[3][c]);
+    unsigned int code = 0;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) {
+        const int c = k + 1, x = x0 + k;
+        const unsigned int vP = D[2][c], vU = D[1][c], vUR = D[1][c + 1], vR = D[2][c + 1];
+        const unsigned int hP = edge_metric_biased(vP, vR, Z[2][c + 2], Z[2][c - 1]);   // P - R
+        const unsigned int hU = edge_metric_biased(vU, vUR, Z[1][c + 2], Z[1][c - 1]);  // U - UR
+        const unsigned int d1 = edge_metric_biased(vU, vR, Z[3][c + 2], Z[0][c - 1]);   // U - R   (down-right)
+        const unsigned int d2 = edge_metric_biased(vP, vUR, Z[0][c + 2], Z[3][c - 1]);  // P - UR  (up-right)
+        const unsigned int pu = ev[c - 1], ru = ev[c];                                   // P - U, R - UR
+        const bool zP = vP != 0, zU = vU != 0, zUR = vUR != 0, zR = vR != 0;            // :22-23
+        const unsigned int sPR = vP + vR, sUUR = vU + vUR;
+        const unsigned int th0 = (unsigned int)tri_threshold((int)(sPR + vU)), th1 = (unsigned int)tri_threshold((int)(sUUR + vR));
+        const unsigned int th2 = (unsigned int)tri_threshold((int)(sUUR + vP)), th3 = (unsigned int)tri_threshold((int)(sPR + vUR));
+        const bool t0 = zR & zU & zP & (d1 < th0) & (pu < th0) & (hP < th0);            // R,U,P   (:117)
+        const bool t1 = zR & zUR & zU & (ru < th1) & (hU < th1) & (d1 < th1);           // R,UR,U  (:118)
+        const bool alt = !(t0 | t1);                                                    // :120
+        const bool t2 = alt & zP & zUR & zU & (d2 < th2) & (hU < th2) & (pu < th2);     // P,UR,U (:122)
+        const bool t3 = alt & zP & zR & zUR & (hP < th3) & (ru < th3) & (d2 < th3);     // P,R,UR (:123)
+        const bool mP = M[1][k] != -1, mU = M[0][k] != -1, mUR = M[0][k + 1] != -1, mR = M[1][k + 1] != -1;
+        const bool in_cols = (x >= 1) & (x < w - 2);                                    // :87-90
+        unsigned int m = 0;
+        m |= (t0 & mR & mU) ? 1u : 0u;                                                  // :133-134
+        m |= (t1 & mR & mUR & mU) ? 2u : 0u;
+        m |= (t2 & mUR & mU) ? 4u : 0u;
+        m |= (t3 & mR & mUR) ? 8u : 0u;
+        code |= ((in_cols & mP) ? m : 0u) << (4 * k);                                   // :113-114
+    }
+    return code;
+}
+
+// MODE 0 = count triangles per tile, 1 = write them at the scanned offsets.
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(kThreads) void tri_kernel(const TriArgs a)
+{
+    __shared__ int stage[MODE == 1 ? 3 * kTriWin : 1];
+    __shared__ int s_wave_tot[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tick = blockIdx.x / a.tiles_per_tick;
+    const int tile = blockIdx.x - tick * a.tiles_per_tick;
+    const TileDesc td = a.tiles[tile];
+    const FrameDesc fd = a.frames[td.frame];
+    const int w = fd.w, h = fd.h;
+    const unsigned short *dep = a.depth + tick * a.tick_pix_stride + fd.depth_off;
+    const int *map = a.pixmap + tick * a.tick_pix_stride + fd.depth_off;
+    const int p0 = (tile - fd.tile_start) * kTile + threadIdx.x * kPxPerLane;
+    const bool in_frame = p0 < fd.npix;
+
+    // (x, y) of the lane's first pixel, as in compute_tile
+    const int v = td.x0 + (int)threadIdx.x * kPxPerLane;
+    int q = (int)((float)v * fd.inv_w);
+    int x0 = v - q * w;
+    if (x0 < 0) { q--; x0 += w; }
+    if (x0 >= w) { q++; x0 -= w; }
+    int y0 = td.y0 + q;
+    if (!in_frame) { x0 = 0; y0 = 0; }
+
+    unsigned int code = 0;      // 4 bits per pixel: which triangles it emits
+    int M[2][kPxPerLane + 1];   // vertex indices: row y-1 (U, UR) and row y (P, R), columns x0 .. x0+8
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c <= kPxPerLane; c++) M[r][c] = -1;
+
+    const size_t code_slot = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (MODE == 1) {
+        // the count pass already evaluated every stencil: reload its verdicts, fetch only the vertex indices
+        code = a.codes[code_slot];
+        if (VEC && code != 0) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int *mrow = map + (long long)(y0 - 1 + r) * w + x0;
+                const int4 m0 = reinterpret_cast<const int4 *>(mrow)[0], m1 = reinterpret_cast<const int4 *>(mrow)[1];
+                M[r][0] = m0.x; M[r][1] = m0.y; M[r][2] = m0.z; M[r][3] = m0.w;
+                M[r][4] = m1.x; M[r][5] = m1.y; M[r][6] = m1.z; M[r][7] = m1.w;
+                M[r][8] = x0 + 8 < w ? mrow[8] : -1;
+            }
+        }
+    } else if (VEC) {
+        // w % 8 == 0: the 8 pixels share row y0; window rows y0-2 .. y0+1, columns x0-1 .. x0+9
+        const bool row_ok = in_frame && y0 >= 2 && y0 < h - 2;   // :87-90 (bands clamp to [2, h-2))
+        if (row_ok) {
+            int D[4][kPxPerLane + 3];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned short *row = dep + (long long)(y0 - 2 + r) * w;
+                const uint4 c = *reinterpret_cast<const uint4 *>(row + x0);
+                const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
+                D[r][0] = x0 > 0 ? row[x0 - 1] : 0;
+#pragma unroll
+                for (int k = 0; k < kPxPerLane; k++) D[r][1 + k] = (cw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                unsigned int right = 0;
+                if (x0 + 8 < w) right = *reinterpret_cast<const unsigned int *>(row + x0 + 8);
+                D[r][9] = right & 0xFFFFu;
+                D[r][10] = right >> 16;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int *mrow = map + (long long)(y0 - 1 + r) * w + x0;
+                const int4 m0 = reinterpret_cast<const int4 *>(mrow)[0], m1 = reinterpret_cast<const int4 *>(mrow)[1];
+                M[r][0] = m0.x; M[r][1] = m0.y; M[r][2] = m0.z; M[r][3] = m0.w;
+                M[r][4] = m1.x; M[r][5] = m1.y; M[r][6] = m1.z; M[r][7] = m1.w;
+                M[r][8] = x0 + 8 < w ? mrow[8] : -1;
+            }
+            code = lane_triangles(D, M, x0, w);
+        }
+    } else {
+        // general widths: a lane's pixels may span rows; every pixel fetches its own 4 x 4 window
+        int x = x0, y = y0;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            if (p0 + k < fd.npix && y >= 2 && y < h - 2 && x >= 1 && x < w - 2) {
+                int W[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) W[r][c] = dep[(long long)(y - 2 + r) * w + (x - 1 + c)];
+                const long long p = (long long)y * w + x;
+                M[1][k] = map[p];            // P
+                M[0][k] = map[p - w];        // U
+                // UR / R of this pixel are kept in the slots the VEC path would use only when they do not collide:
+                // the general path re-reads them at emission time instead (see below), the code word is what counts
+                code |= pixel_triangles(W, map[p], map[p - w], map[p - w + 1], map[p + 1]) << (4 * k);
+            }
+            x++;
+            if (x == w) { x = 0; y++; }
+        }
+    }
+
+    // ---- ranks ---------------------------------------------------------------------------------------------------
+    const int cnt = __popc(code);
+    const int incl = wave_inclusive_scan(cnt, lane);
+    if (lane == 63) s_wave_tot[wave] = incl;
+    int base = 0;
+    if (MODE == 1) base = a.tile_counts[blockIdx.x];
+    __syncthreads();
+    int wave_off = 0, tile_tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int t = s_wave_tot[i];
+        if (i < wave) wave_off += t;
+        tile_tot += t;
+    }
+    if (MODE == 0) {
+        a.codes[code_slot] = code;
+        if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = tile_tot;
+        return;
+    }
+
+    // ---- stage in rank order, copy out coalesced (triangles_shifts order, meshGenerator.cpp:101-104) ------------------
+    int *dst = a.tri + 3 * (tick * a.tick_tri_stride + base);
+    const int rank0 = wave_off + incl - cnt;
+    for (int w0 = 0; w0 < tile_tot; w0 += kTriWin) {
+        int r = rank0 - w0;
+        int x = x0, y = y0;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            const unsigned int m = (code >> (4 * k)) & 15u;
+            if (m) {
+                int mP, mU, mUR, mR;
+                if (VEC) {
+                    mP = M[1][k]; mU = M[0][k]; mUR = M[0][k + 1]; mR = M[1][k + 1];
+                } else {
+                    const long long p = (long long)y * w + x;
+                    mP = map[p]; mU = map[p - w]; mUR = map[p - w + 1]; mR = map[p + 1];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (m & (1u << i)) {
+                        if ((unsigned int)r < (unsigned int)kTriWin) {
+                            const int i0 = i == 0 ? mR : (i == 1 ? mR : mP);
+                            const int i1 = i == 0 ? mU : (i == 1 ? mUR : (i == 2 ? mUR : mR));
+                            const int i2 = i == 0 ? mP : (i == 1 ? mU : (i == 2 ? mU : mUR));
+                            stage[3 * r] = i0;
+                            stage[3 * r + 1] = i1;
+                            stage[3 * r + 2] = i2;
+                        }
+                        r++;
+                    }
+                }
+            }
+            if (!VEC) {
+                x++;
+                if (x == w) { x = 0; y++; }
+            }
+        }
+        __syncthreads();
+        const int n = 3 * min(kTriWin, tile_tot - w0);
+        for (int i = threadIdx.x; i < n; i += kThreads) __builtin_nontemporal_store(stage[i], &dst[3 * w0 + i]);   // written once
+        __syncthreads();
+    }
+}
+
+
+}  // namespace
+
+extern "C" long long lsnFusionTickTriangleCapacity(const LsnFusion *p) { return p ? 2 * p->cap : 0; }
+
+extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+                                void *d_triangles, int *d_tri_offsets, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !d_triangles || !d_tri_offsets) {
+        lsn::set_error("lsnFusionRunMesh: null argument");
+        return -1;
+    }
+    {
+        std::lock_guard<std::mutex> g(p->mu);
+        LSN_HIP(hipSetDevice(p->device));
+        if (p->pixmap.reserve(sizeof(int) * (size_t)p->cap * p->n_ticks) ||
+            p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks) ||
+            p->tri_codes.reserve(sizeof(unsigned int) * (size_t)p->tiles_per_tick * p->n_ticks * kThreads))
+            return -1;
+        p->want_pixmap = true;
+    }
+    // vertices + depth_to_vertices_map (count / scan / write launches)
+    const int rc = lsnFusionRun(p, d_depth, d_colors, d_vertices, d_offsets, stream);
+    std::lock_guard<std::mutex> g(p->mu);
+    p->want_pixmap = false;
+    if (rc) return rc;
+    hipStream_t s = lsn::as_stream(stream);
+    TriArgs t;
+    t.frames = p->frames.as<FrameDesc>();
+    t.tiles = p->tile_frame.as<TileDesc>();
+    t.depth = static_cast<const unsigned short *>(d_depth);
+    t.pixmap = p->pixmap.as<int>();
+    t.tri = static_cast<int *>(d_triangles);
+    t.tile_counts = p->tri_counts.as<int>();
+    t.codes = p->tri_codes.as<unsigned int>();
+    t.tiles_per_tick = p->tiles_per_tick;
+    t.tick_pix_stride = p->cap;
+    t.tick_tri_stride = 2 * p->cap;
+    const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && (p->tick_depth_elems % 8) == 0;
+    const int grid = p->tiles_per_tick * p->n_ticks;
+    if (vec) hipLaunchKernelGGL((tri_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, t);
+    else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, t.tile_counts, t.tiles_per_tick, t.frames, p->n_maps,
+                       d_tri_offsets);
+    if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), 0, s, t);
+    else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), 0, s, t);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+

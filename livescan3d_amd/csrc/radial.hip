@@ -1,0 +1,437 @@
+// radial.hip -- depthMapAndColorSetRadialCorrection: forward warp + raster-order hole closing, lsnFusionRadialCorrect.
+// Shares the plan of fusion.hip (fusion_shared.hpp).
+#include "fusion_shared.hpp"
+
+namespace {
+
+// ---- radial correction (the step before the fusion path on every tick) ---------------------------------------------
+//
+// Replaces depthMapAndColorRadialCorrection (src/NativeUtils/depthprocessing.cpp:191-261) and its export (:1794-1815):
+//   1. forward warp of every valid pixel to (x_corr, y_corr); the reference's raster-order loop lets the LAST source
+//      pixel win a collision -> atomicMax of the source index per destination, then a gather;
+//   2. hole closing, which the reference does IN PLACE in raster order: a pixel filled earlier in the pass is seen by
+//      its right / lower neighbours.  Those dependencies (left, up-left, up, up-right) are honoured exactly by a skewed
+//      wavefront: one thread per row, row y runs two columns behind row y-1, one workgroup barrier per step.
+// All arithmetic in the reference's order (contraction off); (int) follows the x86-64 cvttss2si the reference is built
+// with: NaN / out-of-range -> INT_MIN, which then fails the >= 0 test.
+
+struct RadialParams { float cx, cy, fx, fy, r2, r4, r6, pad; };
+
+__device__ __forceinline__ int f2i_x86(float v)
+{
+    return (v > -2147483904.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+}
+
+__global__ __launch_bounds__(kThreads) void radial_warp_kernel(const FrameDesc *frames, const TileDesc *tiles, const RadialParams *rp,
+                                                               const unsigned short *depth, unsigned int *winner, int tiles_per_tick,
+                                                               long long tick_pix_stride)
+{
+    const int tick = blockIdx.x / tiles_per_tick;
+    const int tile = blockIdx.x - tick * tiles_per_tick;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const RadialParams P = rp[td.frame];
+    const unsigned short *dep = depth + tick * tick_pix_stride + fd.depth_off;
+    unsigned int *win = winner + tick * tick_pix_stride + fd.depth_off;
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {  // consecutive lanes -> consecutive pixels
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        if (dep[p] == 0) continue;                                             // :202-203
+        const int y = p / fd.w, x = p - y * fd.w;
+        const float u = ((float)x - P.cx) / P.fx;                              // :204
+        const float v = ((float)y - P.cy) / P.fy;                              // :205
+        const float r = u * u + v * v;                                         // :206
+        const float d = 1 - P.r2 * r - P.r4 * r * r - P.r6 * r * r * r;        // :207
+        const int x_corr = f2i_x86(u * d * P.fx + P.cx);                       // :209
+        const int y_corr = f2i_x86(v * d * P.fy + P.cy);                       // :210
+        if (x_corr >= 0 && y_corr >= 0 && x_corr < fd.w && y_corr < fd.h)      // :212
+            atomicMax(&win[x_corr + (long long)y_corr * fd.w], (unsigned int)p + 1u);  // later source pixel wins (:214-215)
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void radial_gather_kernel(const FrameDesc *frames, const TileDesc *tiles, const unsigned short *depth,
+                                                                 const unsigned char *rgb, const unsigned int *winner,
+                                                                 unsigned short *map_copy, unsigned char *colors_copy, int tiles_per_tick,
+                                                                 long long tick_pix_stride)
+{
+    const int tick = blockIdx.x / tiles_per_tick;
+    const int tile = blockIdx.x - tick * tiles_per_tick;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const long long fb = tick * tick_pix_stride + fd.depth_off;
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        const unsigned int wsrc = winner[fb + p];
+        unsigned short d = 0;
+        unsigned char c0 = 0, c1 = 0, c2 = 0;
+        if (wsrc) {
+            const long long s = fb + (long long)(wsrc - 1u);
+            d = depth[s];
+            c0 = rgb[3 * s]; c1 = rgb[3 * s + 1]; c2 = rgb[3 * s + 2];
+        }
+        map_copy[fb + p] = d;
+        colors_copy[3 * (fb + p)] = c0;
+        colors_copy[3 * (fb + p) + 1] = c1;
+        colors_copy[3 * (fb + p) + 2] = c2;
+    }
+}
+
+// The warp target of a pixel depends on the intrinsics only, not on the depth values: per calibration, every destination
+// pixel gets the (at most four) source pixels that map onto it, highest index first -- the reference's raster-order loop
+// lets the LAST valid source win (:200-218).  A tick then needs no atomics, no winner array and no memset: the corrected
+// pixel is the first candidate whose depth is not zero.  Destinations with more than four sources (a pathologically
+// contracting calibration) raise the overflow flag and the batch takes the atomicMax path above instead.
+__global__ __launch_bounds__(kThreads) void radial_cand_fill_kernel(const FrameDesc *frames, const TileDesc *tiles, const RadialParams *rp,
+                                                                    unsigned int *count, unsigned int *cand, int *overflow)
+{
+    const int tile = blockIdx.x;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const RadialParams P = rp[td.frame];
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        const int y = p / fd.w, x = p - y * fd.w;
+        const float u = ((float)x - P.cx) / P.fx;                              // :204
+        const float v = ((float)y - P.cy) / P.fy;                              // :205
+        const float r = u * u + v * v;                                         // :206
+        const float d = 1 - P.r2 * r - P.r4 * r * r - P.r6 * r * r * r;        // :207
+        const int x_corr = f2i_x86(u * d * P.fx + P.cx);                       // :209
+        const int y_corr = f2i_x86(v * d * P.fy + P.cy);                       // :210
+        if (x_corr >= 0 && y_corr >= 0 && x_corr < fd.w && y_corr < fd.h) {    // :212
+            const long long dst = fd.depth_off + x_corr + (long long)y_corr * fd.w;
+            const unsigned int slot = atomicAdd(&count[dst], 1u);
+            if (slot < 4) cand[4 * dst + slot] = (unsigned int)p + 1u;
+            else atomicOr(overflow, 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void radial_cand_sort_kernel(uint4 *cand, long long n)
+{
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    uint4 c = cand[i];
+    // descending, empty slots (0) last: a 4-element sorting network
+    auto cswap = [](unsigned int &a, unsigned int &b) { const unsigned int hi = max(a, b), lo = min(a, b); a = hi; b = lo; };
+    cswap(c.x, c.y); cswap(c.z, c.w); cswap(c.x, c.z); cswap(c.y, c.w); cswap(c.y, c.z);
+    cand[i] = c;
+}
+
+__global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const FrameDesc *frames, const TileDesc *tiles, const unsigned short *depth,
+                                                                      const unsigned char *rgb, const uint4 *cand, unsigned short *map_copy,
+                                                                      unsigned char *colors_copy, int tiles_per_tick, long long tick_pix_stride)
+{
+    const int tick = blockIdx.x / tiles_per_tick;
+    const int tile = blockIdx.x - tick * tiles_per_tick;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const long long fb = tick * tick_pix_stride + fd.depth_off;
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        const uint4 c = cand[fd.depth_off + p];
+        // all four candidate depths are fetched at once (independent loads); the first non-zero one wins
+        const unsigned short d0 = c.x ? depth[fb + (c.x - 1u)] : 0, d1 = c.y ? depth[fb + (c.y - 1u)] : 0;
+        const unsigned short d2 = c.z ? depth[fb + (c.z - 1u)] : 0, d3 = c.w ? depth[fb + (c.w - 1u)] : 0;
+        unsigned int src = 0;
+        unsigned short d = 0;
+        if (d0) { src = c.x; d = d0; }
+        else if (d1) { src = c.y; d = d1; }
+        else if (d2) { src = c.z; d = d2; }
+        else if (d3) { src = c.w; d = d3; }
+        unsigned char c0 = 0, c1 = 0, c2 = 0;
+        if (src) {
+            const long long sidx = fb + (long long)(src - 1u);
+            c0 = rgb[3 * sidx]; c1 = rgb[3 * sidx + 1]; c2 = rgb[3 * sidx + 2];
+        }
+        map_copy[fb + p] = d;
+        colors_copy[3 * (fb + p)] = c0;
+        colors_copy[3 * (fb + p) + 1] = c1;
+        colors_copy[3 * (fb + p) + 2] = c2;
+    }
+}
+
+// One workgroup per sensor-frame, one thread per row (bands of blockDim rows when h is larger).  At step t the thread of
+// row y handles column x = 1 + t - 2 (y - band0): the pixels it reads from row y-1 (x-1, x, x+1) were finished at least
+// one barrier ago, its own left neighbour one step ago, everything to the right and below is still original -- exactly
+// the state the reference's raster-order in-place loop sees (:223-256).
+// Everything a step touches lives in LDS rings of 32 columns per row (4 chunks of 8; u16 depth and packed RGB): a row's
+// thread streams its row through the rings two chunks ahead of where it works (the global loads are issued 8 steps
+// before their data is needed) and overwrites a slot when it fills a hole, so the row below reads finals, the row above
+// reads originals, no step waits for global memory, and the step barrier only has to order LDS traffic.  Filled pixels
+// are also stored to the global maps, fire-and-forget.
+constexpr int kRing = 32;
+
+struct RingChunk { unsigned int d[4]; unsigned int c[8]; };  // 8 pixels: depth u16 x 8, colour 0x00BBGGRR x 8
+
+// Loads chunk `chunk` (columns 8 chunk .. 8 chunk + 7) of `row`; anything outside the frame reads as 0.
+__device__ __forceinline__ void ring_load_chunk(const unsigned short *map, const unsigned char *col, int w, int h, int row, int chunk,
+                                                RingChunk &reg)
+{
+    const bool row_ok = row >= 0 && row < h;
+    if ((w & 7) == 0) {
+        // aligned rows: one 16-B depth load and 24 B of colour (three 8-B loads)
+        uint4 dv = make_uint4(0, 0, 0, 0);
+        uint2 c0 = make_uint2(0, 0), c1 = c0, c2 = c0;
+        if (row_ok && chunk >= 0 && chunk * 8 < w) {
+            const long long p = (long long)row * w + chunk * 8;
+            dv = *reinterpret_cast<const uint4 *>(map + p);
+            const uint2 *cp = reinterpret_cast<const uint2 *>(col + 3 * p);
+            c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
+        }
+        reg.d[0] = dv.x; reg.d[1] = dv.y; reg.d[2] = dv.z; reg.d[3] = dv.w;
+        const unsigned int cw[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = 3 * j;
+            const unsigned int lo = cw[b >> 2], hi = cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
+            reg.c[j] = __funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c0 = chunk * 8 + j;
+        unsigned int dv = 0, cv = 0;
+        if (row_ok && c0 >= 0 && c0 < w) {
+            const long long p = (long long)row * w + c0;
+            dv = map[p];
+            cv = col[3 * p] | (col[3 * p + 1] << 8) | (col[3 * p + 2] << 16);
+        }
+        if (j & 1) reg.d[j >> 1] |= dv << 16;
+        else reg.d[j >> 1] = dv;
+        reg.c[j] = cv;
+    }
+}
+
+__device__ __forceinline__ void ring_store_chunk(unsigned short *dring_row, unsigned int *cring_row, int chunk, const RingChunk &reg)
+{
+    const int s0 = (chunk * 8) & (kRing - 1);
+    unsigned int *dd = reinterpret_cast<unsigned int *>(dring_row + s0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) dd[j] = reg.d[j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) cring_row[s0 + j] = reg.c[j];
+}
+
+// A streamed row: its ring slot and the two chunks in flight.
+struct RingFeed {
+    int ring, row;
+    RingChunk p0, p1;
+};
+
+__global__ __launch_bounds__(768) void radial_close_kernel(const FrameDesc *frames, int n_frames, unsigned short *map_copy,
+                                                            unsigned char *colors_copy, long long tick_pix_stride)
+{
+    extern __shared__ unsigned int ring_mem[];  // colours: (blockDim.x + 2) x kRing u32, then depths: the same count of u16
+    const int rows = blockDim.x;
+    unsigned int *cring = ring_mem;
+    unsigned short *dring = reinterpret_cast<unsigned short *>(ring_mem + (rows + 2) * kRing);
+    const int tick = blockIdx.x / n_frames;
+    const int f = blockIdx.x - tick * n_frames;
+    const FrameDesc fd = frames[f];
+    const int w = fd.w, h = fd.h;
+    unsigned short *map = map_copy + tick * tick_pix_stride + fd.depth_off;
+    unsigned char *col = colors_copy + 3 * (tick * tick_pix_stride + fd.depth_off);
+    const int r = threadIdx.x;
+    for (int band0 = 1; band0 < h - 1; band0 += rows) {
+        const int y = band0 + r;
+        // Rows this thread streams through the rings (two named feeds, no runtime-indexed arrays -- those would live in
+        // scratch memory): A = its own row (ring index r + 1); B = a ghost row: the row above the band for thread 0
+        // (index 0), the row below it for the last thread (index rows + 1).
+        const bool has_a = y <= h - 1;
+        const bool has_b = (r == 0) || (r == rows - 1);
+        RingFeed A, B;
+        A.ring = r + 1; A.row = y;
+        B.ring = r == 0 ? 0 : rows + 1; B.row = r == 0 ? band0 - 1 : y + 1;
+        // Every 16 steps ALL lanes publish the two chunks they fetched 16 steps earlier and fetch the next two, so the
+        // wave's global loads are consumed a full round after they were issued.  During the round that starts at column
+        // x0 the neighbours touch columns x0 - 3 .. x0 + 18 of this row: chunks (x0 - 3) >> 3 .. (x0 + 18) >> 3, at most
+        // four -- exactly the ring.
+        const int x_start = 1 - 2 * r;
+        auto top_chunk = [](int x0) { return (x0 + 18) >> 3; };  // arithmetic shift: floor for negative columns too
+        __syncthreads();  // the previous band is done with the rings (and its fills have reached the global maps)
+        {
+            const int P = top_chunk(x_start);
+            if (has_a) {
+                for (int c = P - 3; c <= P; c++) {
+                    ring_load_chunk(map, col, w, h, A.row, c, A.p0);
+                    ring_store_chunk(dring + A.ring * kRing, cring + A.ring * kRing, c, A.p0);
+                }
+                ring_load_chunk(map, col, w, h, A.row, P + 1, A.p0);
+                ring_load_chunk(map, col, w, h, A.row, P + 2, A.p1);
+            }
+            if (has_b) {
+                for (int c = P - 3; c <= P; c++) {
+                    ring_load_chunk(map, col, w, h, B.row, c, B.p0);
+                    ring_store_chunk(dring + B.ring * kRing, cring + B.ring * kRing, c, B.p0);
+                }
+                ring_load_chunk(map, col, w, h, B.row, P + 1, B.p0);
+                ring_load_chunk(map, col, w, h, B.row, P + 2, B.p1);
+            }
+        }
+        __syncthreads();
+        const unsigned short *d_up = dring + r * kRing, *d_below = dring + (r + 2) * kRing;
+        unsigned short *d_mine = dring + (r + 1) * kRing;
+        const unsigned int *c_up = cring + r * kRing, *c_below = cring + (r + 2) * kRing;
+        unsigned int *c_mine = cring + (r + 1) * kRing;
+        const int steps = (w - 2) + 2 * (rows - 1);
+        for (int t = 0; t < steps; t++) {
+            const int x = x_start + t;
+            if (t > 0 && (t & 15) == 0) {  // uniform over the workgroup
+                const int P = top_chunk(x);
+                if (has_a) {
+                    ring_store_chunk(dring + A.ring * kRing, cring + A.ring * kRing, P - 1, A.p0);
+                    ring_store_chunk(dring + A.ring * kRing, cring + A.ring * kRing, P, A.p1);
+                    ring_load_chunk(map, col, w, h, A.row, P + 1, A.p0);
+                    ring_load_chunk(map, col, w, h, A.row, P + 2, A.p1);
+                }
+                if (has_b) {
+                    ring_store_chunk(dring + B.ring * kRing, cring + B.ring * kRing, P - 1, B.p0);
+                    ring_store_chunk(dring + B.ring * kRing, cring + B.ring * kRing, P, B.p1);
+                    ring_load_chunk(map, col, w, h, B.row, P + 1, B.p0);
+                    ring_load_chunk(map, col, w, h, B.row, P + 2, B.p1);
+                }
+                // the new chunks must be in place before any neighbour reads them in this very step
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            }
+            if (y < h - 1 && x >= 1 && x < w - 1 && d_mine[x & (kRing - 1)] == 0) {        // :229-234
+                const int xm = (x - 1) & (kRing - 1), x0 = x & (kRing - 1), xp = (x + 1) & (kRing - 1);
+                const int nb[8] = {d_up[xm], d_up[x0], d_up[xp], d_mine[xm], d_mine[xp], d_below[xm], d_below[x0], d_below[xp]};
+                // the acceptance chain of :241-248, branch-free: lane-mask logic and selects instead of eight nested branches
+                int n = 0, sum = 0, prev_val = -1;
+                unsigned int accepted = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const bool ok = (nb[i] > 0) & ((prev_val == -1) | (abs(nb[i] - prev_val) < 30));  // :241
+                    prev_val = ok ? nb[i] : prev_val;
+                    n += ok ? 1 : 0;
+                    sum += ok ? nb[i] : 0;
+                    accepted |= (ok ? 1u : 0u) << i;
+                }
+                if (n > 4) {                                                                // :250-256
+                    const unsigned int nc[8] = {c_up[xm], c_up[x0], c_up[xp], c_mine[xm], c_mine[xp], c_below[xm], c_below[x0], c_below[xp]};
+                    int sR = 0, sG = 0, sB = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const unsigned int c = (accepted >> i) & 1u ? nc[i] : 0u;
+                        sR += c & 0xFF; sG += (c >> 8) & 0xFF; sB += (c >> 16) & 0xFF;
+                    }
+                    // n is 5..8 and the sums stay below 2^20: a float reciprocal and one correction step divide exactly
+                    const float rn = 1.0f / (float)n;
+                    auto div_n = [&](int v) {
+                        int q = (int)((float)v * rn);
+                        const int r = v - q * n;
+                        q += r >= n ? 1 : 0;
+                        q -= r < 0 ? 1 : 0;
+                        return (unsigned int)q;
+                    };
+                    const unsigned int fd_ = div_n(sum);
+                    const unsigned int fR = div_n(sR), fG = div_n(sG), fB = div_n(sB);
+                    d_mine[x0] = (unsigned short)fd_;
+                    c_mine[x0] = fR | (fG << 8) | (fB << 16);
+                    const long long pos = x + (long long)y * w;
+                    map[pos] = (unsigned short)fd_;
+                    col[pos * 3] = (unsigned char)fR;
+                    col[pos * 3 + 1] = (unsigned char)fG;
+                    col[pos * 3 + 2] = (unsigned char)fB;
+                }
+            }
+            // Step barrier on LDS traffic only: a plain __syncthreads() would also wait for the chunk prefetches and
+            // the fire-and-forget fills (a global round trip per step).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, void *d_depth, void *d_colors, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !intr_params || !d_depth || !d_colors) {
+        lsn::set_error("lsnFusionRadialCorrect: null argument");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    hipStream_t s = lsn::as_stream(stream);
+    const size_t npix = (size_t)p->cap * p->n_ticks;
+    if (p->winner.reserve(4 * npix) || p->map_copy.reserve(2 * npix) || p->colors_copy.reserve(3 * npix) ||
+        p->radial.reserve(sizeof(RadialParams) * p->n_maps))
+        return -1;
+    std::vector<RadialParams> rp(p->n_maps);
+    for (int i = 0; i < p->n_maps; i++) {
+        const float *ip = intr_params + 7 * i;  // IntrinsicCameraParameters(float*), include/NativeUtils/depthprocessing.h:96-97
+        rp[i] = RadialParams{ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], 0.0f};
+    }
+    const int grid = p->tiles_per_tick * p->n_ticks;
+    const bool same_intr = p->cand_valid && p->radial_intr.size() == 7 * (size_t)p->n_maps &&
+                           memcmp(p->radial_intr.data(), intr_params, sizeof(float) * 7 * p->n_maps) == 0;
+    if (!same_intr) {
+        LSN_HIP(hipMemcpyAsync(p->radial.p, rp.data(), sizeof(RadialParams) * p->n_maps, hipMemcpyHostToDevice, s));
+        LSN_HIP(hipStreamSynchronize(s));  // rp is a local
+        // the warp candidates of this calibration (one tick's worth of pixels; `winner` serves as the per-destination counter)
+        if (p->cand.reserve(16 * (size_t)p->cap)) return -1;
+        LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * (size_t)p->cap, s));
+        LSN_HIP(hipMemsetAsync(p->cand.p, 0, 16 * (size_t)p->cap, s));
+        LSN_HIP(hipMemsetAsync(p->misc.as<char>() + 64, 0, sizeof(int), s));
+        int *overflow = reinterpret_cast<int *>(p->misc.as<char>() + 64);
+        hipLaunchKernelGGL(radial_cand_fill_kernel, dim3(p->tiles_per_tick), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(),
+                           p->tile_frame.as<TileDesc>(), p->radial.as<RadialParams>(), p->winner.as<unsigned int>(), p->cand.as<unsigned int>(), overflow);
+        hipLaunchKernelGGL(radial_cand_sort_kernel, dim3((unsigned)((p->cap + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p->cand.as<uint4>(),
+                           p->cap);
+        int ov = 0;
+        LSN_HIP(hipMemcpyAsync(&ov, overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+        LSN_HIP(hipStreamSynchronize(s));
+        p->cand_overflow = ov != 0;
+        p->radial_intr.assign(intr_params, intr_params + 7 * (size_t)p->n_maps);
+        p->cand_valid = true;
+    }
+    const char *force = getenv("LSN_RADIAL_FORCE_ATOMIC");  // tests: take the atomicMax path even when the table did not overflow
+    if (!p->cand_overflow && !(force && atoi(force) != 0)) {
+        hipLaunchKernelGGL(radial_gather_cand_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                           static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors), (const uint4 *)p->cand.as<uint4>(),
+                           p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->tiles_per_tick, p->cap);
+    } else {
+        LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * npix, s));
+        hipLaunchKernelGGL(radial_warp_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                           p->radial.as<RadialParams>(), static_cast<const unsigned short *>(d_depth), p->winner.as<unsigned int>(),
+                           p->tiles_per_tick, p->cap);
+        hipLaunchKernelGGL(radial_gather_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                           static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors),
+                           (const unsigned int *)p->winner.as<unsigned int>(), p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(),
+                           p->tiles_per_tick, p->cap);
+    }
+    int max_h = 1;
+    for (int v : p->h) max_h = v > max_h ? v : max_h;
+    int rows = max_h - 2 < 64 ? 64 : ((max_h - 2 + 63) / 64) * 64;
+    if (rows > 768) rows = 768;  // (rows + 2) x 32 columns x 6 B of LDS rings must fit in 160 KB
+    // One band per frame is the shortest chain of steps, but (rows + 2) x 192 B of LDS per workgroup then allows a single
+    // frame per CU.  With more frames than CUs, 256-row bands (49.5 KB: three frames per CU) win: 2.75 vs 3.37 ms for
+    // 512 frames of 512x424 on MI355X.
+    if ((long long)p->n_maps * p->n_ticks > 256 && rows > 256) rows = 256;
+    if (const char *env = getenv("LSN_RADIAL_ROWS")) {  // tuning: rows per band (multiple of 64, <= 768)
+        const int v = atoi(env);
+        if (v >= 64 && v <= 768 && v % 64 == 0) rows = v;
+    }
+    hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)(p->n_maps * p->n_ticks)), dim3(rows), (sizeof(unsigned int) + sizeof(unsigned short)) * kRing * (rows + 2), s,
+                       p->frames.as<FrameDesc>(), p->n_maps,
+                       p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap);
+    LSN_HIP(hipGetLastError());
+    // :259-260 the corrected maps replace the inputs
+    LSN_HIP(hipMemcpyAsync(d_depth, p->map_copy.p, 2 * npix, hipMemcpyDeviceToDevice, s));
+    LSN_HIP(hipMemcpyAsync(d_colors, p->colors_copy.p, 3 * npix, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
