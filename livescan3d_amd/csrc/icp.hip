@@ -416,6 +416,15 @@ __global__ __launch_bounds__(kThreads) void nn_grid_kernel(const float *queries,
                 best_i = k;
             }
         }
+        // A candidate farther than a cell edge cannot be proven by the 27 cells around the query whatever they hold, so
+        // the query goes to the far pass at once: that pass scans every block that can hold something nearer anyway.
+        const float seed_bound = g.h * kBoundSlack;
+        if (best < INFINITY && best > seed_bound * seed_bound) {
+            idx[i] = best_i;
+            dist[i] = best;
+            far_list[atomicAdd(n_far, 1)] = i;
+            return;
+        }
     }
     // This kernel is a chain of dependent memory round trips per query, not arithmetic: fetch all 27 cell ranges at once
     // (54 independent loads in flight), then walk them with the point loads issued four at a time.
