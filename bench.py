@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--sensors", type=int, default=8, help="streams per tick (north-star target: 8 x 512x424)")
     ap.add_argument("--ticks", type=int, default=64, help="ticks fused per step (one launch sequence)")
     ap.add_argument("--width", type=int, default=512)
