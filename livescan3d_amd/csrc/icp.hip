@@ -26,6 +26,7 @@
 // This file is compiled with -ffp-contract=off.
 #include "lsn_common.hpp"
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -39,8 +40,8 @@ constexpr int kScanBlock = kThreads * kScanItems;  // 4096
 constexpr int kSuper = 16;            // cells per super-block edge
 constexpr int kMaxSupers = kMaxCells / (kSuper * kSuper * kSuper);  // 1024
 constexpr int kMaxBlocks3 = kMaxCells / 64;                          // 4^3-cell blocks
-constexpr float kBoundSlack = 0.999f; // shrinks the geometric bound: covers the rounding of the cell arithmetic
 constexpr int kBfTile = 1024;         // targets per LDS tile in the brute-force kernel
+constexpr int kSeedBlocks = 4;        // blocks nearest to a query patch that are scanned first when it has no candidates yet
 
 struct GridParams {
     float ox, oy, oz;   // origin (bbox min)
@@ -148,16 +149,6 @@ __device__ __forceinline__ float box_min_dist2(float qx, float qy, float qz, con
     const float dy = fmaxf(0.0f, fmaxf(b.ly - qy, qy - b.hy));
     const float dz = fmaxf(0.0f, fmaxf(b.lz - qz, qz - b.hz));
     return dx * dx + dy * dy + dz * dz;
-}
-
-// Upper bound of the NN distance offered by a non-empty box: its farthest corner (every box holds >= 1 point).
-__device__ __forceinline__ float box_max_dist2(float qx, float qy, float qz, const Box &b)
-{
-    const float dx = fmaxf(fabsf(qx - b.lx), fabsf(qx - b.hx));
-    const float dy = fmaxf(fabsf(qy - b.ly), fabsf(qy - b.hy));
-    const float dz = fmaxf(fabsf(qz - b.lz), fabsf(qz - b.hz));
-    const float d = dx * dx + dy * dy + dz * dz;
-    return b.lx <= b.hx ? d * 1.0001f : INFINITY;  // slack: the bound is only used to prune, never reported
 }
 
 // ---- grid build -----------------------------------------------------------------------------------------------
@@ -332,23 +323,35 @@ __global__ __launch_bounds__(kThreads) void cell_scatter_kernel(const float *pts
 
 // ---- nearest neighbour ----------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void claim_target(unsigned long long *keys, int k, float d, int i)
+// The claims of a whole workgroup.  In a scene most queries of a patch share a handful of targets (the rim of the other
+// sensor's surface): one global atomicMin per query then piles thousands of atomics onto single addresses, which the L2
+// serialises (measured: 100 us for 108 k claims).  The workgroup therefore first combines its claims in LDS -- a
+// direct-mapped table of kClaimSlots (target, smallest key) pairs filled with LDS atomics; a query whose slot is taken by
+// another target claims in global memory directly -- and then issues one global atomicMin per occupied slot, skipped
+// when the target's key is already smaller.  Same result: a minimum of minima.  Must be reached by every thread.
+constexpr int kClaimSlots = 1024;
+__device__ __forceinline__ void claim_targets(unsigned long long *keys, bool active, int k, float d, int i, int *slot_k, unsigned long long *slot_v)
 {
-    // icp.cpp:95-126: smallest distance keeps the target; on equal distance the later source index replaces
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)i);
-    atomicMin(&keys[k], key);
-}
-
-__device__ __forceinline__ void scan_range(const float4 *sorted, int s, int e, float qx, float qy, float qz, float &best,
-                                           int &best_i)
-{
-    for (int j = s; j < e; j++) {
-        const float4 p = sorted[j];
-        const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
-        const int k = __float_as_int(p.w);
-        if (d < best || (d == best && k < best_i)) {
-            best = d;
-            best_i = k;
+    for (int t = threadIdx.x; t < kClaimSlots; t += kThreads) {
+        slot_k[t] = -1;
+        slot_v[t] = ~0ull;
+    }
+    __syncthreads();
+    if (active) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)i);
+        const int slot = k & (kClaimSlots - 1);
+        const int owner = atomicCAS(&slot_k[slot], -1, k);
+        if (owner == -1 || owner == k)
+            atomicMin(&slot_v[slot], key);
+        else if (keys[k] > key)
+            atomicMin(&keys[k], key);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kClaimSlots; t += kThreads) {
+        const int tk = slot_k[t];
+        if (tk >= 0) {
+            const unsigned long long v = slot_v[t];
+            if (keys[tk] > v) atomicMin(&keys[tk], v);
         }
     }
 }
@@ -370,6 +373,9 @@ __global__ __launch_bounds__(kThreads) void block_box_kernel(const GridParams *g
             bx.lx = wave_min_f(bx.lx); bx.ly = wave_min_f(bx.ly); bx.lz = wave_min_f(bx.lz);
             bx.hx = wave_max_f(bx.hx); bx.hy = wave_max_f(bx.hy); bx.hz = wave_max_f(bx.hz);
         }
+        // the point range rides in the two spare words: one 32-byte load per block in the query kernel
+        bx.pad0 = __int_as_float(s);
+        bx.pad1 = __int_as_float(e);
         if (lane == 0) boxes[b] = bx;
     }
 }
@@ -387,298 +393,598 @@ __global__ __launch_bounds__(64) void super_box_kernel(const GridParams *gp, con
     if (threadIdx.x == 0) supers[s] = r;
 }
 
-// One thread per query: scan the 27 cells around the (clamped) query cell.  Every unscanned target sits in a cell at
-// Chebyshev distance >= 2, i.e. at least one cell edge h away, so the answer is final once best <= (h * slack)^2
-// (slack covers the rounding of the cell arithmetic).  Otherwise the query joins the far list, carrying what it found.
-__global__ __launch_bounds__(kThreads) void nn_grid_kernel(const float *queries, int n2, const GridParams *gp, const int *cell_start,
-                                                           const float4 *sorted, int *idx, float *dist, unsigned long long *keys,
-                                                           int *far_list, int *n_far, const float *seed_targets, int n1)
+// Lower bound of dist2(q, p) for EVERY q inside the query box W = [wl, wh] and every p inside b, evaluated with the same
+// operations as box_min_dist2: q <= wh gives b.l - wh <= b.l - q exactly, rounding is monotone, so the per-axis gap never
+// exceeds the one box_min_dist2 computes for any q of W, and the squares and sums keep the order.  Empty boxes
+// (lo = +inf, hi = -inf) come out as +inf.
+__device__ __forceinline__ float boxbox_min_dist2(float wlx, float wly, float wlz, float whx, float why, float whz, const Box &b)
 {
-    const GridParams g = *gp;
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n2) return;
-    const float qx = queries[3 * (size_t)i], qy = queries[3 * (size_t)i + 1], qz = queries[3 * (size_t)i + 2];
-    const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx);
-    const int cy = cell_coord(qy, g.oy, g.inv_h, g.ny);
-    const int cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
-    float best = INFINITY;
-    int best_i = 0x7FFFFFFF;
-    if (seed_targets) {
-        // ICP iterations after the first: the query moved a little, so its previous neighbour (idx[i], a real target
-        // point) is an excellent candidate.  Starting from it changes nothing in the result -- the answer is still the
-        // lexicographic (distance, index) minimum over every point that is not provably farther -- but the far pass
-        // begins with a tight bound and prunes almost the whole hierarchy at once.
-        const int k = idx[i];
-        if ((unsigned int)k < (unsigned int)n1) {
-            const float d = dist2(qx, qy, qz, seed_targets[3 * (size_t)k], seed_targets[3 * (size_t)k + 1], seed_targets[3 * (size_t)k + 2]);
-            if (d == d) {  // not NaN
-                best = d;
-                best_i = k;
-            }
-        }
-        // A candidate farther than a cell edge cannot be proven by the 27 cells around the query whatever they hold, so
-        // the query goes to the far pass at once: that pass scans every block that can hold something nearer anyway.
-        const float seed_bound = g.h * kBoundSlack;
-        if (best < INFINITY && best > seed_bound * seed_bound) {
-            idx[i] = best_i;
-            dist[i] = best;
-            far_list[atomicAdd(n_far, 1)] = i;
-            return;
-        }
-    }
-    // This kernel is a chain of dependent memory round trips per query, not arithmetic: fetch all 27 cell ranges at once
-    // (54 independent loads in flight), then walk them with the point loads issued four at a time.
-    int rs[27], re[27];
-#pragma unroll
-    for (int k = 0; k < 27; k++) {
-        const int x = cx + (k % 3) - 1, y = cy + ((k / 3) % 3) - 1, z = cz + (k / 9) - 1;
-        const bool in = (unsigned int)x < (unsigned int)g.nx && (unsigned int)y < (unsigned int)g.ny && (unsigned int)z < (unsigned int)g.nz;
-        const int c = in ? cell_index(x, y, z, g) : 0;
-        rs[k] = in ? cell_start[c] : 0;
-        re[k] = in ? cell_start[c + 1] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < 27; k++) {
-        int j = rs[k];
-        for (; j + 4 <= re[k]; j += 4) {
-            const float4 p0 = sorted[j], p1 = sorted[j + 1], p2 = sorted[j + 2], p3 = sorted[j + 3];
-            const float d0 = dist2(qx, qy, qz, p0.x, p0.y, p0.z), d1 = dist2(qx, qy, qz, p1.x, p1.y, p1.z);
-            const float d2 = dist2(qx, qy, qz, p2.x, p2.y, p2.z), d3 = dist2(qx, qy, qz, p3.x, p3.y, p3.z);
-            const int k0 = __float_as_int(p0.w), k1 = __float_as_int(p1.w), k2 = __float_as_int(p2.w), k3 = __float_as_int(p3.w);
-            if (d0 < best || (d0 == best && k0 < best_i)) { best = d0; best_i = k0; }
-            if (d1 < best || (d1 == best && k1 < best_i)) { best = d1; best_i = k1; }
-            if (d2 < best || (d2 == best && k2 < best_i)) { best = d2; best_i = k2; }
-            if (d3 < best || (d3 == best && k3 < best_i)) { best = d3; best_i = k3; }
-        }
-        scan_range(sorted, j, re[k], qx, qy, qz, best, best_i);
-    }
-    const float bound = g.h * kBoundSlack;
-    if (best <= bound * bound) {
-        idx[i] = best_i;
-        dist[i] = best;
-        if (keys) claim_target(keys, best_i, best, i);
-    } else {
-        idx[i] = best_i;  // what the neighbourhood offered (0x7FFFFFFF / inf when it was empty): the far pass starts there
-        dist[i] = best;
-        far_list[atomicAdd(n_far, 1)] = i;
+    const float dx = fmaxf(0.0f, fmaxf(b.lx - whx, wlx - b.hx));
+    const float dy = fmaxf(0.0f, fmaxf(b.ly - why, wly - b.hy));
+    const float dz = fmaxf(0.0f, fmaxf(b.lz - whz, wlz - b.hz));
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// In-wave LDS hand-over: LDS instructions of one wave execute in order, so a ds_write of all lanes followed by ds_reads of
+// the same wave needs no hardware wait -- only the compiler must not move the accesses across this point.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct alignas(16) WaveStage {  // 64 candidate points of one wave, structure of arrays: 4 consecutive points = one 16-B LDS read
+    float x[64], y[64], z[64];
+    int i[64];
+};
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+
+// dist2 of one query against four points, as packed f32 pairs (v_pk_add_f32 with negated operand, v_pk_mul_f32): one
+// rounding per operation and the order (d0*d0 + d1*d1) + d2*d2 of PointCloud::kdtree_distance (icp.h:40-47); contraction is off.
+__device__ __forceinline__ f4v dist2x4(f2v qx, f2v qy, f2v qz, f4v X, f4v Y, f4v Z)
+{
+    const f2v ax = qx - X.xy, bx = qx - X.zw;
+    const f2v ay = qy - Y.xy, by = qy - Y.zw;
+    const f2v az = qz - Z.xy, bz = qz - Z.zw;
+    const f2v a = ax * ax + ay * ay + az * az;
+    const f2v b = bx * bx + by * by + bz * bz;
+    f4v d;
+    d.xy = a;
+    d.zw = b;
+    return d;
+}
+
+__device__ __forceinline__ void lex_update(float d, int k, float &best, int &best_i)
+{
+    if (d < best || (d == best && k < best_i)) {
+        best = d;
+        best_i = k;
     }
 }
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+// Every lane (one query each) against the points sorted[js, je): the wave loads 64 points at a time with one coalesced
+// 16-byte load per lane, parks them in its LDS stage and then walks them four at a time -- all lanes read the same LDS
+// address (broadcast), the twelve differences / products / sums run as packed f32 pairs (one rounding per operation, the
+// order of PointCloud::kdtree_distance, icp.h:40-47).  Only the minimum of the four distances is compared with the lane's
+// best; the (distance, index) bookkeeping runs in the rare case that some lane of the wave is improved or tied.
+__device__ __forceinline__ void scan_points(const float4 *__restrict__ sorted, int js, int je, WaveStage &st, int lane, float qx, float qy,
+                                            float qz, float &best, int &best_i)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
+    const f2v qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+    for (int base = js; base < je; base += 64) {
+        const int cnt = min(64, je - base);  // wave-uniform
+        float4 p = make_float4(NAN, NAN, NAN, __int_as_float(0x7FFFFFFF));  // padding: its distance is NaN, never taken
+        if (lane < cnt) p = sorted[base + lane];
+        st.x[lane] = p.x;
+        st.y[lane] = p.y;
+        st.z[lane] = p.z;
+        st.i[lane] = __float_as_int(p.w);
+        wave_lds_fence();
+        for (int t = 0; t < cnt; t += 8) {  // two independent groups of four per step (fills the issue slots between dependent packed ops)
+            const f4v d = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&st.x[t]), *reinterpret_cast<const f4v *>(&st.y[t]),
+                                  *reinterpret_cast<const f4v *>(&st.z[t]));
+            const f4v e = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&st.x[t + 4]), *reinterpret_cast<const f4v *>(&st.y[t + 4]),
+                                  *reinterpret_cast<const f4v *>(&st.z[t + 4]));
+            const float m = fminf(fminf(fminf(d.x, d.y), fminf(d.z, d.w)), fminf(fminf(e.x, e.y), fminf(e.z, e.w)));  // fminf skips NaN
+            if (__ballot(m <= best)) {                                                                                 // wave-uniform branch
+                const i4v K = *reinterpret_cast<const i4v *>(&st.i[t]);
+                const i4v L = *reinterpret_cast<const i4v *>(&st.i[t + 4]);
+                lex_update(d.x, K.x, best, best_i);
+                lex_update(d.y, K.y, best, best_i);
+                lex_update(d.z, K.z, best, best_i);
+                lex_update(d.w, K.w, best, best_i);
+                lex_update(e.x, L.x, best, best_i);
+                lex_update(e.y, L.y, best, best_i);
+                lex_update(e.z, L.z, best, best_i);
+                lex_update(e.w, L.w, best, best_i);
+            }
+        }
+        wave_lds_fence();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Exact nearest neighbour for 64 SPATIALLY SORTED QUERIES AT A TIME ("query group" = one wave's worth).  The source cloud
+// is sorted once per call along its own voxel order, so a group is a compact patch (about one 4^3-cell block) and -- the
+// motion being rigid -- stays one for every iteration.  A patch shares its candidates: instead of 64 private tree walks
+// (round 1: one wave per far query, each a chain of dependent loads) the two-level box hierarchy is culled once per
+// group against the box W of its queries, 64 boxes per step, one per lane, and every surviving block is streamed through
+// LDS for all 64 queries at once.
+//
+// The search is cut into INDEPENDENT work items so that no wave ever runs a chain of dependent memory round trips and
+// no slow wave holds the launch up (measured: the one-kernel form below, kept as the overflow fallback, was bound by its
+// slowest wave -- ~200 us for ~50 dependent loads -- while the average wave needed 370 candidate points):
+//   nn_cull_kernel    one wave per group: seed every query with its previous neighbour (a REAL target point, so the
+//                     result does not depend on it), W, the largest bound; emits (group, super-block) items
+//   nn_blocks_kernel  one wave per item: the super-block's 64 block boxes, one per lane, against W, then against every
+//                     query's own bound; emits (group, point range) items, at most kChunk points each
+//   nn_scan_kernel    one wave per item: 64 queries x the range's points through LDS, packed f32; the lexicographic
+//                     (distance, index) minimum is merged into the query's 64-bit key with atomicMin
+//   nn_finish_kernel  one thread per query: index / distance out (original order) + the one-to-one claim
+// Without seeds (first ICP iteration, lsnIcpNearest) nn_seedless_kernel first emits the blocks nearest to each group as
+// scan items; their minima are the seeds.
+//
+// Exactness: a query's key only ever takes (distance, index) pairs of real target points, and a box is passed over only
+// when no query of the group can need it: the group test opens a box when boxbox_min_dist2(W, box) <= max_l bound_l,
+// which holds whenever some lane's own box_min_dist2(q_l, box) <= bound_l (see boxbox_min_dist2); the per-lane test
+// skips a box only when its exact f32 lower bound EXCEEDS every lane's bound, so equal-distance candidates are still
+// evaluated and the lowest index wins, like everywhere else.  The bounds are fixed for the whole step (the seeds); they
+// are distances of real points, so every point that could beat or tie them is inside an opened box.
+// The item lists have a fixed capacity; if one overflows (pathological inputs: no usable seeds, far outliers everywhere)
+// the finish kernel runs the complete walk (wave_search) for every group instead -- slower, same result.
+//
+// Queries with a non-finite coordinate do not take part in the culling (they would open every box); they end with
+// index 0 / distance +inf, which is what the search gives them when target 0 is finite.
+
+constexpr int kChunk = 256;             // points per scan item (4 LDS batches)
+constexpr unsigned long long kNoKey = 0x7F8000007FFFFFFFull;  // (+inf, no index)
+
+struct GroupInfo {  // per query group, written by nn_cull_kernel
+    float wlx, wly, wlz, whx, why, whz;  // W: the box of the group's queries
+    float rmax;                          // largest bound in the group (-1: nobody searches)
+    int pad;
+};
+
+constexpr int kSegs = 64;        // the work lists are cut into 64 segments with a counter each: an append is one atomicAdd per
+                                 // wave on the counter of segment (group mod 64) -- a single counter serialised ~10^4 atomics
+                                 // per step on one address (measured: 30-50 us per launch)
+constexpr int kBankInts = 256;   // counters of one bank: [0,64) list A, [64,128) list B, [128,192) seed-round part of B, [192] overflow
+
+struct NnWork {  // device work lists of one ICP workspace
+    uint2 *list_a;      // (group, super-block), segment s = entries [s * seg_a, (s + 1) * seg_a)
+    int4 *list_b;       // (group, first point, end point, -)
+    int seg_a, seg_b;   // segment capacities
+    int *counters;      // two banks of kBankInts
+};
+
+// A consumer wave's view of a segmented list: lane l holds the (clamped) length of segment l; item number `it` of the
+// concatenation is entry (it - excl[seg]) of segment seg = number of segments that end at or before it.
+struct SegView {
+    int incl, excl, total;
+};
+__device__ __forceinline__ SegView seg_view(const int *counts, int seg_cap, int lane)
+{
+    const int c = min(counts[lane], seg_cap);
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    SegView v;
+    v.incl = incl;
+    v.excl = incl - c;
+    v.total = __shfl(incl, 63, 64);
     return v;
 }
-
-// Far queries (compacted list): exact NN through the two-level AABB hierarchy, ONE WAVE PER QUERY -- the hierarchy is
-// 64-ary on purpose: the 64 lanes test 64 super-block boxes at a time, then the 64 block boxes of a super-block in one
-// step, then scan a block's points 64 at a time; (distance, index) pairs are reduced lexicographically with wave
-// shuffles.  Super-blocks are visited nearest-first, so the bound (min of: what the 27-cell scan found, the smallest
-// farthest-corner distance of any box seen, the best point so far) tightens after the first visit and almost every
-// other box is skipped.  A box is skipped only when its exact f32 minimum distance EXCEEDS the bound, so equal-distance
-// candidates are still seen and the lowest index wins, like everywhere else.
-__global__ __launch_bounds__(kThreads) void nn_far_kernel(const float *queries, const GridParams *gp, const int *cell_start,
-                                                          const float4 *sorted, const Box *boxes, const Box *supers, const int *far_list,
-                                                          const int *n_far, int *idx, float *dist, unsigned long long *keys)
+__device__ __forceinline__ int seg_locate(const SegView &v, int it, int seg_cap)
 {
-    // every super-block's minimum distance lives in LDS (lane l owns entries l, 64 + l, ...): the loops below then run
-    // over the chunks that exist (3 for a typical 2-sensor scene) instead of a compile-time 16
-    __shared__ float s_md[kThreads / 64][kMaxSupers];
-    const int lane = threadIdx.x & 63;
-    float *md = s_md[threadIdx.x >> 6];
-    const int slot = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);  // one query per wave
-    if (slot >= *n_far) return;                                          // wave-uniform
-    const int i = far_list[slot];
-    const int n_supers = gp->ncells / 4096;
-    const float qx = queries[3 * (size_t)i], qy = queries[3 * (size_t)i + 1], qz = queries[3 * (size_t)i + 2];
-    float best = dist[i];  // uniform across the wave from here on
-    int best_i = idx[i];
+    const int seg = __popcll(__ballot(v.incl <= it));
+    return seg * seg_cap + (it - __shfl(v.excl, seg, 64));
+}
 
-    const int n_chunks = (n_supers + 63) >> 6;
-    float ub = INFINITY;
-    for (int c = 0; c < n_chunks; c++) {
-        const int s = c * 64 + lane;
-        float m = INFINITY;
-        if (s < n_supers) {
-            const Box b = supers[s];
-            m = box_min_dist2(qx, qy, qz, b);
-            ub = fminf(ub, box_max_dist2(qx, qy, qz, b));
-        }
-        md[s] = m;
+__device__ __forceinline__ unsigned long long pack_key(float d, int k)
+{
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)k;
+}
+__device__ __forceinline__ float key_dist(unsigned long long key) { return __uint_as_float((unsigned int)(key >> 32)); }
+__device__ __forceinline__ int key_index(unsigned long long key) { return (int)(unsigned int)key; }
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY; }
+
+__device__ __forceinline__ int wave_excl_scan_i(int v, int lane)
+{
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
-    float bound = fminf(best, wave_min_f(ub));
+    return incl - v;
+}
 
-    for (int visits = 0; visits <= kMaxSupers; visits++) {
-        // nearest unvisited super-block
-        float m = INFINITY;
-        int mc = 0;
-        for (int c = 0; c < n_chunks; c++) {
-            const float v = md[c * 64 + lane];
-            if (v < m) {
-                m = v;
-                mc = c;
-            }
-        }
-        const float wm = wave_min_f(m);
-        if (!(wm <= bound)) break;  // nothing left that could hold a point at distance <= bound (also ends on NaN)
-        const int src = __ffsll((long long)__ballot(m == wm)) - 1;
-        const int s = __shfl(mc, src, 64) * 64 + src;
-        if (lane == src) md[s] = INFINITY;  // visited (only this lane ever reads the entry again)
+// Appends the point range [js, je) of every lane with `take` set to list B as (group, range) items of <= kChunk points.
+__device__ __forceinline__ void emit_ranges(const NnWork &wk, int *seg_counters, int *overflow, int g, bool take, int js, int je, int lane)
+{
+    const int n_items = take ? (je - js + kChunk - 1) / kChunk : 0;
+    const int before = wave_excl_scan_i(n_items, lane);
+    const int total = __shfl(before + n_items, 63, 64);
+    if (total == 0) return;  // wave-uniform
+    const int seg = g & (kSegs - 1);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(seg_counters + seg, total);
+    base = __shfl(base, 0, 64);
+    if (base + total > wk.seg_b) {
+        if (lane == 0) atomicExch(overflow, 1);
+        return;
+    }
+    for (int c = 0; c < n_items; c++) {
+        const int a = js + c * kChunk;
+        wk.list_b[(size_t)seg * wk.seg_b + base + before + c] = make_int4(g, a, min(a + kChunk, je), 0);
+    }
+}
 
-        // its 64 blocks, one per lane; every lane also fetches its block's point range now, so that the candidate loop
-        // below starts on the points without another dependent round trip per block
-        const Box bb = boxes[s * 64 + lane];
-        const int range0 = cell_start[(s * 64 + lane) * 64], range1 = cell_start[(s * 64 + lane) * 64 + 64];
-        const float mb = box_min_dist2(qx, qy, qz, bb);
-        bound = fminf(bound, wave_min_f(box_max_dist2(qx, qy, qz, bb)));
-        unsigned long long cand = __ballot(mb <= bound);
-        float lbest = best;
-        int lbi = best_i;
-        while (cand) {
-            const int b = __ffsll((long long)cand) - 1;
-            cand &= cand - 1;
-            const int e = __shfl(range1, b, 64);
-            for (int j = __shfl(range0, b, 64) + lane; j < e; j += 64) {
-                const float4 p = sorted[j];
-                const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
-                const int k = __float_as_int(p.w);
-                if (d < lbest || (d == lbest && k < lbi)) {
-                    lbest = d;
-                    lbi = k;
+// The complete walk for one group in one wave: seeds the search from the nearest blocks when some query has no candidate,
+// then opens every super-block / block that a query may need, tightening the bounds as it goes.  Exact for any input;
+// used when the item lists overflow.
+__device__ void wave_search(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, const Box *__restrict__ boxes,
+                            const Box *__restrict__ supers, WaveStage &st, int lane, float qx, float qy, float qz, bool part, float &best,
+                            int &best_i)
+{
+    if (!__ballot(part)) return;
+    const float wlx = wave_min_f(part ? qx : INFINITY), wly = wave_min_f(part ? qy : INFINITY), wlz = wave_min_f(part ? qz : INFINITY);
+    const float whx = wave_max_f(part ? qx : -INFINITY), why = wave_max_f(part ? qy : -INFINITY), whz = wave_max_f(part ? qz : -INFINITY);
+    const int n_supers = gp->ncells / 4096;
+    int seed_super = -1;
+    unsigned long long seed_done = 0;
+    if (__ballot(part && !(best < INFINITY))) {
+        // some query has no candidate yet: scan the blocks nearest to the patch first (any real point bounds the search)
+        float m_best = INFINITY;
+        int s_best = 0;
+        for (int c0 = 0; c0 < n_supers; c0 += 64) {
+            const int sl = c0 + lane;
+            if (sl < n_supers) {
+                const float m = boxbox_min_dist2(wlx, wly, wlz, whx, why, whz, supers[sl]);
+                if (m < m_best) {
+                    m_best = m;
+                    s_best = sl;
                 }
             }
         }
-        // lexicographic (distance, index) minimum over the wave; non-negative floats order like their bit patterns
-        const unsigned long long key = wave_min_u64(((unsigned long long)__float_as_uint(lbest) << 32) | (unsigned int)lbi);
-        const float kd = __uint_as_float((unsigned int)(key >> 32));
-        if (kd < best || (kd == best && (int)(unsigned int)key < best_i)) {
-            best = kd;
-            best_i = (int)(unsigned int)key;
+        const float wm = wave_min_f(m_best);
+        if (wm < INFINITY) {
+            const int src_lane = __ffsll((long long)__ballot(m_best == wm)) - 1;
+            seed_super = __shfl(s_best, src_lane, 64);
+            const Box bb = boxes[seed_super * 64 + lane];
+            float mb = boxbox_min_dist2(wlx, wly, wlz, whx, why, whz, bb);
+            for (int t = 0; t < kSeedBlocks; t++) {
+                const float wmb = wave_min_f(mb);
+                if (!(wmb < INFINITY)) break;
+                const int b = __ffsll((long long)__ballot(mb == wmb)) - 1;
+                const int js = __builtin_amdgcn_readlane(__float_as_int(bb.pad0), b), je = __builtin_amdgcn_readlane(__float_as_int(bb.pad1), b);
+                scan_points(sorted, js, je, st, lane, qx, qy, qz, best, best_i);
+                seed_done |= 1ull << b;
+                if (lane == b) mb = INFINITY;
+            }
         }
-        bound = fminf(bound, best);
     }
-    if (lane == 0) {
-        if (best_i == 0x7FFFFFFF) best_i = 0;  // every distance was NaN: keep the index in range
-        idx[i] = best_i;
-        dist[i] = best;
-        if (keys) claim_target(keys, best_i, best, i);
-    }
-}
-
-// Far queries that come with a good candidate (ICP iterations after the first: the previous neighbour seeds the search):
-// the job is no longer to FIND a near point but to PROVE that nothing is nearer.  Still one wave per query (point scans
-// must stay 64 wide: a single lane walking a block's points is a chain of dependent loads), but without the machinery of
-// the exploring kernel above -- no nearest-first ordering, no LDS table, one reduction at the very end: the lanes test the
-// super-block boxes 64 at a time against the candidate's distance, the (few) boxes that do not exceed it are opened in
-// index order, lanes keep private (distance, index) minima and only the bound is refreshed per super-block.  Same pruning
-// rule as everywhere: a box is skipped only when its exact f32 minimum distance EXCEEDS the bound; ties go to the lowest index.
-__global__ __launch_bounds__(kThreads) void nn_far_seeded_kernel(const float *queries, const GridParams *gp, const int *cell_start,
-                                                                 const float4 *sorted, const Box *boxes, const Box *supers,
-                                                                 const int *far_list, const int *n_far, int *idx, float *dist,
-                                                                 unsigned long long *keys, int *far2_list, int *n_far2)
-{
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);  // one query per wave
-    if (slot >= *n_far) return;                                          // wave-uniform
-    const int i = far_list[slot];
-    const float qx = queries[3 * (size_t)i], qy = queries[3 * (size_t)i + 1], qz = queries[3 * (size_t)i + 2];
-    const float seed = dist[i];
-    const int seed_i = idx[i];
-    if (!(seed < INFINITY)) {  // inf / NaN: nothing to prove against -> the exploring kernel searches from scratch
-        if (lane == 0) far2_list[atomicAdd(n_far2, 1)] = i;
-        return;
-    }
-    float bound = seed;                 // wave-uniform
-    float lbest = seed;                 // per-lane running minimum, lexicographic with lbi
-    int lbi = seed_i;
-    const int n_supers = gp->ncells / 4096;
+    float bound = part ? best : -1.0f;  // a lane outside the search never opens a box
+    float rmax = wave_max_f(bound);
     for (int c0 = 0; c0 < n_supers; c0 += 64) {
         const int sl = c0 + lane;
         float m = INFINITY;
-        if (sl < n_supers) m = box_min_dist2(qx, qy, qz, supers[sl]);
-        unsigned long long open = __ballot(m <= bound);
+        if (sl < n_supers) m = boxbox_min_dist2(wlx, wly, wlz, whx, why, whz, supers[sl]);
+        unsigned long long open = __ballot(m <= rmax && m < INFINITY);
         while (open) {
             const int s = c0 + __ffsll((long long)open) - 1;
             open &= open - 1;
             // the super-block's 64 blocks, one per lane, with their point ranges
             const Box bb = boxes[s * 64 + lane];
-            const int range0 = cell_start[(s * 64 + lane) * 64], range1 = cell_start[(s * 64 + lane) * 64 + 64];
-            unsigned long long cand = __ballot(box_min_dist2(qx, qy, qz, bb) <= bound);
+            const float mb = boxbox_min_dist2(wlx, wly, wlz, whx, why, whz, bb);
+            unsigned long long cand = __ballot(mb <= rmax && mb < INFINITY);
+            if (s == seed_super) cand &= ~seed_done;
             while (cand) {
                 const int b = __ffsll((long long)cand) - 1;
                 cand &= cand - 1;
-                const int e = __shfl(range1, b, 64);
-                for (int j = __shfl(range0, b, 64) + lane; j < e; j += 64) {
-                    const float4 p = sorted[j];
-                    const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
-                    const int k = __float_as_int(p.w);
-                    if (d < lbest || (d == lbest && k < lbi)) {
-                        lbest = d;
-                        lbi = k;
-                    }
-                }
+                Box xb;  // block b's box, broadcast from lane b
+                xb.lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.lx), b));
+                xb.ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.ly), b));
+                xb.lz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.lz), b));
+                xb.hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.hx), b));
+                xb.hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.hy), b));
+                xb.hz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.hz), b));
+                if (!__ballot(box_min_dist2(qx, qy, qz, xb) <= bound)) continue;  // no lane can find anything nearer or tied in it
+                const int js = __builtin_amdgcn_readlane(__float_as_int(bb.pad0), b), je = __builtin_amdgcn_readlane(__float_as_int(bb.pad1), b);
+                scan_points(sorted, js, je, st, lane, qx, qy, qz, best, best_i);
+                bound = part ? best : -1.0f;
             }
-            bound = wave_min_f(lbest);
-            // super-blocks of this chunk that the tighter bound rules out need not be opened
-            open &= __ballot(m <= bound);
+            rmax = wave_max_f(bound);
+            open &= __ballot(m <= rmax);  // super-blocks of this chunk that the tighter bounds rule out need not be opened
         }
-    }
-    const unsigned long long key = wave_min_u64(((unsigned long long)__float_as_uint(lbest) << 32) | (unsigned int)lbi);
-    if (lane == 0) {
-        idx[i] = (int)(unsigned int)key;
-        dist[i] = __uint_as_float((unsigned int)(key >> 32));
-        if (keys) claim_target(keys, (int)(unsigned int)key, __uint_as_float((unsigned int)(key >> 32)), i);
     }
 }
 
-// LDS-tiled brute force: a workgroup owns 256 queries (directly, or through the `list` of unresolved queries) and
-// streams the whole target cloud through LDS; every lane reads the same LDS address (broadcast, conflict-free).
-// Targets are visited in index order with a strict '<', so the lowest index wins ties.
-__global__ __launch_bounds__(kThreads) void nn_brute_kernel(const float *targets, int n1, const float *queries, int n2,
-                                                            const int *list, const int *n_list, int *idx, float *dist,
-                                                            unsigned long long *keys)
+// No seeds yet: every query's key starts empty, and the kSeedBlocks blocks nearest to the group's box (inside the nearest
+// super-block) become scan items; what they yield seeds the real search (any real point bounds it).
+__global__ __launch_bounds__(kThreads) void nn_seedless_kernel(const float4 *__restrict__ src, int n2, const GridParams *__restrict__ gp,
+                                                               const Box *__restrict__ boxes, const Box *__restrict__ supers,
+                                                               unsigned long long *best_key, NnWork wk, int bank)
 {
-    __shared__ float tx[kBfTile], ty[kBfTile], tz[kBfTile];
-    const int nq = list ? *n_list : n2;
-    if (blockIdx.x * kThreads >= nq) return;  // uniform per workgroup
-    const int slot = blockIdx.x * kThreads + threadIdx.x;
-    const bool active = slot < nq;
-    const int i = active ? (list ? list[slot] : slot) : 0;
-    float qx = 0, qy = 0, qz = 0;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const int j = g * 64 + lane;
+    if (g * 64 >= n2) return;  // wave-uniform
+    const bool active = j < n2;
+    float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
     if (active) {
-        qx = queries[3 * (size_t)i];
-        qy = queries[3 * (size_t)i + 1];
-        qz = queries[3 * (size_t)i + 2];
+        q4 = src[j];
+        best_key[j] = kNoKey;
     }
+    const bool part = active && finite3(q4.x, q4.y, q4.z);
+    if (!__ballot(part)) return;
+    const float wlx = wave_min_f(part ? q4.x : INFINITY), wly = wave_min_f(part ? q4.y : INFINITY), wlz = wave_min_f(part ? q4.z : INFINITY);
+    const float whx = wave_max_f(part ? q4.x : -INFINITY), why = wave_max_f(part ? q4.y : -INFINITY), whz = wave_max_f(part ? q4.z : -INFINITY);
+    const int n_supers = gp->ncells / 4096;
+    float m_best = INFINITY;
+    int s_best = 0;
+    for (int c0 = 0; c0 < n_supers; c0 += 64) {
+        const int sl = c0 + lane;
+        if (sl < n_supers) {
+            const float m = boxbox_min_dist2(wlx, wly, wlz, whx, why, whz, supers[sl]);
+            if (m < m_best) {
+                m_best = m;
+                s_best = sl;
+            }
+        }
+    }
+    const float wm = wave_min_f(m_best);
+    if (!(wm < INFINITY)) return;  // no target point with comparable coordinates at all
+    const int seed_super = __shfl(s_best, __ffsll((long long)__ballot(m_best == wm)) - 1, 64);
+    const Box bb = boxes[seed_super * 64 + lane];
+    float mb = boxbox_min_dist2(wlx, wly, wlz, whx, why, whz, bb);
+    unsigned long long chosen = 0;
+    for (int t = 0; t < kSeedBlocks; t++) {
+        const float wmb = wave_min_f(mb);
+        if (!(wmb < INFINITY)) break;
+        const int b = __ffsll((long long)__ballot(mb == wmb)) - 1;
+        chosen |= 1ull << b;
+        if (lane == b) mb = INFINITY;
+    }
+    int *cnt = wk.counters + kBankInts * bank;
+    emit_ranges(wk, cnt + 2 * kSegs, cnt + 3 * kSegs, g, (chosen >> lane) & 1, __float_as_int(bb.pad0), __float_as_int(bb.pad1), lane);
+}
+
+// One wave per query group.  APPLY: first move the group's queries by the previous iteration's (T, Rn) -- icp.cpp:143-146 +
+// :165: v = (v + T) * Rn, row vectors, f32, one rounding per operation -- in the sorted working copy and in the caller's
+// array (same three floats at the query's original position), and clear the match keys for this iteration's claims.
+// Then: the query's seed (its previous neighbour's distance from where the query is now; without seed_targets the key the
+// seed round left), the group's box and largest bound, and one (group, super-block) item per super-block the group may need.
+template <bool APPLY>
+__global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *verts2, int n2, const IcpState *st, unsigned long long *keys,
+                                                           int n_keys, const GridParams *__restrict__ gp, const Box *__restrict__ supers,
+                                                           const float *__restrict__ seed_targets, int n1, const int *idx,
+                                                           unsigned long long *best_key, GroupInfo *groups, NnWork wk, int bank)
+{
+    if (APPLY)
+        for (int k = blockIdx.x * kThreads + threadIdx.x; k < n_keys; k += gridDim.x * kThreads) keys[k] = ~0ull;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const int j = g * 64 + lane;
+    if (g * 64 >= n2) return;  // wave-uniform
+    const bool active = j < n2;
+    float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
+    if (active) q4 = src[j];
+    const int orig = __float_as_int(q4.w);
+    if (APPLY && active && st->mk > 0) {
+        const float x = q4.x + st->T[0], y = q4.y + st->T[1], z = q4.z + st->T[2];
+        q4.x = x * st->Rn[0] + y * st->Rn[3] + z * st->Rn[6];
+        q4.y = x * st->Rn[1] + y * st->Rn[4] + z * st->Rn[7];
+        q4.z = x * st->Rn[2] + y * st->Rn[5] + z * st->Rn[8];
+        src[j] = q4;
+        const size_t o = 3 * (size_t)orig;
+        verts2[o] = q4.x;
+        verts2[o + 1] = q4.y;
+        verts2[o + 2] = q4.z;
+    }
+    const float qx = q4.x, qy = q4.y, qz = q4.z;
+    const bool part = active && finite3(qx, qy, qz);
+    unsigned long long key = kNoKey;
+    if (seed_targets) {
+        if (part) {
+            const int k = idx[orig];
+            if ((unsigned int)k < (unsigned int)n1) {
+                const float d = dist2(qx, qy, qz, seed_targets[3 * (size_t)k], seed_targets[3 * (size_t)k + 1], seed_targets[3 * (size_t)k + 2]);
+                if (d == d) key = pack_key(d, k);  // not NaN
+            }
+        }
+        if (active) best_key[j] = key;
+    } else if (active) {
+        key = best_key[j];
+    }
+    const float bound = part ? key_dist(key) : -1.0f;  // a lane outside the search never opens a box
+    GroupInfo gi;
+    gi.wlx = wave_min_f(part ? qx : INFINITY); gi.wly = wave_min_f(part ? qy : INFINITY); gi.wlz = wave_min_f(part ? qz : INFINITY);
+    gi.whx = wave_max_f(part ? qx : -INFINITY); gi.why = wave_max_f(part ? qy : -INFINITY); gi.whz = wave_max_f(part ? qz : -INFINITY);
+    gi.rmax = wave_max_f(bound);
+    gi.pad = 0;
+    if (lane == 0) groups[g] = gi;
+    if (!(gi.rmax >= 0.0f)) return;
+    const int n_supers = gp->ncells / 4096;
+    int *cnt = wk.counters + kBankInts * bank;
+    // two passes over the super-block boxes (count, then write) so that the append costs the wave ONE atomicAdd
+    int total = 0;
+    for (int c0 = 0; c0 < n_supers; c0 += 64) {
+        const int sl = c0 + lane;
+        float m = INFINITY;
+        if (sl < n_supers) m = boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, supers[sl]);
+        total += __popcll(__ballot(m <= gi.rmax && m < INFINITY));
+    }
+    if (total == 0) return;
+    const int seg = g & (kSegs - 1);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(cnt + seg, total);
+    base = __shfl(base, 0, 64);
+    if (base + total > wk.seg_a) {
+        if (lane == 0) atomicExch(cnt + 3 * kSegs, 1);
+        return;
+    }
+    uint2 *out = wk.list_a + (size_t)seg * wk.seg_a + base;
+    for (int c0 = 0; c0 < n_supers; c0 += 64) {
+        const int sl = c0 + lane;
+        float m = INFINITY;
+        if (sl < n_supers) m = boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, supers[sl]);
+        const bool open = m <= gi.rmax && m < INFINITY;
+        const unsigned long long mask = __ballot(open);
+        if (open) out[__popcll(mask & ((1ull << lane) - 1))] = make_uint2((unsigned int)g, (unsigned int)sl);
+        out += __popcll(mask);
+    }
+}
+
+// One wave per (group, super-block) item: the super-block's 64 blocks, one per lane, against the group's box, then each
+// surviving block against every query's own bound; what is left becomes scan items.
+__global__ __launch_bounds__(kThreads) void nn_blocks_kernel(const float4 *__restrict__ src, int n2, const Box *__restrict__ boxes,
+                                                             const unsigned long long *__restrict__ best_key,
+                                                             const GroupInfo *__restrict__ groups, NnWork wk, int bank)
+{
+    const int lane = threadIdx.x & 63;
+    int *cnt = wk.counters + kBankInts * bank;
+    if (cnt[3 * kSegs]) return;  // a list overflowed: the finish kernel searches from scratch
+    const SegView view = seg_view(cnt, wk.seg_a, lane);
+    const int n_waves = gridDim.x * (kThreads / 64);
+    for (int it = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); it < view.total; it += n_waves) {
+        const uint2 item = wk.list_a[seg_locate(view, it, wk.seg_a)];
+        const int g = (int)item.x, s = (int)item.y;
+        const int j = g * 64 + lane;
+        const Box bb = boxes[s * 64 + lane];
+        const GroupInfo gi = groups[g];
+        float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
+        float bound = -1.0f;
+        if (j < n2) {
+            q4 = src[j];
+            if (finite3(q4.x, q4.y, q4.z)) bound = key_dist(best_key[j]);
+        }
+        const float mb = boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, bb);
+        unsigned long long cand = __ballot(mb <= gi.rmax && mb < INFINITY);
+        unsigned long long take = 0;
+        while (cand) {
+            const int b = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            Box xb;  // block b's box, broadcast from lane b
+            xb.lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.lx), b));
+            xb.ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.ly), b));
+            xb.lz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.lz), b));
+            xb.hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.hx), b));
+            xb.hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.hy), b));
+            xb.hz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.hz), b));
+            if (__ballot(box_min_dist2(q4.x, q4.y, q4.z, xb) <= bound)) take |= 1ull << b;  // some query may find something nearer or tied in it
+        }
+        emit_ranges(wk, cnt + kSegs, cnt + 3 * kSegs, g, (take >> lane) & 1, __float_as_int(bb.pad0), __float_as_int(bb.pad1), lane);
+    }
+}
+
+// One wave per (group, point range) item: the group's 64 queries against the range's points; a query whose (distance,
+// index) pair improved merges it into its key -- atomicMin on (distance bits << 32 | index) is the lexicographic minimum.
+__global__ __launch_bounds__(kThreads) void nn_scan_kernel(const float4 *__restrict__ src, int n2, const float4 *__restrict__ sorted,
+                                                           unsigned long long *best_key, NnWork wk, int bank, int counter_slot)
+{
+    __shared__ WaveStage s_stage[kThreads / 64];
+    const int lane = threadIdx.x & 63;
+    WaveStage &st = s_stage[threadIdx.x >> 6];
+    const int *cnt = wk.counters + kBankInts * bank;
+    if (cnt[3 * kSegs]) return;
+    const SegView view = seg_view(cnt + counter_slot * kSegs, wk.seg_b, lane);
+    const int n_waves = gridDim.x * (kThreads / 64);
+    for (int it = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); it < view.total; it += n_waves) {
+        const int4 item = wk.list_b[seg_locate(view, it, wk.seg_b)];
+        const int j = item.x * 64 + lane;
+        float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
+        unsigned long long key = kNoKey;
+        if (j < n2) {
+            q4 = src[j];
+            key = best_key[j];
+        }
+        float best = key_dist(key);
+        int best_i = key_index(key);
+        scan_points(sorted, item.y, item.z, st, lane, q4.x, q4.y, q4.z, best, best_i);
+        const unsigned long long now = pack_key(best, best_i);
+        if (j < n2 && now < key) atomicMin(&best_key[j], now);
+    }
+}
+
+// One thread per query: the neighbour index and squared distance at the query's ORIGINAL position, and the one-to-one claim.
+// When an item list overflowed, every group first runs the complete walk (seeded with whatever its keys hold).
+__global__ __launch_bounds__(kThreads) void nn_finish_kernel(const float4 *__restrict__ src, int n2, const GridParams *__restrict__ gp,
+                                                             const float4 *__restrict__ sorted, const Box *__restrict__ boxes,
+                                                             const Box *__restrict__ supers, const unsigned long long *best_key, int *idx,
+                                                             float *dist, unsigned long long *keys, NnWork wk, int bank)
+{
+    __shared__ WaveStage s_stage[kThreads / 64];
+    __shared__ int s_claim_k[kClaimSlots];
+    __shared__ unsigned long long s_claim_v[kClaimSlots];
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    int *cnt = wk.counters + kBankInts * bank;
+    const bool overflow = cnt[3 * kSegs] != 0;
+    // the other bank served the previous step and is read by nobody any more: clear it for the next step
+    if (blockIdx.x == 0) wk.counters[kBankInts * (1 - bank) + threadIdx.x] = 0;
+    const bool active = j < n2;
+    float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
+    unsigned long long key = kNoKey;
+    if (active) {
+        q4 = src[j];
+        key = best_key[j];
+    }
+    float best = key_dist(key);
+    int best_i = key_index(key);
+    if (overflow) wave_search(gp, sorted, boxes, supers, s_stage[threadIdx.x >> 6], lane, q4.x, q4.y, q4.z, active && finite3(q4.x, q4.y, q4.z), best, best_i);
+    const int orig = __float_as_int(q4.w);
+    if (active) {
+        if (best_i == 0x7FFFFFFF) best_i = 0;  // nothing comparable (NaN everywhere): keep the index in range
+        idx[orig] = best_i;
+        dist[orig] = best;
+    }
+    if (keys) claim_targets(keys, active, best_i, best, orig, s_claim_k, s_claim_v);
+}
+
+// LDS-tiled brute force (nn_mode 0, the ablation leg): a workgroup owns 256 queries and streams the whole target cloud
+// through LDS; every lane reads the same LDS address (broadcast, conflict-free), four targets per 16-byte read, the
+// arithmetic in packed f32 pairs.  Targets are visited in index order and a lane is only updated on a strictly smaller
+// distance, so the lowest index wins ties.
+__global__ __launch_bounds__(kThreads) void nn_brute_kernel(const float *__restrict__ targets, int n1, const float4 *__restrict__ src, int n2,
+                                                            int *idx, float *dist, unsigned long long *keys)
+{
+    __shared__ alignas(16) float tiles[3 * kBfTile];
+    float *tx = tiles, *ty = tiles + kBfTile, *tz = tiles + 2 * kBfTile;
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    const bool active = j < n2;
+    float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
+    if (active) q4 = src[j];
+    const float qx = q4.x, qy = q4.y, qz = q4.z;
+    const f2v qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     float best = INFINITY;
     int best_i = 0x7FFFFFFF;
     for (int t0 = 0; t0 < n1; t0 += kBfTile) {
         const int nt = min(kBfTile, n1 - t0);
         __syncthreads();
-        for (int j = threadIdx.x; j < nt; j += kThreads) {
-            tx[j] = targets[3 * (size_t)(t0 + j)];
-            ty[j] = targets[3 * (size_t)(t0 + j) + 1];
-            tz[j] = targets[3 * (size_t)(t0 + j) + 2];
+        for (int t = threadIdx.x; t < kBfTile; t += kThreads) {
+            const bool in = t < nt;  // the tail of the last tile is padded with NaN: its distances are NaN, never taken
+            tx[t] = in ? targets[3 * (size_t)(t0 + t)] : NAN;
+            ty[t] = in ? targets[3 * (size_t)(t0 + t) + 1] : NAN;
+            tz[t] = in ? targets[3 * (size_t)(t0 + t) + 2] : NAN;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < nt; j++) {
-            const float d = dist2(qx, qy, qz, tx[j], ty[j], tz[j]);
-            if (d < best) {
-                best = d;
-                best_i = t0 + j;
+        for (int t = 0; t < nt; t += 8) {  // two independent groups of four per step
+            const f4v d = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&tx[t]), *reinterpret_cast<const f4v *>(&ty[t]),
+                                  *reinterpret_cast<const f4v *>(&tz[t]));
+            const f4v e = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&tx[t + 4]), *reinterpret_cast<const f4v *>(&ty[t + 4]),
+                                  *reinterpret_cast<const f4v *>(&tz[t + 4]));
+            const float m = fminf(fminf(fminf(d.x, d.y), fminf(d.z, d.w)), fminf(fminf(e.x, e.y), fminf(e.z, e.w)));
+            if (__ballot(m < best)) {  // wave-uniform; rare once the running minima have settled
+                const int k = t0 + t;
+                if (d.x < best) { best = d.x; best_i = k; }
+                if (d.y < best) { best = d.y; best_i = k + 1; }
+                if (d.z < best) { best = d.z; best_i = k + 2; }
+                if (d.w < best) { best = d.w; best_i = k + 3; }
+                if (e.x < best) { best = e.x; best_i = k + 4; }
+                if (e.y < best) { best = e.y; best_i = k + 5; }
+                if (e.z < best) { best = e.z; best_i = k + 6; }
+                if (e.w < best) { best = e.w; best_i = k + 7; }
             }
         }
     }
+    const int orig = __float_as_int(q4.w);
     if (active) {
         if (best_i == 0x7FFFFFFF) best_i = 0;
-        idx[i] = best_i;
-        dist[i] = best;
-        if (keys) claim_target(keys, best_i, best, i);
+        idx[orig] = best_i;
+        dist[orig] = best;
+    }
+    if (keys) {
+        __syncthreads();  // the tiles are done with: the claim table reuses their LDS
+        claim_targets(keys, active, best_i, best, orig, reinterpret_cast<int *>(tiles), reinterpret_cast<unsigned long long *>(tiles + kBfTile));
     }
 }
 
@@ -689,63 +995,51 @@ __device__ __forceinline__ bool is_winner(const unsigned long long *keys, const 
     return (unsigned int)(keys[idx[i]] & 0xFFFFFFFFull) == 0xFFFFFFFFu - (unsigned int)i;
 }
 
-// pass 1: m = number of one-to-one matches, sum of their squared distances
-__global__ __launch_bounds__(kThreads) void stats1_kernel(const int *idx, const float *dist, const unsigned long long *keys, int n2,
-                                                          double *part /* [blocks][2] */)
+// pass 1: m = number of one-to-one matches, the sum of their squared distances and the sum of the squares of those
+__global__ __launch_bounds__(kThreads) void stats_kernel(const int *idx, const float *dist, const unsigned long long *keys, int n2,
+                                                         double *part /* [blocks][3] */)
 {
-    __shared__ double lds[4 * 2];
-    double v[2] = {0, 0};
+    __shared__ double lds[4 * 3];
+    double v[3] = {0, 0, 0};
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n2; i += gridDim.x * kThreads) {
         if (is_winner(keys, idx, i)) {
+            const double d = (double)dist[i];
             v[0] += 1.0;
-            v[1] += (double)dist[i];
+            v[1] += d;
+            v[2] += d * d;
         }
     }
-    block_sum_d<2>(v, lds);
-    if (threadIdx.x == 0) {
-        part[blockIdx.x * 2] = v[0];
-        part[blockIdx.x * 2 + 1] = v[1];
+    block_sum_d<3>(v, lds);
+    if (threadIdx.x < 3) {
+        double out = v[0];
+        if (threadIdx.x == 1) out = v[1];
+        if (threadIdx.x == 2) out = v[2];
+        part[blockIdx.x * 3 + threadIdx.x] = out;
     }
 }
 
-// pass 2: sum (d - mean)^2 with mean rounded to f32 like GetStandardDeviation (icp.cpp:36-49)
-__global__ __launch_bounds__(kThreads) void stats2_kernel(const int *idx, const float *dist, const unsigned long long *keys, int n2,
-                                                          const double *part1, int n_part1, double *part /* [blocks][1] */,
-                                                          IcpState *st)
-{
-    __shared__ double lds[4 * 2];
-    double s1[2];
-    reduce_partials<2>(part1, n_part1, s1, lds);
-    const float mean = (float)(s1[1] / s1[0]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->m = (int)s1[0];
-        st->mean = mean;
-    }
-    double v[1] = {0};
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n2; i += gridDim.x * kThreads) {
-        if (is_winner(keys, idx, i)) {
-            const float df = dist[i] - mean;  // f32 difference, squared in double (pow(float,int) -> double)
-            v[0] += (double)df * (double)df;
-        }
-    }
-    block_sum_d<1>(v, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = v[0];
-}
-
-// pass 3: reject d > 2.5*std (icp.cpp:56-73), accumulate count, sum m1, sum m2, sum m2 m1^T over the kept matches
+// pass 2: mean and standard deviation of the matches' squared distances (GetStandardDeviation, icp.cpp:34-54: the mean is
+// rounded to f32, the deviations are taken from that f32 mean, the sum is kept in a float and divided by the count),
+// reject d > 2.5*std (icp.cpp:56-73), accumulate count, sum m1, sum m2, sum m2 m1^T over the kept matches.
+// sum (d - mean)^2 = sum d^2 - 2 mean sum d + m mean^2 is evaluated in double from pass 1's three sums (mean = the f32
+// value): one pass over the matches instead of two; the cancellation costs ~1e-15 relative, far below the f32 result.
 __global__ __launch_bounds__(kThreads) void accum_kernel(const float *verts1, const float *verts2, const int *idx, const float *dist,
-                                                         const unsigned long long *keys, int n2, const double *part2, int n_part2,
+                                                         const unsigned long long *keys, int n2, const double *part1, int n_part1,
                                                          double *part /* [blocks][16] */, IcpState *st)
 {
     __shared__ double lds[4 * 16];
-    double s2[1];
-    reduce_partials<1>(part2, n_part2, s2, lds);
-    const float m_f = (float)st->m;  // written by stats2_kernel of the same iteration (previous launch)
-    float sd = (float)(s2[0]);       // the reference keeps the running sum in a float
+    double s1[3];
+    reduce_partials<3>(part1, n_part1, s1, lds);
+    const float mean = (float)(s1[1] / s1[0]);
+    const float m_f = (float)(int)s1[0];
+    const double dev = s1[2] - 2.0 * (double)mean * s1[1] + s1[0] * (double)mean * (double)mean;
+    float sd = (float)(dev > 0.0 ? dev : 0.0);  // the reference keeps the running sum in a float
     sd = sd / m_f;
     sd = sqrtf(sd);
     const float thresh = 2.5f * sd;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->m = (int)s1[0];
+        st->mean = mean;
         st->stddev = sd;
         st->thresh = thresh;
     }
@@ -908,22 +1202,29 @@ __global__ __launch_bounds__(kThreads) void solve_kernel(const double *part3, in
     }
 }
 
-// icp.cpp:143-146 + :165: v = (v + T) * Rn, row vectors, f32, one rounding per operation
-__global__ __launch_bounds__(kThreads) void apply_kernel(float *verts2, int n2, const IcpState *st)
+// icp.cpp:143-146 + :165: v = (v + T) * Rn, row vectors, f32, one rounding per operation.  Thread j moves query j of the
+// sorted working copy and stores the same three floats into the caller's array at the query's original position; the
+// same launch clears the match keys for the next iteration's atomicMin.
+__global__ __launch_bounds__(kThreads) void apply_kernel(float4 *src, float *verts2, int n2, const IcpState *st, unsigned long long *keys,
+                                                         int n_keys)
 {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j < n_keys) keys[j] = ~0ull;
     if (st->mk <= 0) return;
     const float T0 = st->T[0], T1 = st->T[1], T2 = st->T[2];
     const float r0 = st->Rn[0], r1 = st->Rn[1], r2 = st->Rn[2], r3 = st->Rn[3], r4 = st->Rn[4], r5 = st->Rn[5], r6 = st->Rn[6],
                 r7 = st->Rn[7], r8 = st->Rn[8];
-    if (i >= n2) return;
-    float x = verts2[3 * (size_t)i], y = verts2[3 * (size_t)i + 1], z = verts2[3 * (size_t)i + 2];
-    x = x + T0;
-    y = y + T1;
-    z = z + T2;
-    verts2[3 * (size_t)i] = x * r0 + y * r3 + z * r6;
-    verts2[3 * (size_t)i + 1] = x * r1 + y * r4 + z * r7;
-    verts2[3 * (size_t)i + 2] = x * r2 + y * r5 + z * r8;
+    if (j >= n2) return;
+    float4 q = src[j];
+    const float x = q.x + T0, y = q.y + T1, z = q.z + T2;
+    q.x = x * r0 + y * r3 + z * r6;
+    q.y = x * r1 + y * r4 + z * r7;
+    q.z = x * r2 + y * r5 + z * r8;
+    src[j] = q;
+    const size_t o = 3 * (size_t)__float_as_int(q.w);
+    verts2[o] = q.x;
+    verts2[o + 1] = q.y;
+    verts2[o + 2] = q.z;
 }
 
 }  // namespace
@@ -932,12 +1233,34 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(float *verts2, int n2, 
 // host side
 // -------------------------------------------------------------------------------------------------------------
 
+// One voxel grid over a cloud: the cell-sorted copy (x, y, z, original index) and, for a target, the box hierarchy.
+struct GridBufs {
+    lsn::DevBuf gp, cell_of, cell_cnt, cell_start, sorted, boxes, supers;
+    int reserve(int max_n, bool with_boxes)
+    {
+        int bad = 0;
+        bad |= gp.reserve(sizeof(GridParams));
+        bad |= cell_of.reserve(sizeof(int) * (size_t)max_n);
+        bad |= cell_cnt.reserve(sizeof(int) * (size_t)kMaxCells);
+        bad |= cell_start.reserve(sizeof(int) * ((size_t)kMaxCells + kScanBlock));
+        bad |= sorted.reserve(sizeof(float4) * (size_t)max_n);
+        if (with_boxes) {
+            bad |= boxes.reserve(sizeof(Box) * (size_t)kMaxBlocks3);
+            bad |= supers.reserve(sizeof(Box) * (size_t)kMaxSupers);
+        }
+        return bad;
+    }
+};
+
 struct LsnIcp {
     int device = 0;
     int max_n1 = 0, max_n2 = 0;
     float cell_override = 0.0f;
-    lsn::DevBuf gp, bbox_part, cell_of, cell_cnt, cell_start, block_sums, sorted, boxes, supers;
-    lsn::DevBuf idx, dist, keys, unresolved, unresolved2, counters, part1, part2, part3, state, trace;
+    GridBufs tgt, src;    // tgt: cell-sorted target + boxes; src.sorted: the spatially sorted working copy of the source
+    lsn::DevBuf bbox_part, block_sums;
+    lsn::DevBuf idx, dist, keys, counters, part1, part3, state, trace;
+    lsn::DevBuf best_key, groups, list_a, list_b;   // the NN step's per-query keys, per-group boxes and work lists
+    int seg_a = 0, seg_b = 0;   // capacity of one list segment
     int trace_iters = 0;
     bool seed_nn = true;   // $LSN_ICP_NO_SEED=1 turns the previous-neighbour seeding off (ablation)
     std::mutex mu;
@@ -962,23 +1285,26 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
     const char *env = getenv("LSN_ICP_CELL");
     if (env) w->cell_override = (float)atof(env);
     bool bad = false;
-    bad |= w->gp.reserve(sizeof(GridParams)) != 0;
+    bad |= w->tgt.reserve(max_n1, true) != 0;
+    bad |= w->src.reserve(max_n2, false) != 0;
     bad |= w->bbox_part.reserve(sizeof(float) * 6 * kMaxBlocks) != 0;
-    bad |= w->cell_of.reserve(sizeof(int) * (size_t)max_n1) != 0;
-    bad |= w->cell_cnt.reserve(sizeof(int) * (size_t)kMaxCells) != 0;
-    bad |= w->cell_start.reserve(sizeof(int) * ((size_t)kMaxCells + kScanBlock)) != 0;
     bad |= w->block_sums.reserve(sizeof(int) * 2048) != 0;
-    bad |= w->sorted.reserve(sizeof(float4) * (size_t)max_n1) != 0;
-    bad |= w->boxes.reserve(sizeof(Box) * (size_t)kMaxBlocks3) != 0;
-    bad |= w->supers.reserve(sizeof(Box) * (size_t)kMaxSupers) != 0;
     bad |= w->idx.reserve(sizeof(int) * (size_t)max_n2) != 0;
     bad |= w->dist.reserve(sizeof(float) * (size_t)max_n2) != 0;
     bad |= w->keys.reserve(sizeof(unsigned long long) * (size_t)max_n1) != 0;
-    bad |= w->unresolved.reserve(sizeof(int) * (size_t)max_n2) != 0;
-    bad |= w->unresolved2.reserve(sizeof(int) * (size_t)max_n2) != 0;
-    bad |= w->counters.reserve(64) != 0;
-    bad |= w->part1.reserve(sizeof(double) * 2 * kMaxBlocks) != 0;
-    bad |= w->part2.reserve(sizeof(double) * kMaxBlocks) != 0;
+    bad |= w->counters.reserve(sizeof(int) * 2 * kBankInts) != 0;
+    {
+        const int n_groups = (max_n2 + 63) / 64;
+        // generous: a seeded group needs ~5 super-blocks and ~10 point ranges; $LSN_ICP_TINY_LISTS=1 forces the overflow path (tests)
+        const bool tiny = getenv("LSN_ICP_TINY_LISTS") && atoi(getenv("LSN_ICP_TINY_LISTS")) != 0;
+        w->seg_a = tiny ? 2 : 1024 + n_groups / 4;   // x 64 segments: 64 k + 16 per group
+        w->seg_b = tiny ? 2 : 4096 + n_groups;       // x 64 segments: 256 k + 64 per group
+        bad |= w->best_key.reserve(sizeof(unsigned long long) * (size_t)max_n2) != 0;
+        bad |= w->groups.reserve(sizeof(GroupInfo) * (size_t)n_groups) != 0;
+        bad |= w->list_a.reserve(sizeof(uint2) * (size_t)w->seg_a * kSegs) != 0;
+        bad |= w->list_b.reserve(sizeof(int4) * (size_t)w->seg_b * kSegs) != 0;
+    }
+    bad |= w->part1.reserve(sizeof(double) * 3 * kMaxBlocks) != 0;
     bad |= w->part3.reserve(sizeof(double) * 16 * kMaxBlocks) != 0;
     bad |= w->state.reserve(sizeof(IcpState)) != 0;
     bad |= w->trace.reserve(sizeof(float) * 16 * kTraceCap) != 0;
@@ -999,70 +1325,100 @@ extern "C" void lsnIcpDestroy(LsnIcp *w)
 static inline int blocks_for(int n) { return (n + kThreads - 1) / kThreads; }
 static inline int capped_blocks(int n) { int b = blocks_for(n); return b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b); }
 
-// Builds the voxel grid over the target cloud (stream ordered, no host synchronisation).
-static int build_grid(LsnIcp *w, const float *d_verts1, int n1, hipStream_t s)
+// Builds the voxel grid over a cloud (stream ordered, no host synchronisation): g.sorted = the points in cell order with
+// their original index; with_boxes adds the block / super-block AABBs the query kernel culls with.
+static int build_grid(LsnIcp *w, GridBufs &g, const float *d_pts, int n, bool with_boxes, hipStream_t s)
 {
-    const int nb = capped_blocks(n1);
-    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kThreads), 0, s, d_verts1, n1, w->bbox_part.as<float>());
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, s, w->bbox_part.as<float>(), nb, n1, w->cell_override,
-                       w->gp.as<GridParams>());
-    LSN_HIP(hipMemsetAsync(w->cell_cnt.p, 0, sizeof(int) * (size_t)kMaxCells, s));
-    hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(kThreads), 0, s, d_verts1, n1, w->gp.as<GridParams>(), w->cell_of.as<int>(),
-                       w->cell_cnt.as<int>());
+    const int nb = capped_blocks(n);
+    GridParams *gp = g.gp.as<GridParams>();
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kThreads), 0, s, d_pts, n, w->bbox_part.as<float>());
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, s, w->bbox_part.as<float>(), nb, n, w->cell_override, gp);
+    LSN_HIP(hipMemsetAsync(g.cell_cnt.p, 0, sizeof(int) * (size_t)kMaxCells, s));
+    hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(kThreads), 0, s, d_pts, n, gp, g.cell_of.as<int>(), g.cell_cnt.as<int>());
     const int sb = kMaxCells / kScanBlock;  // 1024
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sb), dim3(kThreads), 0, s, w->cell_cnt.as<int>(), w->gp.as<GridParams>(),
-                       w->block_sums.as<int>());
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sb), dim3(kThreads), 0, s, g.cell_cnt.as<int>(), gp, w->block_sums.as<int>());
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, w->block_sums.as<int>(), sb);
-    hipLaunchKernelGGL(scan_finish_kernel, dim3(sb + 1), dim3(kThreads), 0, s, w->cell_cnt.as<int>(), w->gp.as<GridParams>(),
-                       w->block_sums.as<int>(), w->cell_start.as<int>());
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(kThreads), 0, s, d_verts1, n1, w->cell_of.as<int>(), w->cell_start.as<int>(),
-                       w->cell_cnt.as<int>(), w->sorted.as<float4>());
-    hipLaunchKernelGGL(block_box_kernel, dim3(2048), dim3(kThreads), 0, s, (const GridParams *)w->gp.as<GridParams>(),
-                       (const int *)w->cell_start.as<int>(), (const float4 *)w->sorted.as<float4>(), w->boxes.as<Box>());
-    hipLaunchKernelGGL(super_box_kernel, dim3(kMaxSupers), dim3(64), 0, s, (const GridParams *)w->gp.as<GridParams>(),
-                       (const Box *)w->boxes.as<Box>(), w->supers.as<Box>());
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(sb + 1), dim3(kThreads), 0, s, g.cell_cnt.as<int>(), gp, w->block_sums.as<int>(),
+                       g.cell_start.as<int>());
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(kThreads), 0, s, d_pts, n, g.cell_of.as<int>(), g.cell_start.as<int>(),
+                       g.cell_cnt.as<int>(), g.sorted.as<float4>());
+    if (with_boxes) {
+        hipLaunchKernelGGL(block_box_kernel, dim3(2048), dim3(kThreads), 0, s, (const GridParams *)gp, (const int *)g.cell_start.as<int>(),
+                           (const float4 *)g.sorted.as<float4>(), g.boxes.as<Box>());
+        hipLaunchKernelGGL(super_box_kernel, dim3(kMaxSupers), dim3(64), 0, s, (const GridParams *)gp, (const Box *)g.boxes.as<Box>(),
+                           g.supers.as<Box>());
+    }
     LSN_HIP(hipGetLastError());
     return 0;
 }
 
-static int run_nn(LsnIcp *w, const float *d_verts1, int n1, const float *d_verts2, int n2, int *d_idx, float *d_dist,
-                  unsigned long long *keys, int nn_mode, hipStream_t s, bool seeded = false)
+static NnWork work_of(LsnIcp *w)
 {
+    NnWork wk;
+    wk.list_a = w->list_a.as<uint2>();
+    wk.list_b = w->list_b.as<int4>();
+    wk.seg_a = w->seg_a;
+    wk.seg_b = w->seg_b;
+    wk.counters = w->counters.as<int>();
+    return wk;
+}
+
+constexpr int kBlocksGrid = 1024;   // workgroups of nn_blocks_kernel (4 items in flight each; they loop over the list)
+constexpr int kScanGrid = 2048;     // workgroups of nn_scan_kernel
+
+// One NN step over the sorted working copy of the source (w->src.sorted, n2 queries); results land at the queries'
+// ORIGINAL positions in d_idx / d_dist.  seeded: d_idx holds every query's previous neighbour (ICP iterations > 0); the
+// first launch then also applies the previous iteration's motion (st) to the source and clears `keys`.
+// `bank` alternates between consecutive steps on a stream (the counters of the other bank are cleared meanwhile).
+static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int n2, int *d_idx, float *d_dist, unsigned long long *keys,
+                  int nn_mode, hipStream_t s, bool seeded, const IcpState *st, int bank)
+{
+    float4 *src = w->src.sorted.as<float4>();
     if (nn_mode == 0) {
-        hipLaunchKernelGGL(nn_brute_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts1, n1, d_verts2, n2, (const int *)nullptr,
-                           (const int *)nullptr, d_idx, d_dist, keys);
-    } else {
-        int *n_unres = w->counters.as<int>();
-        LSN_HIP(hipMemsetAsync(n_unres, 0, sizeof(int), s));
-        hipLaunchKernelGGL(nn_grid_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts2, n2, w->gp.as<GridParams>(),
-                           w->cell_start.as<int>(), w->sorted.as<float4>(), d_idx, d_dist, keys, w->unresolved.as<int>(), n_unres,
-                           seeded ? d_verts1 : (const float *)nullptr, n1);
-        const int *far = w->unresolved.as<int>();
-        const int *n_far = n_unres;
-        if (seeded) {
-            // every far query carries its previous neighbour: the proving kernel takes them; only queries without a
-            // finite candidate go on to the exploring kernel
-            LSN_HIP(hipMemsetAsync(n_unres + 1, 0, sizeof(int), s));
-            hipLaunchKernelGGL(nn_far_seeded_kernel, dim3((n2 + 3) / 4), dim3(kThreads), 0, s, d_verts2, (const GridParams *)w->gp.as<GridParams>(),
-                               (const int *)w->cell_start.as<int>(), (const float4 *)w->sorted.as<float4>(), (const Box *)w->boxes.as<Box>(),
-                               (const Box *)w->supers.as<Box>(), far, n_far, d_idx, d_dist, keys, w->unresolved2.as<int>(), n_unres + 1);
-            far = w->unresolved2.as<int>();
-            n_far = n_unres + 1;
-        }
-        // the queries nothing above could prove; workgroups beyond the list length exit at once
-        hipLaunchKernelGGL(nn_far_kernel, dim3((n2 + 3) / 4), dim3(kThreads), 0, s, d_verts2, (const GridParams *)w->gp.as<GridParams>(),
-                           (const int *)w->cell_start.as<int>(), (const float4 *)w->sorted.as<float4>(), (const Box *)w->boxes.as<Box>(),
-                           (const Box *)w->supers.as<Box>(), far, n_far, d_idx, d_dist, keys);
+        hipLaunchKernelGGL(nn_brute_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts1, n1, (const float4 *)src, n2, d_idx, d_dist, keys);
+        LSN_HIP(hipGetLastError());
+        return 0;
     }
+    const GridParams *gp = w->tgt.gp.as<GridParams>();
+    const float4 *sorted = w->tgt.sorted.as<float4>();
+    const Box *boxes = w->tgt.boxes.as<Box>(), *supers = w->tgt.supers.as<Box>();
+    unsigned long long *best_key = w->best_key.as<unsigned long long>();
+    GroupInfo *groups = w->groups.as<GroupInfo>();
+    const NnWork wk = work_of(w);
+    const int n_groups = (n2 + 63) / 64;
+    const dim3 per_group((n_groups + kThreads / 64 - 1) / (kThreads / 64));
+    if (seeded) {
+        hipLaunchKernelGGL(nn_cull_kernel<true>, per_group, dim3(kThreads), 0, s, src, d_verts2, n2, st, keys, n1, gp, supers, d_verts1, n1,
+                           (const int *)d_idx, best_key, groups, wk, bank);
+    } else {
+        hipLaunchKernelGGL(nn_seedless_kernel, per_group, dim3(kThreads), 0, s, (const float4 *)src, n2, gp, boxes, supers, best_key, wk, bank);
+        hipLaunchKernelGGL(nn_scan_kernel, dim3(kScanGrid), dim3(kThreads), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, 2);
+        hipLaunchKernelGGL(nn_cull_kernel<false>, per_group, dim3(kThreads), 0, s, src, (float *)nullptr, n2, (const IcpState *)nullptr,
+                           (unsigned long long *)nullptr, 0, gp, supers, (const float *)nullptr, n1, (const int *)nullptr, best_key, groups, wk, bank);
+    }
+    hipLaunchKernelGGL(nn_blocks_kernel, dim3(kBlocksGrid), dim3(kThreads), 0, s, (const float4 *)src, n2, boxes,
+                       (const unsigned long long *)best_key, (const GroupInfo *)groups, wk, bank);
+    hipLaunchKernelGGL(nn_scan_kernel, dim3(kScanGrid), dim3(kThreads), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, 1);
+    hipLaunchKernelGGL(nn_finish_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, (const float4 *)src, n2, gp, sorted, boxes, supers,
+                       (const unsigned long long *)best_key, d_idx, d_dist, keys, wk, bank);
     LSN_HIP(hipGetLastError());
-    static const bool debug = getenv("LSN_ICP_DEBUG") != nullptr;   // dev aid: synchronises, prints the far-list sizes and the grid
-    if (debug && nn_mode != 0) {
-        int c[2] = {0, 0};
+    static const bool debug = getenv("LSN_ICP_DEBUG") != nullptr;   // dev aid: synchronises and prints the work-list sizes and the grid
+    if (debug) {
+        int c[2 * kBankInts];
         GridParams g;
         (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(c, w->counters.p, sizeof(c), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&g, w->gp.p, sizeof(g), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[lsn icp] n2=%d far=%d far2=%d h=%g grid=%dx%dx%d\n", n2, c[0], seeded ? c[1] : -1, (double)g.h, g.nx, g.ny, g.nz);
+        (void)hipMemcpy(c, w->counters.p, sizeof(c), hipMemcpyDeviceToHost);   // (the other bank has been cleared by now)
+        (void)hipMemcpy(&g, w->tgt.gp.p, sizeof(g), hipMemcpyDeviceToHost);
+        const int *b = c + kBankInts * bank;
+        long long na = 0, nb = 0, ns = 0;
+        int ma = 0, mb = 0;
+        for (int k = 0; k < kSegs; k++) {
+            na += b[k]; nb += b[kSegs + k]; ns += b[2 * kSegs + k];
+            ma = b[k] > ma ? b[k] : ma;
+            mb = b[kSegs + k] + b[2 * kSegs + k] > mb ? b[kSegs + k] + b[2 * kSegs + k] : mb;
+        }
+        fprintf(stderr, "[lsn icp] n1=%d n2=%d groups=%d seeded=%d h=%g grid=%dx%dx%d supers=%d; items: super-blocks %lld (fullest segment %d of %d), ranges %lld + seed ranges %lld (fullest segment %d of %d), overflow %d\n",
+                n1, n2, n_groups, (int)seeded, (double)g.h, g.nx, g.ny, g.nz, g.ncells / 4096, na, ma, w->seg_a, nb, ns, mb, w->seg_b, b[3 * kSegs]);
     }
     return 0;
 }
@@ -1092,8 +1448,10 @@ extern "C" int lsnIcpNearest(LsnIcp *w, const float *d_verts1, int n1, const flo
     std::lock_guard<std::mutex> g(w->mu);
     LSN_HIP(hipSetDevice(w->device));
     hipStream_t s = lsn::as_stream(stream);
-    if (nn_mode != 0 && build_grid(w, d_verts1, n1, s)) return -1;
-    return run_nn(w, d_verts1, n1, d_verts2, n2, d_idx, d_dist2, nullptr, nn_mode, s);
+    if (nn_mode != 0 && build_grid(w, w->tgt, d_verts1, n1, true, s)) return -1;
+    if (build_grid(w, w->src, d_verts2, n2, false, s)) return -1;
+    LSN_HIP(hipMemsetAsync(w->counters.p, 0, sizeof(int) * 2 * kBankInts, s));
+    return run_nn(w, d_verts1, n1, nullptr, n2, d_idx, d_dist2, nullptr, nn_mode, s, false, nullptr, 0);
 }
 
 extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int n2, float *d_R, float *d_t, int maxIter,
@@ -1111,25 +1469,32 @@ extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_vert
     w->trace_iters = maxIter < kTraceCap ? (maxIter > 0 ? maxIter : 0) : kTraceCap;
     if (maxIter <= 0) return 0;
 
-    if (nn_mode != 0 && build_grid(w, d_verts1, n1, s)) return -1;  // the target is fixed: one build for all iterations
+    // the target is fixed: one grid for all iterations; the source is sorted once (rigid motion keeps neighbours together)
+    if (nn_mode != 0 && build_grid(w, w->tgt, d_verts1, n1, true, s)) return -1;
+    if (build_grid(w, w->src, d_verts2, n2, false, s)) return -1;
 
     const int nb = capped_blocks(n2);
     unsigned long long *keys = w->keys.as<unsigned long long>();
     IcpState *st = w->state.as<IcpState>();
+    LSN_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)n1, s));
+    LSN_HIP(hipMemsetAsync(w->counters.p, 0, sizeof(int) * 2 * kBankInts, s));
     for (int iter = 0; iter < maxIter; iter++) {
-        LSN_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)n1, s));
-        // from the second iteration on idx[] still holds every query's previous neighbour: the search is seeded with it
-        if (run_nn(w, d_verts1, n1, d_verts2, n2, w->idx.as<int>(), w->dist.as<float>(), keys, nn_mode, s, iter > 0 && w->seed_nn)) return -1;
-        hipLaunchKernelGGL(stats1_kernel, dim3(nb), dim3(kThreads), 0, s, w->idx.as<int>(), w->dist.as<float>(), keys, n2,
+        // from the second iteration on idx[] still holds every query's previous neighbour: the search is seeded with it, and
+        // its first launch also carries out the previous iteration's motion and clears the match keys
+        const bool fused = iter > 0 && w->seed_nn && nn_mode != 0;
+        if (iter > 0 && !fused)
+            hipLaunchKernelGGL(apply_kernel, dim3(blocks_for(n2 > n1 ? n2 : n1)), dim3(kThreads), 0, s, w->src.sorted.as<float4>(), d_verts2, n2,
+                               (const IcpState *)st, keys, n1);
+        if (run_nn(w, d_verts1, n1, d_verts2, n2, w->idx.as<int>(), w->dist.as<float>(), keys, nn_mode, s, fused, st, iter & 1)) return -1;
+        hipLaunchKernelGGL(stats_kernel, dim3(nb), dim3(kThreads), 0, s, w->idx.as<int>(), w->dist.as<float>(), keys, n2,
                            w->part1.as<double>());
-        hipLaunchKernelGGL(stats2_kernel, dim3(nb), dim3(kThreads), 0, s, w->idx.as<int>(), w->dist.as<float>(), keys, n2,
-                           w->part1.as<double>(), nb, w->part2.as<double>(), st);
         hipLaunchKernelGGL(accum_kernel, dim3(nb), dim3(kThreads), 0, s, d_verts1, (const float *)d_verts2, w->idx.as<int>(),
-                           w->dist.as<float>(), keys, n2, w->part2.as<double>(), nb, w->part3.as<double>(), st);
+                           w->dist.as<float>(), keys, n2, w->part1.as<double>(), nb, w->part3.as<double>(), st);
         hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(kThreads), 0, s, w->part3.as<double>(), nb, d_R, d_t, st,
                            iter < kTraceCap ? w->trace.as<float>() : (float *)nullptr, iter);
-        hipLaunchKernelGGL(apply_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts2, n2, (const IcpState *)st);
     }
+    hipLaunchKernelGGL(apply_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, w->src.sorted.as<float4>(), d_verts2, n2, (const IcpState *)st,
+                       keys, 0);
     LSN_HIP(hipGetLastError());
     return 0;
 }
