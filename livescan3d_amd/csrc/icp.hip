@@ -41,6 +41,7 @@ constexpr int kSuper = 16;            // cells per super-block edge
 constexpr int kMaxSupers = kMaxCells / (kSuper * kSuper * kSuper);  // 1024
 constexpr int kMaxBlocks3 = kMaxCells / 64;                          // 4^3-cell blocks
 constexpr int kBfTile = 1024;         // targets per LDS tile in the brute-force kernel
+constexpr int kChunk = 256;            // points per scan item (4 LDS batches of 64)
 constexpr int kSeedBlocks = 4;        // blocks nearest to a query patch that are scanned first when it has no candidates yet
 
 struct GridParams {
@@ -446,44 +447,62 @@ __device__ __forceinline__ void lex_update(float d, int k, float &best, int &bes
     }
 }
 
+__device__ __forceinline__ void scan_batch(const float4 &p, int cnt, WaveStage &st, int lane, f2v qx2, f2v qy2, f2v qz2, float &best, int &best_i)
+{
+    st.x[lane] = p.x;
+    st.y[lane] = p.y;
+    st.z[lane] = p.z;
+    st.i[lane] = __float_as_int(p.w);
+    wave_lds_fence();
+    for (int t = 0; t < cnt; t += 8) {  // two independent groups of four per step (fills the issue slots between dependent packed ops)
+        const f4v d = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&st.x[t]), *reinterpret_cast<const f4v *>(&st.y[t]),
+                              *reinterpret_cast<const f4v *>(&st.z[t]));
+        const f4v e = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&st.x[t + 4]), *reinterpret_cast<const f4v *>(&st.y[t + 4]),
+                              *reinterpret_cast<const f4v *>(&st.z[t + 4]));
+        const float m = fminf(fminf(fminf(d.x, d.y), fminf(d.z, d.w)), fminf(fminf(e.x, e.y), fminf(e.z, e.w)));  // fminf skips NaN
+        if (__ballot(m <= best)) {                                                                                 // wave-uniform branch
+            const i4v K = *reinterpret_cast<const i4v *>(&st.i[t]);
+            const i4v L = *reinterpret_cast<const i4v *>(&st.i[t + 4]);
+            lex_update(d.x, K.x, best, best_i);
+            lex_update(d.y, K.y, best, best_i);
+            lex_update(d.z, K.z, best, best_i);
+            lex_update(d.w, K.w, best, best_i);
+            lex_update(e.x, L.x, best, best_i);
+            lex_update(e.y, L.y, best, best_i);
+            lex_update(e.z, L.z, best, best_i);
+            lex_update(e.w, L.w, best, best_i);
+        }
+    }
+    wave_lds_fence();
+}
+
+__device__ __forceinline__ float4 load_point_or_pad(const float4 *__restrict__ sorted, int j, int je)
+{
+    float4 p = make_float4(NAN, NAN, NAN, __int_as_float(0x7FFFFFFF));  // padding: its distance is NaN, never taken
+    if (j < je) p = sorted[j];
+    return p;
+}
+
 // Every lane (one query each) against the points sorted[js, je): the wave loads 64 points at a time with one coalesced
-// 16-byte load per lane, parks them in its LDS stage and then walks them four at a time -- all lanes read the same LDS
-// address (broadcast), the twelve differences / products / sums run as packed f32 pairs (one rounding per operation, the
-// order of PointCloud::kdtree_distance, icp.h:40-47).  Only the minimum of the four distances is compared with the lane's
-// best; the (distance, index) bookkeeping runs in the rare case that some lane of the wave is improved or tied.
+// 16-byte load per lane -- up to four such batches in flight at once, one memory round trip per kChunk points -- parks a
+// batch in its LDS stage and then walks it eight points at a time: all lanes read the same LDS address (broadcast), the
+// differences / products / sums run as packed f32 pairs (one rounding per operation, the order of
+// PointCloud::kdtree_distance, icp.h:40-47).  Only the minimum of the eight distances is compared with the lane's best;
+// the (distance, index) bookkeeping runs in the rare case that some lane of the wave is improved or tied.
 __device__ __forceinline__ void scan_points(const float4 *__restrict__ sorted, int js, int je, WaveStage &st, int lane, float qx, float qy,
                                             float qz, float &best, int &best_i)
 {
     const f2v qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
-    for (int base = js; base < je; base += 64) {
-        const int cnt = min(64, je - base);  // wave-uniform
-        float4 p = make_float4(NAN, NAN, NAN, __int_as_float(0x7FFFFFFF));  // padding: its distance is NaN, never taken
-        if (lane < cnt) p = sorted[base + lane];
-        st.x[lane] = p.x;
-        st.y[lane] = p.y;
-        st.z[lane] = p.z;
-        st.i[lane] = __float_as_int(p.w);
-        wave_lds_fence();
-        for (int t = 0; t < cnt; t += 8) {  // two independent groups of four per step (fills the issue slots between dependent packed ops)
-            const f4v d = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&st.x[t]), *reinterpret_cast<const f4v *>(&st.y[t]),
-                                  *reinterpret_cast<const f4v *>(&st.z[t]));
-            const f4v e = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&st.x[t + 4]), *reinterpret_cast<const f4v *>(&st.y[t + 4]),
-                                  *reinterpret_cast<const f4v *>(&st.z[t + 4]));
-            const float m = fminf(fminf(fminf(d.x, d.y), fminf(d.z, d.w)), fminf(fminf(e.x, e.y), fminf(e.z, e.w)));  // fminf skips NaN
-            if (__ballot(m <= best)) {                                                                                 // wave-uniform branch
-                const i4v K = *reinterpret_cast<const i4v *>(&st.i[t]);
-                const i4v L = *reinterpret_cast<const i4v *>(&st.i[t + 4]);
-                lex_update(d.x, K.x, best, best_i);
-                lex_update(d.y, K.y, best, best_i);
-                lex_update(d.z, K.z, best, best_i);
-                lex_update(d.w, K.w, best, best_i);
-                lex_update(e.x, L.x, best, best_i);
-                lex_update(e.y, L.y, best, best_i);
-                lex_update(e.z, L.z, best, best_i);
-                lex_update(e.w, L.w, best, best_i);
-            }
-        }
-        wave_lds_fence();
+    for (int base = js; base < je; base += kChunk) {
+        const float4 p0 = load_point_or_pad(sorted, base + lane, je);
+        const float4 p1 = load_point_or_pad(sorted, base + 64 + lane, je);
+        const float4 p2 = load_point_or_pad(sorted, base + 128 + lane, je);
+        const float4 p3 = load_point_or_pad(sorted, base + 192 + lane, je);
+        const int left = je - base;  // wave-uniform
+        scan_batch(p0, min(64, left), st, lane, qx2, qy2, qz2, best, best_i);
+        if (left > 64) scan_batch(p1, min(64, left - 64), st, lane, qx2, qy2, qz2, best, best_i);
+        if (left > 128) scan_batch(p2, min(64, left - 128), st, lane, qx2, qy2, qz2, best, best_i);
+        if (left > 192) scan_batch(p3, min(64, left - 192), st, lane, qx2, qy2, qz2, best, best_i);
     }
 }
 
@@ -520,7 +539,6 @@ __device__ __forceinline__ void scan_points(const float4 *__restrict__ sorted, i
 // Queries with a non-finite coordinate do not take part in the culling (they would open every box); they end with
 // index 0 / distance +inf, which is what the search gives them when target 0 is finite.
 
-constexpr int kChunk = 256;             // points per scan item (4 LDS batches)
 constexpr unsigned long long kNoKey = 0x7F8000007FFFFFFFull;  // (+inf, no index)
 
 struct GroupInfo {  // per query group, written by nn_cull_kernel
@@ -532,7 +550,11 @@ struct GroupInfo {  // per query group, written by nn_cull_kernel
 constexpr int kSegs = 64;        // the work lists are cut into 64 segments with a counter each: an append is one atomicAdd per
                                  // wave on the counter of segment (group mod 64) -- a single counter serialised ~10^4 atomics
                                  // per step on one address (measured: 30-50 us per launch)
-constexpr int kBankInts = 256;   // counters of one bank: [0,64) list A, [64,128) list B, [128,192) seed-round part of B, [192] overflow
+constexpr int kSegStride = 32;  // ints between two segments' counters: one 128-byte line each -- atomics on one line serialise in its L2 channel
+                                // whatever the address (measured: 8 k appends on 64 adjacent counters took as long as on one)
+constexpr int kCntA = 0, kCntB = 1, kCntSeed = 2;          // a segment's counters inside its line: list A, list B, seed-round part of B
+constexpr int kOverflow = kSegs * kSegStride;              // the bank's overflow flag
+constexpr int kBankInts = kSegs * kSegStride + kSegStride; // ints per bank
 
 struct NnWork {  // device work lists of one ICP workspace
     uint2 *list_a;      // (group, super-block), segment s = entries [s * seg_a, (s + 1) * seg_a)
@@ -541,31 +563,8 @@ struct NnWork {  // device work lists of one ICP workspace
     int *counters;      // two banks of kBankInts
 };
 
-// A consumer wave's view of a segmented list: lane l holds the (clamped) length of segment l; item number `it` of the
-// concatenation is entry (it - excl[seg]) of segment seg = number of segments that end at or before it.
-struct SegView {
-    int incl, excl, total;
-};
-__device__ __forceinline__ SegView seg_view(const int *counts, int seg_cap, int lane)
-{
-    const int c = min(counts[lane], seg_cap);
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    SegView v;
-    v.incl = incl;
-    v.excl = incl - c;
-    v.total = __shfl(incl, 63, 64);
-    return v;
-}
-__device__ __forceinline__ int seg_locate(const SegView &v, int it, int seg_cap)
-{
-    const int seg = __popcll(__ballot(v.incl <= it));
-    return seg * seg_cap + (it - __shfl(v.excl, seg, 64));
-}
+// Consumers: wave w of a launch serves segment (w mod 64), entries w / 64, w / 64 + waves / 64, ...: the segment's length
+// and the wave's first entry are independent loads (one memory round trip before the work starts, no prefix sums).
 
 __device__ __forceinline__ unsigned long long pack_key(float d, int k)
 {
@@ -588,18 +587,27 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane)
 }
 
 // Appends the point range [js, je) of every lane with `take` set to list B as (group, range) items of <= kChunk points.
-__device__ __forceinline__ void emit_ranges(const NnWork &wk, int *seg_counters, int *overflow, int g, bool take, int js, int je, int lane)
+// `spread` picks the segment: a heavy group's ranges are spread over the segments by its super-blocks.
+__device__ __forceinline__ void emit_ranges(const NnWork &wk, int *bank, int which, int g, int spread, bool take, int js, int je, int lane)
 {
     const int n_items = take ? (je - js + kChunk - 1) / kChunk : 0;
     const int before = wave_excl_scan_i(n_items, lane);
     const int total = __shfl(before + n_items, 63, 64);
     if (total == 0) return;  // wave-uniform
-    const int seg = g & (kSegs - 1);
+    const int seg = spread & (kSegs - 1);
     int base = 0;
-    if (lane == 0) base = atomicAdd(seg_counters + seg, total);
+    if (lane == 0) base = atomicAdd(bank + seg * kSegStride + which, total);
     base = __shfl(base, 0, 64);
-    if (base + total > wk.seg_b) {
-        if (lane == 0) atomicExch(overflow, 1);
+    if (which == kCntSeed) {
+        // the seed round's items sit at the top of the segment, growing downwards, the search's at the bottom: they only meet
+        // when the segment is full
+        base = wk.seg_b - base - total;
+        if (base < 0) {
+            if (lane == 0) atomicExch(bank + kOverflow, 1);
+            return;
+        }
+    } else if (base + total > wk.seg_b) {
+        if (lane == 0) atomicExch(bank + kOverflow, 1);
         return;
     }
     for (int c = 0; c < n_items; c++) {
@@ -734,8 +742,7 @@ __global__ __launch_bounds__(kThreads) void nn_seedless_kernel(const float4 *__r
         chosen |= 1ull << b;
         if (lane == b) mb = INFINITY;
     }
-    int *cnt = wk.counters + kBankInts * bank;
-    emit_ranges(wk, cnt + 2 * kSegs, cnt + 3 * kSegs, g, (chosen >> lane) & 1, __float_as_int(bb.pad0), __float_as_int(bb.pad1), lane);
+    emit_ranges(wk, wk.counters + kBankInts * bank, kCntSeed, g, g, (chosen >> lane) & 1, __float_as_int(bb.pad0), __float_as_int(bb.pad1), lane);
 }
 
 // One wave per query group.  APPLY: first move the group's queries by the previous iteration's (T, Rn) -- icp.cpp:143-146 +
@@ -806,10 +813,10 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *v
     if (total == 0) return;
     const int seg = g & (kSegs - 1);
     int base = 0;
-    if (lane == 0) base = atomicAdd(cnt + seg, total);
+    if (lane == 0) base = atomicAdd(cnt + seg * kSegStride + kCntA, total);
     base = __shfl(base, 0, 64);
     if (base + total > wk.seg_a) {
-        if (lane == 0) atomicExch(cnt + 3 * kSegs, 1);
+        if (lane == 0) atomicExch(cnt + kOverflow, 1);
         return;
     }
     uint2 *out = wk.list_a + (size_t)seg * wk.seg_a + base;
@@ -832,11 +839,14 @@ __global__ __launch_bounds__(kThreads) void nn_blocks_kernel(const float4 *__res
 {
     const int lane = threadIdx.x & 63;
     int *cnt = wk.counters + kBankInts * bank;
-    if (cnt[3 * kSegs]) return;  // a list overflowed: the finish kernel searches from scratch
-    const SegView view = seg_view(cnt, wk.seg_a, lane);
-    const int n_waves = gridDim.x * (kThreads / 64);
-    for (int it = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); it < view.total; it += n_waves) {
-        const uint2 item = wk.list_a[seg_locate(view, it, wk.seg_a)];
+    if (cnt[kOverflow]) return;  // a list overflowed: the finish kernel searches from scratch
+    const int wave_id = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), stride = (gridDim.x * (kThreads / 64)) >> 6;
+    const int seg = wave_id & (kSegs - 1);
+    const uint2 *list = wk.list_a + (size_t)seg * wk.seg_a;
+    int slot = wave_id >> 6;
+    uint2 item = list[min(slot, wk.seg_a - 1)];  // speculative: issued together with the length
+    const int n_items = min(cnt[seg * kSegStride + kCntA], wk.seg_a);
+    for (; slot < n_items; slot += stride, item = list[min(slot, wk.seg_a - 1)]) {
         const int g = (int)item.x, s = (int)item.y;
         const int j = g * 64 + lane;
         const Box bb = boxes[s * 64 + lane];
@@ -862,24 +872,27 @@ __global__ __launch_bounds__(kThreads) void nn_blocks_kernel(const float4 *__res
             xb.hz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.hz), b));
             if (__ballot(box_min_dist2(q4.x, q4.y, q4.z, xb) <= bound)) take |= 1ull << b;  // some query may find something nearer or tied in it
         }
-        emit_ranges(wk, cnt + kSegs, cnt + 3 * kSegs, g, (take >> lane) & 1, __float_as_int(bb.pad0), __float_as_int(bb.pad1), lane);
+        emit_ranges(wk, cnt, kCntB, g, g + s, (take >> lane) & 1, __float_as_int(bb.pad0), __float_as_int(bb.pad1), lane);
     }
 }
 
 // One wave per (group, point range) item: the group's 64 queries against the range's points; a query whose (distance,
 // index) pair improved merges it into its key -- atomicMin on (distance bits << 32 | index) is the lexicographic minimum.
 __global__ __launch_bounds__(kThreads) void nn_scan_kernel(const float4 *__restrict__ src, int n2, const float4 *__restrict__ sorted,
-                                                           unsigned long long *best_key, NnWork wk, int bank, int counter_slot)
+                                                           unsigned long long *best_key, NnWork wk, int bank, int which)
 {
     __shared__ WaveStage s_stage[kThreads / 64];
     const int lane = threadIdx.x & 63;
     WaveStage &st = s_stage[threadIdx.x >> 6];
     const int *cnt = wk.counters + kBankInts * bank;
-    if (cnt[3 * kSegs]) return;
-    const SegView view = seg_view(cnt + counter_slot * kSegs, wk.seg_b, lane);
-    const int n_waves = gridDim.x * (kThreads / 64);
-    for (int it = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); it < view.total; it += n_waves) {
-        const int4 item = wk.list_b[seg_locate(view, it, wk.seg_b)];
+    if (cnt[kOverflow]) return;
+    const int wave_id = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), stride = (gridDim.x * (kThreads / 64)) >> 6;
+    const int seg = wave_id & (kSegs - 1);
+    const int4 *list = wk.list_b + (size_t)seg * wk.seg_b;
+    int slot = wave_id >> 6;
+    int4 item = list[min(slot, wk.seg_b - 1)];  // speculative: issued together with the length
+    const int n_items = min(cnt[seg * kSegStride + which], wk.seg_b);
+    for (; slot < n_items; slot += stride, item = list[min(slot, wk.seg_b - 1)]) {
         const int j = item.x * 64 + lane;
         float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
         unsigned long long key = kNoKey;
@@ -908,9 +921,10 @@ __global__ __launch_bounds__(kThreads) void nn_finish_kernel(const float4 *__res
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * kThreads + threadIdx.x;
     int *cnt = wk.counters + kBankInts * bank;
-    const bool overflow = cnt[3 * kSegs] != 0;
+    const bool overflow = cnt[kOverflow] != 0;
     // the other bank served the previous step and is read by nobody any more: clear it for the next step
-    if (blockIdx.x == 0) wk.counters[kBankInts * (1 - bank) + threadIdx.x] = 0;
+    if (blockIdx.x == 0)
+        for (int t = threadIdx.x; t < kBankInts; t += kThreads) wk.counters[kBankInts * (1 - bank) + t] = 0;
     const bool active = j < n2;
     float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
     unsigned long long key = kNoKey;
@@ -1087,9 +1101,12 @@ __device__ void svd3(const double A[9], double U[9], double w[3], double V[9])
                 }
                 if (fabs(c) <= 1e-300 || c * c <= 1e-32 * (a * b)) continue;  // columns already orthogonal to ~1e-16
                 rotations++;
-                const double zeta = (b - a) / (2.0 * c);
-                const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                // tan of the rotation: sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (b - a) / (2c), multiplied through
+                // by 2|c| -- one division and one square root per rotation instead of three and two (this thread is the
+                // critical path of an ICP iteration)
+                const double ba = b - a;
+                const double tt = ((ba >= 0) == (c >= 0) ? 2.0 : -2.0) * fabs(c) / (fabs(ba) + sqrt(ba * ba + 4.0 * c * c));
+                const double cs = rsqrt(1.0 + tt * tt), sn = cs * tt;
                 for (int k = 0; k < 3; k++) {
                     const double bp = B[3 * k + p], bq = B[3 * k + q];
                     B[3 * k + p] = cs * bp - sn * bq;
@@ -1117,8 +1134,10 @@ __device__ void svd3(const double A[9], double U[9], double w[3], double V[9])
     }
     for (int i = 0; i < 9; i++) V[i] = Vs[i];
     for (int j = 0; j < 3; j++) w[j] = ws[j];
-    for (int j = 0; j < 3; j++)
-        for (int k = 0; k < 3; k++) U[3 * k + j] = (w[j] > 1e-300) ? Bs[3 * k + j] / w[j] : 0.0;
+    for (int j = 0; j < 3; j++) {
+        const double inv = (w[j] > 1e-300) ? 1.0 / w[j] : 0.0;
+        for (int k = 0; k < 3; k++) U[3 * k + j] = Bs[3 * k + j] * inv;
+    }
     if (!(w[0] > 1e-300)) {
         for (int i = 0; i < 9; i++) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
         return;
@@ -1298,7 +1317,7 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
         // generous: a seeded group needs ~5 super-blocks and ~10 point ranges; $LSN_ICP_TINY_LISTS=1 forces the overflow path (tests)
         const bool tiny = getenv("LSN_ICP_TINY_LISTS") && atoi(getenv("LSN_ICP_TINY_LISTS")) != 0;
         w->seg_a = tiny ? 2 : 1024 + n_groups / 4;   // x 64 segments: 64 k + 16 per group
-        w->seg_b = tiny ? 2 : 4096 + n_groups;       // x 64 segments: 256 k + 64 per group
+        w->seg_b = tiny ? 2 : 8192 + 2 * n_groups;   // x 64 segments: 512 k + 128 per group
         bad |= w->best_key.reserve(sizeof(unsigned long long) * (size_t)max_n2) != 0;
         bad |= w->groups.reserve(sizeof(GroupInfo) * (size_t)n_groups) != 0;
         bad |= w->list_a.reserve(sizeof(uint2) * (size_t)w->seg_a * kSegs) != 0;
@@ -1363,8 +1382,6 @@ static NnWork work_of(LsnIcp *w)
     return wk;
 }
 
-constexpr int kBlocksGrid = 1024;   // workgroups of nn_blocks_kernel (4 items in flight each; they loop over the list)
-constexpr int kScanGrid = 2048;     // workgroups of nn_scan_kernel
 
 // One NN step over the sorted working copy of the source (w->src.sorted, n2 queries); results land at the queries'
 // ORIGINAL positions in d_idx / d_dist.  seeded: d_idx holds every query's previous neighbour (ICP iterations > 0); the
@@ -1387,18 +1404,20 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
     const NnWork wk = work_of(w);
     const int n_groups = (n2 + 63) / 64;
     const dim3 per_group((n_groups + kThreads / 64 - 1) / (kThreads / 64));
+    // consumer launches: a seeded group needs ~3-5 super-blocks and ~5-8 point ranges; longer lists are served by looping
+    const dim3 blocks_grid(16 * ((2 * n_groups + 15) / 16)), scan_grid(16 * ((4 * n_groups + 15) / 16));
     if (seeded) {
         hipLaunchKernelGGL(nn_cull_kernel<true>, per_group, dim3(kThreads), 0, s, src, d_verts2, n2, st, keys, n1, gp, supers, d_verts1, n1,
                            (const int *)d_idx, best_key, groups, wk, bank);
     } else {
         hipLaunchKernelGGL(nn_seedless_kernel, per_group, dim3(kThreads), 0, s, (const float4 *)src, n2, gp, boxes, supers, best_key, wk, bank);
-        hipLaunchKernelGGL(nn_scan_kernel, dim3(kScanGrid), dim3(kThreads), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, 2);
+        hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(kThreads), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntSeed);
         hipLaunchKernelGGL(nn_cull_kernel<false>, per_group, dim3(kThreads), 0, s, src, (float *)nullptr, n2, (const IcpState *)nullptr,
                            (unsigned long long *)nullptr, 0, gp, supers, (const float *)nullptr, n1, (const int *)nullptr, best_key, groups, wk, bank);
     }
-    hipLaunchKernelGGL(nn_blocks_kernel, dim3(kBlocksGrid), dim3(kThreads), 0, s, (const float4 *)src, n2, boxes,
+    hipLaunchKernelGGL(nn_blocks_kernel, blocks_grid, dim3(kThreads), 0, s, (const float4 *)src, n2, boxes,
                        (const unsigned long long *)best_key, (const GroupInfo *)groups, wk, bank);
-    hipLaunchKernelGGL(nn_scan_kernel, dim3(kScanGrid), dim3(kThreads), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, 1);
+    hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(kThreads), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntB);
     hipLaunchKernelGGL(nn_finish_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, (const float4 *)src, n2, gp, sorted, boxes, supers,
                        (const unsigned long long *)best_key, d_idx, d_dist, keys, wk, bank);
     LSN_HIP(hipGetLastError());
@@ -1413,12 +1432,14 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
         long long na = 0, nb = 0, ns = 0;
         int ma = 0, mb = 0;
         for (int k = 0; k < kSegs; k++) {
-            na += b[k]; nb += b[kSegs + k]; ns += b[2 * kSegs + k];
-            ma = b[k] > ma ? b[k] : ma;
-            mb = b[kSegs + k] + b[2 * kSegs + k] > mb ? b[kSegs + k] + b[2 * kSegs + k] : mb;
+            const int *c3 = b + k * kSegStride;
+            na += c3[kCntA]; nb += c3[kCntB]; ns += c3[kCntSeed];
+            ma = c3[kCntA] > ma ? c3[kCntA] : ma;
+            mb = c3[kCntB] > mb ? c3[kCntB] : mb;
+            mb = c3[kCntSeed] > mb ? c3[kCntSeed] : mb;
         }
         fprintf(stderr, "[lsn icp] n1=%d n2=%d groups=%d seeded=%d h=%g grid=%dx%dx%d supers=%d; items: super-blocks %lld (fullest segment %d of %d), ranges %lld + seed ranges %lld (fullest segment %d of %d), overflow %d\n",
-                n1, n2, n_groups, (int)seeded, (double)g.h, g.nx, g.ny, g.nz, g.ncells / 4096, na, ma, w->seg_a, nb, ns, mb, w->seg_b, b[3 * kSegs]);
+                n1, n2, n_groups, (int)seeded, (double)g.h, g.nx, g.ny, g.nz, g.ncells / 4096, na, ma, w->seg_a, nb, ns, mb, w->seg_b, b[kOverflow]);
     }
     return 0;
 }
