@@ -8,21 +8,24 @@
 //   * exact nearest neighbour -- either an LDS-tiled brute force (nn_mode 0) or a voxel grid over the target built
 //     ONCE per call (the target never moves): counting sort by cell, cells ordered super-block (16^3 cells) ->
 //     block (4^3 cells) -> cell so that every block and super-block is one contiguous range of the sorted points,
-//     tight AABBs per block and super-block.  A query first scans the 27 cells around it; that answer is final when
-//     the best f32 distance is provably inside the scanned neighbourhood.  The remaining ("far") queries are
-//     compacted and resolved by a second kernel that walks the two-level AABB hierarchy with exact f32 lower bounds
-//     (a box is skipped only when its minimum distance exceeds the best so far), so the result is the exact NN at
-//     any distance without ever falling back to O(n1) work per query.  Distances are evaluated exactly like
+//     tight AABBs per block and super-block.  The source cloud is sorted the same way once per call, so 64 consecutive
+//     queries form a compact patch ("query group") that shares its candidates: the hierarchy is culled per group and
+//     every surviving block is streamed through LDS for all 64 queries at once, as independent work items spread over
+//     the whole device (see the NN section below).  A box is passed over only when its exact f32 minimum distance
+//     exceeds every query's bound, so the result is the exact NN at any distance.  Distances are evaluated exactly like
 //     PointCloud::kdtree_distance (include/NativeUtils/icp.h:40-47): (d0*d0 + d1*d1) + d2*d2, no FMA.
 //     Equal distances resolve to the lowest target index (nanoflann's tie order is traversal dependent).
 //   * one-to-one matching -- a 64-bit atomicMin per target on (dist_bits << 32 | ~i): minimum distance wins, the
-//     LATER source index wins ties, which is what the sequential scan at icp.cpp:95-126 ends with.
+//     LATER source index wins ties, which is what the sequential scan at icp.cpp:95-126 ends with; a workgroup first
+//     combines its claims in LDS (scene clouds pile thousands of claims onto a few rim targets).
 //   * statistics / Kabsch sums -- wavefront shuffle reductions -> LDS -> one partial per workgroup, combined in a
-//     fixed order in double (deterministic, run-to-run bit-identical).  The accumulators are sum(d), sum((d-mean)^2),
-//     count, sum(m1), sum(m2), sum(m2 m1^T): the reference's solver is closed-form Kabsch, not a 6x6 normal matrix.
+//     fixed order in double over the queries' ORIGINAL order (deterministic, run-to-run bit-identical, independent of
+//     the sort).  The accumulators are count, sum(d), sum(d^2), sum(m1), sum(m2), sum(m2 m1^T): the reference's
+//     solver is closed-form Kabsch, not a 6x6 normal matrix.
 //   * 3x3 SVD -- one-sided Jacobi in double in a single-thread kernel (U*Vt is the polar factor of M: independent
 //     of the SVD algorithm up to rounding), then the same f32 products, det test and updates as icp.cpp:155-168.
-//   * apply -- one fused translate+rotate pass over the source cloud in the reference's f32 operation order.
+//   * apply -- the translate+rotate of the source cloud in the reference's f32 operation order rides in the first
+//     kernel of the next iteration's NN step (one separate pass after the last iteration).
 // This file is compiled with -ffp-contract=off.
 #include "lsn_common.hpp"
 
@@ -598,15 +601,7 @@ __device__ __forceinline__ void emit_ranges(const NnWork &wk, int *bank, int whi
     int base = 0;
     if (lane == 0) base = atomicAdd(bank + seg * kSegStride + which, total);
     base = __shfl(base, 0, 64);
-    if (which == kCntSeed) {
-        // the seed round's items sit at the top of the segment, growing downwards, the search's at the bottom: they only meet
-        // when the segment is full
-        base = wk.seg_b - base - total;
-        if (base < 0) {
-            if (lane == 0) atomicExch(bank + kOverflow, 1);
-            return;
-        }
-    } else if (base + total > wk.seg_b) {
+    if (base + total > wk.seg_b) {  // (the seed round's items are consumed before the search's are written: both start at 0)
         if (lane == 0) atomicExch(bank + kOverflow, 1);
         return;
     }
@@ -833,14 +828,14 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *v
 
 // One wave per (group, super-block) item: the super-block's 64 blocks, one per lane, against the group's box, then each
 // surviving block against every query's own bound; what is left becomes scan items.
-__global__ __launch_bounds__(kThreads) void nn_blocks_kernel(const float4 *__restrict__ src, int n2, const Box *__restrict__ boxes,
+__global__ __launch_bounds__(64) void nn_blocks_kernel(const float4 *__restrict__ src, int n2, const Box *__restrict__ boxes,
                                                              const unsigned long long *__restrict__ best_key,
                                                              const GroupInfo *__restrict__ groups, NnWork wk, int bank)
 {
     const int lane = threadIdx.x & 63;
     int *cnt = wk.counters + kBankInts * bank;
     if (cnt[kOverflow]) return;  // a list overflowed: the finish kernel searches from scratch
-    const int wave_id = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), stride = (gridDim.x * (kThreads / 64)) >> 6;
+    const int wave_id = blockIdx.x, stride = gridDim.x >> 6;  // one wave per workgroup: a slot on the CU is free again as soon as its wave is done
     const int seg = wave_id & (kSegs - 1);
     const uint2 *list = wk.list_a + (size_t)seg * wk.seg_a;
     int slot = wave_id >> 6;
@@ -878,15 +873,14 @@ __global__ __launch_bounds__(kThreads) void nn_blocks_kernel(const float4 *__res
 
 // One wave per (group, point range) item: the group's 64 queries against the range's points; a query whose (distance,
 // index) pair improved merges it into its key -- atomicMin on (distance bits << 32 | index) is the lexicographic minimum.
-__global__ __launch_bounds__(kThreads) void nn_scan_kernel(const float4 *__restrict__ src, int n2, const float4 *__restrict__ sorted,
+__global__ __launch_bounds__(64) void nn_scan_kernel(const float4 *__restrict__ src, int n2, const float4 *__restrict__ sorted,
                                                            unsigned long long *best_key, NnWork wk, int bank, int which)
 {
-    __shared__ WaveStage s_stage[kThreads / 64];
-    const int lane = threadIdx.x & 63;
-    WaveStage &st = s_stage[threadIdx.x >> 6];
+    __shared__ WaveStage st;
+    const int lane = threadIdx.x;
     const int *cnt = wk.counters + kBankInts * bank;
     if (cnt[kOverflow]) return;
-    const int wave_id = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), stride = (gridDim.x * (kThreads / 64)) >> 6;
+    const int wave_id = blockIdx.x, stride = gridDim.x >> 6;  // one wave per workgroup, like nn_blocks_kernel
     const int seg = wave_id & (kSegs - 1);
     const int4 *list = wk.list_b + (size_t)seg * wk.seg_b;
     int slot = wave_id >> 6;
@@ -1404,20 +1398,21 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
     const NnWork wk = work_of(w);
     const int n_groups = (n2 + 63) / 64;
     const dim3 per_group((n_groups + kThreads / 64 - 1) / (kThreads / 64));
-    // consumer launches: a seeded group needs ~3-5 super-blocks and ~5-8 point ranges; longer lists are served by looping
-    const dim3 blocks_grid(16 * ((2 * n_groups + 15) / 16)), scan_grid(16 * ((4 * n_groups + 15) / 16));
+    // consumer launches (one wave per workgroup, a multiple of 64 of them): a seeded group needs ~3-5 super-blocks and ~5-8
+    // point ranges; longer lists are served by looping.  Waves without an item leave after one load.
+    const dim3 blocks_grid(64 * ((6 * n_groups + 63) / 64)), scan_grid(64 * ((8 * n_groups + 63) / 64));
     if (seeded) {
         hipLaunchKernelGGL(nn_cull_kernel<true>, per_group, dim3(kThreads), 0, s, src, d_verts2, n2, st, keys, n1, gp, supers, d_verts1, n1,
                            (const int *)d_idx, best_key, groups, wk, bank);
     } else {
         hipLaunchKernelGGL(nn_seedless_kernel, per_group, dim3(kThreads), 0, s, (const float4 *)src, n2, gp, boxes, supers, best_key, wk, bank);
-        hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(kThreads), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntSeed);
+        hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(64), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntSeed);
         hipLaunchKernelGGL(nn_cull_kernel<false>, per_group, dim3(kThreads), 0, s, src, (float *)nullptr, n2, (const IcpState *)nullptr,
                            (unsigned long long *)nullptr, 0, gp, supers, (const float *)nullptr, n1, (const int *)nullptr, best_key, groups, wk, bank);
     }
-    hipLaunchKernelGGL(nn_blocks_kernel, blocks_grid, dim3(kThreads), 0, s, (const float4 *)src, n2, boxes,
+    hipLaunchKernelGGL(nn_blocks_kernel, blocks_grid, dim3(64), 0, s, (const float4 *)src, n2, boxes,
                        (const unsigned long long *)best_key, (const GroupInfo *)groups, wk, bank);
-    hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(kThreads), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntB);
+    hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(64), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntB);
     hipLaunchKernelGGL(nn_finish_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, (const float4 *)src, n2, gp, sorted, boxes, supers,
                        (const unsigned long long *)best_key, d_idx, d_dist, keys, wk, bank);
     LSN_HIP(hipGetLastError());
