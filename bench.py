@@ -11,7 +11,9 @@ over the ranks (fixed total work: "strong" scaling).  Prints ONE JSON line on ra
 
 Extra objects in the line: "roofline" (dominant kernel: algorithmic bytes 2P + 19V per sensor-frame / HIP-event
 kernel time vs 8 TB/s), "cpu_baseline" (the CPU oracle = port of the reference path, timed on this host's cores on
-a bounded sample, rank 0 at N = 1 only), "icp" (configs[1]: 2 sensors x 512x424, ICP(maxIter=10) ms per iteration).
+a bounded sample, rank 0 at N = 1 only), "icp" (configs[1]: 2 sensors x 512x424, ICP(maxIter=10) ms per iteration, with
+a roofline per kernel group from the library's own HIP events), "icp_config2" (configs[2]: 8 sensors, target = 7 sensors'
+clouds: voxel-grid NN vs brute-force NN).
 """
 import argparse
 import contextlib
@@ -437,6 +439,7 @@ def main():
     if rank == 0 and not args.no_icp:
         with leg(result, "icp"):
             result["icp"] = bench_icp(args, torch, native, synth, dev, stream, with_cpu=(world == 1 and not args.no_cpu))
+            result["icp_config2"] = result["icp"].pop("config2")
 
     # ---- the whole pose-refinement pass (H2 / f-3): N sensors x 2 refine passes x 10 ICP iterations in one call ---------
     if rank == 0 and not multi and not args.no_icp:
@@ -521,39 +524,103 @@ def pmc_traffic(args, S_loc, B, w, h):
     return None if rec is None else rec["hbm_bytes_per_launch"]
 
 
-def bench_icp(args, torch, native, synth, dev, stream, with_cpu):
-    """configs[1]: 2 sensors x 512x424 'scene' frames, sensor 1 mis-calibrated; ICP(maxIter=10), device resident."""
+VALU_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: dense fp32 vector peak (FMA, packed)
+
+
+def _scene_clouds_on_device(torch, synth, dev, n_sensors, w=512, h=424):
+    """The per-sensor clouds of one scene tick, produced by the fusion kernels themselves (device tensors [n_i, 3] f32)."""
     from livescan3d_amd.fusion import DeviceFusion, upload_rig
-    w, h, iters = 512, 424, 10
-    rig = synth.make_rig("scene", 2, w, h, seed=4, perturb=True)
+    rig = synth.make_rig("scene", n_sensors, w, h, seed=4, perturb=True)
     fus = DeviceFusion(1, rig.widths, rig.heights, device=dev.index)
     fus.set_params(rig.intr, rig.wt, rig.bounds)
     d, c = upload_rig(rig, 1, dev.index)
     v, off = fus.run(d, c)
     torch.cuda.synchronize()
     off = off[0].cpu().numpy()
-    xyz = v[0, :int(off[2]), 4:16].contiguous().view(torch.float32).view(-1, 3)
-    tgt = xyz[:int(off[1])].contiguous()
-    src0 = xyz[int(off[1]):].contiguous()
+    xyz = v[0, :int(off[-1]), 4:16].contiguous().view(torch.float32).view(-1, 3)
+    return [xyz[int(off[i]):int(off[i + 1])].contiguous() for i in range(n_sensors)]
+
+
+def _time_icp(torch, native, ws, tgt, src0, iters, mode, reps, stream, dev, profile=False):
+    """Best-of-reps wall time of one lsnIcpRun (HIP events on the launch stream); with profile=True also the library's own
+    phase timing of the best run and the number of one-to-one matches of the last iteration."""
+    n1, n2 = tgt.shape[0], src0.shape[0]
+    best, best_prof = None, None
+    ws.set_profiling(profile)
+    for r in range(reps + 1):
+        src = src0.clone()
+        Rt = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        ws.run(tgt.data_ptr(), n1, src.data_ptr(), n2, Rt.data_ptr(), Rt.data_ptr() + 36, iters, mode, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        if r > 0 or reps == 1:
+            t = e0.elapsed_time(e1)
+            if best is None or t < best:
+                best = t
+                best_prof = ws.profile(stream) if profile else None
+    ws.set_profiling(False)
+    return best, best_prof
+
+
+def _icp_roofline(n1, n2, m, iters, prof, brute_ms=None):
+    """Per kernel group: SURVEY 8(d)'s algorithmic bytes per iteration / the library's HIP-event time per iteration / 8 TB/s.
+    The apply pass of iteration k rides in the first NN kernel of iteration k+1, so the NN group carries its 24 n2 bytes."""
+    out = {}
+    nn_bytes = 12 * n1 + 12 * n2 + 8 * n2 + 24 * n2 * (iters - 1) / iters
+    mr_bytes = 16 * n2 + 8 * n1 + 24 * m
+    for name, nbytes, ms in (("nn_and_apply", nn_bytes, prof["nn"] / iters), ("match_reject_reduce_solve", mr_bytes, prof["match_reduce_solve"] / iters)):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[name] = {"bound": "hbm", "algorithmic_bytes": int(nbytes), "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    out["build_ms_per_call"] = prof["build"]
+    out["final_apply_ms"] = prof["final_apply"]
+    if brute_ms is not None:
+        tf = 8.0 * n1 * n2 / (brute_ms * 1e-3) / 1e12
+        out["nn_brute"] = {"bound": "valu", "flop": 8.0 * n1 * n2, "ms": brute_ms, "achieved": tf, "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / VALU_F32_PEAK_TF}
+    return out
+
+
+def _time_nn(torch, native, ws, tgt, src, mode, stream, dev, reps=3):
+    n1, n2 = tgt.shape[0], src.shape[0]
+    idx = torch.empty(n2, dtype=torch.int32, device=dev)
+    d2 = torch.empty(n2, dtype=torch.float32, device=dev)
+    best = None
+    for r in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        ws.nearest(tgt.data_ptr(), n1, src.data_ptr(), n2, idx.data_ptr(), d2.data_ptr(), mode, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        if r > 0:
+            t = e0.elapsed_time(e1)
+            best = t if best is None or t < best else best
+    return best, idx, d2
+
+
+def bench_icp(args, torch, native, synth, dev, stream, with_cpu):
+    """configs[1]: 2 sensors x 512x424 'scene' frames, sensor 1 mis-calibrated; ICP(maxIter=10), device resident.
+    configs[2] (under "config2"): 8 sensors x 512x424, target = 7 sensors, source = 1: voxel-grid NN vs brute-force NN."""
+    iters = 10
+    clouds = _scene_clouds_on_device(torch, synth, dev, 2)
+    tgt, src0 = clouds[0], clouds[1]
     n1, n2 = tgt.shape[0], src0.shape[0]
     ws = native.IcpWorkspace(dev.index, n1, n2)
-    out = {"workload": "configs[1]: 2 sensors x 512x424 scene frames, ICP(maxIter=10), device resident", "n1": n1, "n2": n2}
-    for name, mode in (("grid", native.NN_GRID), ("brute", native.NN_BRUTE)):
-        reps = args.icp_reps if mode == native.NN_GRID else 1
-        times = []
-        for r in range(reps + 1):
-            src = src0.clone()
-            Rt = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            ws.run(tgt.data_ptr(), n1, src.data_ptr(), n2, Rt.data_ptr(), Rt.data_ptr() + 36, iters, mode, stream)
-            e1.record()
-            torch.cuda.synchronize()
-            if r > 0 or reps == 1:
-                times.append(e0.elapsed_time(e1))
-        out[f"iter_ms_{name}"] = min(times) / iters
+    out = {"workload": "configs[1]: 2 sensors x 512x424 scene frames, ICP(maxIter=10), device resident", "n1": n1, "n2": n2,
+           "parity": "NN pinned to the reference's nanoflann fixtures; match / rejection / Kabsch steps PARITY UNPINNED (OpenCV 3.2 binaries absent), checked against the CPU restatement at 1e-4"}
+    t_grid, _ = _time_icp(torch, native, ws, tgt, src0, iters, native.NN_GRID, args.icp_reps, stream, dev)
+    t_brute, _ = _time_icp(torch, native, ws, tgt, src0, iters, native.NN_BRUTE, 1, stream, dev)
+    out["iter_ms_grid"] = t_grid / iters
+    out["iter_ms_brute"] = t_brute / iters
     out["iter_ms"] = out["iter_ms_grid"]
+    # per-group roofline from the library's own events (a separate profiled run: the events cost a few microseconds per iteration)
+    t_prof, prof = _time_icp(torch, native, ws, tgt, src0, iters, native.NN_GRID, 2, stream, dev, profile=True)
+    m_last = int(ws.trace(iters, stream)[-1][0])
+    brute_nn_ms, _, _ = _time_nn(torch, native, ws, tgt, src0, native.NN_BRUTE, stream, dev, reps=1)
+    out["roofline"] = _icp_roofline(n1, n2, m_last, iters, prof, brute_ms=brute_nn_ms)
+    out["profiled_iter_ms"] = t_prof / iters
     if with_cpu:
         from oracle import orc
         cores = os.cpu_count() or 1
@@ -571,6 +638,29 @@ def bench_icp(args, torch, native, synth, dev, stream, with_cpu):
             orc.ref_nn(t_np, s_np)
             out["cpu_reference_nn_ms"] = 1e3 * (time.perf_counter() - t0)
             out["cpu_reference_nn_kind"] = "reference (kd-tree build + OpenMP queries of icp.cpp:18-32 on the same clouds, one iteration's worth)"
+    ws.close()
+
+    # configs[2]: the refine loop's shape for one of 8 sensors (MainWindowForm.cs:349-376): target = all other sensors' clouds
+    clouds = _scene_clouds_on_device(torch, synth, dev, 8)
+    src8 = clouds[0]
+    tgt8 = torch.cat(clouds[1:]).contiguous()
+    n1, n2 = tgt8.shape[0], src8.shape[0]
+    ws = native.IcpWorkspace(dev.index, n1, n2)
+    c2 = {"workload": "configs[2]: 8 sensors x 512x424 scene frames, target = 7 sensors' clouds, source = sensor 0, ICP(maxIter=10), device resident; voxel-grid NN vs brute-force NN",
+          "n1": n1, "n2": n2}
+    t_grid, _ = _time_icp(torch, native, ws, tgt8, src8, iters, native.NN_GRID, args.icp_reps, stream, dev)
+    t_brute, _ = _time_icp(torch, native, ws, tgt8, src8, iters, native.NN_BRUTE, 1, stream, dev)
+    c2["iter_ms_grid"] = t_grid / iters
+    c2["iter_ms_brute"] = t_brute / iters
+    t_prof, prof = _time_icp(torch, native, ws, tgt8, src8, iters, native.NN_GRID, 2, stream, dev, profile=True)
+    m_last = int(ws.trace(iters, stream)[-1][0])
+    nn_grid_ms, gi, gd = _time_nn(torch, native, ws, tgt8, src8, native.NN_GRID, stream, dev)
+    nn_brute_ms, bi, bd = _time_nn(torch, native, ws, tgt8, src8, native.NN_BRUTE, stream, dev, reps=1)
+    c2["nn_step_ms_grid_unseeded"] = nn_grid_ms
+    c2["nn_step_ms_brute"] = nn_brute_ms
+    c2["nn_modes_identical"] = bool(torch.equal(gi, bi) and torch.equal(gd.view(torch.int32), bd.view(torch.int32)))
+    c2["roofline"] = _icp_roofline(n1, n2, m_last, iters, prof, brute_ms=nn_brute_ms)
+    out["config2"] = c2
     ws.close()
     return out
 

@@ -209,6 +209,12 @@ int lsnIcpNearest(LsnIcp *icp, const float *d_verts1, int n1, const float *d_ver
 int lsnRefine(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
               float *world_R, float *world_t, float *Rs_out, float *Ts_out);
 
+/* Optional phase timing of lsnIcpRun (measurement aid): with profiling on, every lsnIcpRun records HIP events on its stream;
+ * lsnIcpProfile synchronises `stream` and returns the milliseconds of the last run in ms4 = {grid build + source sort,
+ * NN steps (incl. the fused apply of the previous iteration), match statistics + Kabsch sums + solve, final apply}. */
+int lsnIcpSetProfiling(LsnIcp *icp, int on);
+int lsnIcpProfile(LsnIcp *icp, float *ms4, void *stream);
+
 /* Per-iteration diagnostics of the last lsnIcpRun (copied to host; synchronises `stream`):
  * out[iter] = {n_matched, n_kept, mean, stddev, T[3], Rn[9]} as 16 floats (counts stored as floats). */
 int lsnIcpTrace(LsnIcp *icp, float *out16_per_iter, int max_iters, void *stream);

@@ -1274,6 +1274,12 @@ struct LsnIcp {
     lsn::DevBuf idx, dist, keys, counters, part1, part3, state, trace;
     lsn::DevBuf best_key, groups, list_a, list_b;   // the NN step's per-query keys, per-group boxes and work lists
     int seg_a = 0, seg_b = 0;   // capacity of one list segment
+    // optional phase timing of lsnIcpRun (lsnIcpSetProfiling): HIP events on the caller's stream around
+    // [0] grid build + source sort, [1] the NN steps (incl. the fused apply), [2] statistics + Kabsch sums + solve, [3] final apply
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    std::vector<int> event_phase;   // phase that ENDS at event k (event 0 opens the run)
+    size_t n_events = 0;
     int trace_iters = 0;
     bool seed_nn = true;   // $LSN_ICP_NO_SEED=1 turns the previous-neighbour seeding off (ablation)
     std::mutex mu;
@@ -1332,7 +1338,48 @@ extern "C" void lsnIcpDestroy(LsnIcp *w)
 {
     if (!w) return;
     (void)hipSetDevice(w->device);
+    for (hipEvent_t e : w->events) (void)hipEventDestroy(e);
     delete w;
+}
+
+extern "C" int lsnIcpSetProfiling(LsnIcp *w, int on)
+{
+    lsn::clear_error();
+    if (!w) return -1;
+    std::lock_guard<std::mutex> g(w->mu);
+    w->profiling = on != 0;
+    w->n_events = 0;
+    return 0;
+}
+
+// records the end of `phase` on the stream (profiling only)
+static void mark(LsnIcp *w, int phase, hipStream_t s)
+{
+    if (!w->profiling) return;
+    if (w->n_events == w->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        w->events.push_back(e);
+        w->event_phase.push_back(0);
+    }
+    w->event_phase[w->n_events] = phase;
+    (void)hipEventRecord(w->events[w->n_events++], s);
+}
+
+extern "C" int lsnIcpProfile(LsnIcp *w, float *ms4, void *stream)
+{
+    lsn::clear_error();
+    if (!w || !ms4) return -1;
+    std::lock_guard<std::mutex> g(w->mu);
+    LSN_HIP(hipSetDevice(w->device));
+    LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
+    for (int k = 0; k < 4; k++) ms4[k] = 0.0f;
+    for (size_t k = 1; k < w->n_events; k++) {
+        float ms = 0.0f;
+        LSN_HIP(hipEventElapsedTime(&ms, w->events[k - 1], w->events[k]));
+        ms4[w->event_phase[k] & 3] += ms;
+    }
+    return (int)w->n_events;
 }
 
 static inline int blocks_for(int n) { return (n + kThreads - 1) / kThreads; }
@@ -1485,6 +1532,8 @@ extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_vert
     w->trace_iters = maxIter < kTraceCap ? (maxIter > 0 ? maxIter : 0) : kTraceCap;
     if (maxIter <= 0) return 0;
 
+    w->n_events = 0;
+    mark(w, 0, s);
     // the target is fixed: one grid for all iterations; the source is sorted once (rigid motion keeps neighbours together)
     if (nn_mode != 0 && build_grid(w, w->tgt, d_verts1, n1, true, s)) return -1;
     if (build_grid(w, w->src, d_verts2, n2, false, s)) return -1;
@@ -1501,16 +1550,20 @@ extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_vert
         if (iter > 0 && !fused)
             hipLaunchKernelGGL(apply_kernel, dim3(blocks_for(n2 > n1 ? n2 : n1)), dim3(kThreads), 0, s, w->src.sorted.as<float4>(), d_verts2, n2,
                                (const IcpState *)st, keys, n1);
+        if (iter == 0) mark(w, 0, s);
         if (run_nn(w, d_verts1, n1, d_verts2, n2, w->idx.as<int>(), w->dist.as<float>(), keys, nn_mode, s, fused, st, iter & 1)) return -1;
+        mark(w, 1, s);
         hipLaunchKernelGGL(stats_kernel, dim3(nb), dim3(kThreads), 0, s, w->idx.as<int>(), w->dist.as<float>(), keys, n2,
                            w->part1.as<double>());
         hipLaunchKernelGGL(accum_kernel, dim3(nb), dim3(kThreads), 0, s, d_verts1, (const float *)d_verts2, w->idx.as<int>(),
                            w->dist.as<float>(), keys, n2, w->part1.as<double>(), nb, w->part3.as<double>(), st);
         hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(kThreads), 0, s, w->part3.as<double>(), nb, d_R, d_t, st,
                            iter < kTraceCap ? w->trace.as<float>() : (float *)nullptr, iter);
+        mark(w, 2, s);
     }
     hipLaunchKernelGGL(apply_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, w->src.sorted.as<float4>(), d_verts2, n2, (const IcpState *)st,
                        keys, 0);
+    mark(w, 3, s);
     LSN_HIP(hipGetLastError());
     return 0;
 }

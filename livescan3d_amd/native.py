@@ -25,7 +25,7 @@ EXPORTS = [
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
-    "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnRefine",
+    "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
     "lsnZstdAvailable", "lsnFrameParseHeader", "lsnFrameDecode", "lsnFrameEncode", "lsnRecordingNext", "lsnRecordingAppend",
@@ -139,6 +139,10 @@ def lib():
     L.lsnRefine.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.lsnIcpTrace.restype = C.c_int
     L.lsnIcpTrace.argtypes = [vp, vp, C.c_int, vp]
+    L.lsnIcpSetProfiling.restype = C.c_int
+    L.lsnIcpSetProfiling.argtypes = [vp, C.c_int]
+    L.lsnIcpProfile.restype = C.c_int
+    L.lsnIcpProfile.argtypes = [vp, vp, vp]
     ll = C.c_longlong
     L.lsnTransferCreate.restype = vp
     L.lsnTransferCreate.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -432,6 +436,16 @@ class IcpWorkspace:
     def nearest(self, d_verts1, n1, d_verts2, n2, d_idx, d_dist2, nn_mode=NN_GRID, stream=0):
         _check(lib().lsnIcpNearest(self._h, d_verts1, int(n1), d_verts2, int(n2), d_idx, d_dist2, int(nn_mode), stream),
                "lsnIcpNearest")
+
+    def set_profiling(self, on=True):
+        _check(lib().lsnIcpSetProfiling(self._h, 1 if on else 0), "lsnIcpSetProfiling")
+
+    def profile(self, stream=0):
+        """Milliseconds of the last profiled run(): {build, nn, match_reduce_solve, final_apply} (synchronises the stream)."""
+        ms = np.zeros(4, dtype=np.float32)
+        if lib().lsnIcpProfile(self._h, _ptr(ms), stream) < 0:
+            raise NativeUtilsError(f"lsnIcpProfile failed: {last_error()}")
+        return {"build": float(ms[0]), "nn": float(ms[1]), "match_reduce_solve": float(ms[2]), "final_apply": float(ms[3])}
 
     def trace(self, max_iters, stream=0):
         out = np.zeros((max(max_iters, 1), 16), dtype=np.float32)

@@ -2,6 +2,9 @@
 
 Bars: nearest-neighbour indices and f32 squared distances bit-exact (integer/index work); XYZ after ICP, R and t
 within 1e-4 m / 1e-4 of the oracle (the north-star tolerance; GPU sums are in double, the reference's in f32)."""
+import glob
+import os
+
 import numpy as np
 import pytest
 
@@ -55,6 +58,77 @@ def test_nn_matches_oracle_bitexact(gpu, orc, mode):
         got_i, got_d = _gpu_nn(t, q, mode)
         assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)), f"case {k}: squared distances differ"
         assert np.array_equal(got_i, want_i), f"case {k}: indices differ at {np.flatnonzero(got_i != want_i)[:5]}"
+
+
+GOLDEN_NN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "nn_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN_NN, ids=[os.path.basename(p) for p in GOLDEN_NN])
+@pytest.mark.parametrize("mode", [native.NN_BRUTE, native.NN_GRID])
+def test_nn_against_reference_nanoflann_fixture_directly(gpu, path, mode):
+    """The HIP NN straight against the indices / squared distances the reference's own nanoflann step produced
+    (tests/golden/nn_*.npz, generated from oracle/_ref): no oracle in between."""
+    g = np.load(path)
+    got_i, got_d = _gpu_nn(g["targets"], g["queries"], mode)
+    assert np.array_equal(got_d.view(np.uint32), g["dist2"].view(np.uint32))
+    assert np.array_equal(got_i, g["idx"].astype(np.int64))
+
+
+@pytest.mark.parametrize("name", ["configs1_2x512x424", "configs2_8x512x424", "lattice_2x192x160"])
+def test_nn_full_size_scene_rigs_against_reference_fixture(gpu, orc, name):
+    """configs[1] and configs[2] at their real sizes (2 / 8 sensors x 512x424; configs[2]: n1 = 738 k targets, the caller shape
+    of MainWindowForm.cs:349-376) plus a lattice-snapped rig with 3.9 % exact f32 ties: voxel-grid NN and brute-force NN agree
+    bit for bit with each other, with the oracle's kd-tree, and with what the reference's nanoflann step answered for every
+    query (tests/golden/nn_scene_full.json) -- indices may differ from the reference's only at exact f32 ties, where ours
+    is the lowest tied index (nanoflann's depends on its traversal, include/nanoflann.h:1200-1247)."""
+    from tests import scene_cases
+    case = scene_cases.load_cases()[name]
+    tgt, src = scene_cases.case_clouds(orc, name, case)
+    gi, gd = _gpu_nn(tgt, src, native.NN_GRID)
+    bi, bd = _gpu_nn(tgt, src, native.NN_BRUTE)
+    assert np.array_equal(gi, bi) and np.array_equal(gd.view(np.uint32), bd.view(np.uint32)), "grid and brute-force NN differ"
+    scene_cases.check_against_reference(case, gi, gd, "HIP NN")
+    oi, od = orc.nn(tgt, src, mode="kdtree", n_threads=8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    if orc.have_ref_nn() and case.get("lattice"):
+        # live against the compiled reference where oracle/_ref travelled along: differences only at exact ties
+        ri, rd = orc.ref_nn(tgt, src)
+        assert np.array_equal(rd.view(np.uint32), gd.view(np.uint32))
+        diff = np.flatnonzero(ri != gi)
+        assert set(diff.tolist()) <= set(case["tie_queries"])
+        d = tgt[ri[diff]] - src[diff]
+        assert np.array_equal(((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).view(np.uint32), gd[diff].view(np.uint32))
+
+
+def test_nn_list_overflow_falls_back_to_the_complete_walk(gpu, orc, monkeypatch):
+    """The NN step's work lists have a fixed capacity; when one overflows every query group runs the complete hierarchy walk
+    instead.  $LSN_ICP_TINY_LISTS (read when a workspace is created) forces that path: same bits."""
+    monkeypatch.setenv("LSN_ICP_TINY_LISTS", "1")
+    clouds = _scene_clouds(orc, 2, 256, 212)
+    want_i, want_d = orc.nn(clouds[0], clouds[1], mode="kdtree", n_threads=8)
+    got_i, got_d = _gpu_nn(clouds[0], clouds[1], native.NN_GRID)
+    assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)) and np.array_equal(got_i, want_i)
+    got_v, got_R, got_t = native.icp(clouds[0], clouds[1], max_iter=4)       # the export's workspace was created earlier: normal path
+    monkeypatch.delenv("LSN_ICP_TINY_LISTS")
+    ref_v, ref_R, ref_t = orc.icp(clouds[0], clouds[1], max_iter=4, n_threads=8)
+    assert np.abs(got_v - ref_v).max() <= TOL
+
+
+def test_nn_non_finite_points_do_not_derail_the_search(gpu, orc):
+    """NaN / inf coordinates in either cloud: the finite queries still get their exact neighbour among the comparable targets,
+    the others an index in range (they take no part in the culling), and nothing hangs."""
+    rng = np.random.default_rng(11)
+    t = rng.uniform(-1, 1, size=(5000, 3)).astype(np.float32)
+    q = rng.uniform(-1.2, 1.2, size=(3000, 3)).astype(np.float32)
+    t[7] = [np.nan, 0, 0]; t[4000] = [np.inf, 1, 1]; t[123, 2] = -np.inf
+    bad_q = [0, 63, 64, 1999, 2999]
+    q[0] = [np.nan, np.nan, np.nan]; q[63] = [np.inf, 0, 0]; q[64, 1] = np.nan; q[1999] = [-np.inf, np.inf, 0]; q[2999, 2] = np.nan
+    want_i, want_d = orc.nn(t, q, mode="brute", n_threads=8)
+    ok = np.ones(len(q), bool); ok[bad_q] = False
+    for mode in (native.NN_GRID, native.NN_BRUTE):
+        got_i, got_d = _gpu_nn(t, q, mode)
+        assert np.array_equal(got_i[ok], want_i[ok]) and np.array_equal(got_d[ok].view(np.uint32), want_d[ok].view(np.uint32))
+        assert ((got_i >= 0) & (got_i < len(t))).all()
 
 
 def test_nn_full_size(gpu, orc):
