@@ -412,28 +412,8 @@ def main():
     # ---- drop-in export on host buffers (PCIe-inclusive; never `value`) -----------------------------------------
     if rank == 0 and not args.no_host_path:
         with leg(result, "host_path"):
-            import ctypes as C
-            rig = synth.make_rig("noise", S, w, h, seed=1, bounds=bounds)
-            L = native.lib()
-            vp = C.c_void_p
-            argv = [S, rig.depth_maps.ctypes.data_as(vp), rig.depth_colors.ctypes.data_as(vp), rig.widths.ctypes.data_as(vp),
-                    rig.heights.ctypes.data_as(vp), rig.intr.ctypes.data_as(vp), rig.wt.ctypes.data_as(vp)]
-            mesh = native.Mesh()
-
-            def call():   # exactly what KinectServer.GenerateMesh does around the P/Invoke, minus the managed copies
-                L.generateMeshFromDepthMaps(*argv, C.byref(mesh), False, *[float(x) for x in bounds], False)
-                n = mesh.nVertices
-                L.deleteMesh(C.byref(mesh))
-                return n
-            for _ in range(3):
-                nv = call()
-            n, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < 2.0:
-                call()
-                n += 1
-            result["host_path_frames_per_s"] = n / (time.perf_counter() - t0)
-            result["host_path_note"] = (f"generateMeshFromDepthMaps + deleteMesh on host arrays ({S} x {w}x{h}, {nv} vertices back, "
-                                        "triangulation included): H2D from pageable memory + kernels + D2H into pinned memory")
+            result["host_path"] = bench_host_path(native, synth, S, w, h, bounds)
+            result["host_path_frames_per_s"] = result["host_path"]["merge_noise"]["calls_per_s"]
 
     # ---- ICP, configs[1] ------------------------------------------------------------------------------------------
     if rank == 0 and not args.no_icp:
@@ -456,6 +436,80 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+PCIE_GBS = 63.0   # MI355X_MICROARCH.md: PCIe 5.0 x16, per direction
+
+
+def bench_host_path(native, synth, S, w, h, bounds):
+    """The reference's own exports on HOST arrays, exactly as KinectServer calls them (KinectServer.cs:354-389, 527-554): upload,
+    kernels, download, deleteMesh.  PCIe-bound: every variant is set against bytes_up / 63 GB/s + bytes_down / 63 GB/s (the
+    download cannot start before the upload has been consumed)."""
+    import ctypes as C
+    L = native.lib()
+    vp = C.c_void_p
+    out = {"pcie_peak_GBs_per_direction": PCIE_GBS,
+           "note": "calls timed back to back from one host thread for ~2 s each; frac = (bytes_up + bytes_down) / 63 GB/s / measured time per call"}
+
+    def run(name, rig, call, bytes_up, describe):
+        for _ in range(4):           # the caller's arrays get registered on their second sighting
+            nv, nt = call()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 2.0:
+            call()
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        bytes_down = 16 * nv + 12 * nt
+        bound = (bytes_up + bytes_down) / (PCIE_GBS * 1e9)
+        out[name] = {"what": describe, "calls_per_s": 1.0 / dt, "ms_per_call": 1e3 * dt, "bytes_up": int(bytes_up), "bytes_down": int(bytes_down),
+                     "vertices": int(nv), "triangles": int(nt), "pcie_bound_ms": 1e3 * bound, "frac_of_pcie_bound": bound / dt}
+
+    try:   # what a plain 15 MB copy reaches on this box (pinned host memory, either direction): the practical ceiling under the 63 GB/s of the spec
+        import torch
+        hbuf = torch.empty(15 << 20, dtype=torch.uint8).pin_memory()
+        dbuf = torch.empty(15 << 20, dtype=torch.uint8, device="cuda")
+        rates = {}
+        for name, dst, src in (("h2d", dbuf, hbuf), ("d2h", hbuf, dbuf)):
+            best = None
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dst.copy_(src, non_blocking=True)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            rates[name] = (15 << 20) / best / 1e9
+        out["plain_copy_15MB_GBs"] = rates
+        del hbuf, dbuf
+    except Exception as e:  # noqa: BLE001
+        out["plain_copy_15MB_GBs"] = f"not measured: {e}"
+
+    for kind in ("noise", "scene"):
+        rig = synth.make_rig(kind, S, w, h, seed=1, bounds=bounds) if kind == "noise" else synth.make_rig(kind, S, w, h, seed=4, perturb=True)
+        argv = [S, rig.depth_maps.ctypes.data_as(vp), rig.depth_colors.ctypes.data_as(vp), rig.widths.ctypes.data_as(vp),
+                rig.heights.ctypes.data_as(vp), rig.intr.ctypes.data_as(vp), rig.wt.ctypes.data_as(vp)]
+        bnd = [float(x) for x in rig.bounds]
+        mesh = native.Mesh()
+
+        def merge():   # exactly what KinectServer.GenerateMesh does around the P/Invoke, minus the managed copies
+            L.generateMeshFromDepthMaps(*argv, C.byref(mesh), False, *bnd, False)
+            n = (mesh.nVertices, mesh.nTriangles)
+            L.deleteMesh(C.byref(mesh))
+            return n
+
+        def singles():  # GetLatestFrameVerticesOnly: one generateVerticesFromDepthMap per sensor (the refine path's input)
+            nv = 0
+            for i in range(S):
+                L.generateVerticesFromDepthMap(*argv[1:], C.byref(mesh), *bnd, i)
+                nv += mesh.nVertices
+                L.deleteMesh(C.byref(mesh))
+            return nv, 0
+
+        up = rig.depth_maps.nbytes + rig.depth_colors.nbytes
+        run(f"merge_{kind}", rig, merge, up, f"generateMeshFromDepthMaps + deleteMesh, {S} x {w}x{h} {kind} frames, vertices + triangles back")
+        if kind == "scene":
+            run("vertices_only_scene", rig, singles, up, f"{S} x (generateVerticesFromDepthMap + deleteMesh), the {S} sensors of one scene tick, vertices only")
+    return out
 
 
 def bench_wire(args, torch, native, synth, dev, stream, S, w, h, bounds, with_cpu):

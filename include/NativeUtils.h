@@ -182,7 +182,12 @@ int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const
                          const void *d_rgb_c, long long slab, const int *d_tile_prefix, const int *d_shard_offsets, void *d_merged,
                          int *d_merged_offsets, void *stream);
 
-/* 1 when the last look-back launch (mode 1) gave up on a bounded spin (outputs invalid), else 0; synchronises. */
+/* The plan's sticky device-side error flag since the last check (synchronises `stream`, clears the flag):
+ *   0 = fine; 1 = a look-back launch (mode 1) gave up on a bounded spin; 2 = a write pass found a tile whose survivors
+ *   differ from what the count pass had counted (the inputs changed between the two passes: a buffer counted ahead by
+ *   lsnFusionRunStreamed was refilled, or the inputs of a call in flight were overwritten) -- the affected tiles wrote
+ *   nothing, the outputs of that call are invalid.  lsnFusionLookbackFailed is the same call under its round-1 name. */
+int lsnFusionCheck(LsnFusion *plan, void *stream);
 int lsnFusionLookbackFailed(LsnFusion *plan, void *stream);
 
 /* An ICP workspace for clouds of at most max_n1 target / max_n2 source points. */

@@ -3,8 +3,21 @@
 // LiveScanServer hands over host arrays (pinned managed arrays / AllocHGlobal blocks, KinectServer.cs:354-374,
 // MainWindowForm.cs:364-370) and reads host memory back (Marshal.Copy, KinectServer.cs:383), so these entry points
 // add the H2D / D2H hops around the same kernels bench.py drives directly on HBM-resident data.
-// One process-wide context (device from $LSN_DEVICE, default 0) serialises the calls: the reference's exports are
-// re-entrant and LiveScanServer calls them from two BackgroundWorkers (MainWindowForm.cs:238,304).
+// One process-wide context (device from $LSN_DEVICE, default 0): the merge / single-sensor / radial calls share one set of
+// device buffers and serialise on one lock; ICP has its own buffers, stream and lock, so a multi-millisecond refine call does
+// not hold up the merge calls (LiveScanServer runs them on two BackgroundWorkers, MainWindowForm.cs:238,304).
+//
+// A merge call is PCIe-bound (8 x 512x424: 8.7 MB up, 15-35 MB down, against ~30 us of kernels), so the hops are laid out
+// to keep the link busy and nothing else in the way:
+//   * the caller's arrays are uploaded as they are.  Registering them once with hipHostRegister (C# keeps the same arrays
+//     from tick to tick, KinectServer.cs:74-80) buys nothing on this platform -- measured on the MI355X box
+//     (tools/pcie_probe.cpp): pageable 3.5 / 5.2 / 15 MB copies run at 49-55 GB/s, registered and hipHostMalloc'ed ones at
+//     47-55 GB/s -- and a stale registration (the caller frees an array, the allocator hands the pages to another one) makes
+//     later copies fail with "invalid argument".  The cache is therefore OFF unless $LSN_HOST_REGISTER=1;
+//   * depth goes up first: the count pass needs nothing else and runs while the colours are still on the link;
+//   * the offset table comes back through a small pinned block right behind the scan, so the host knows the vertex count
+//     (and has the output block ready) before the write pass has finished;
+//   * the vertices leave on a second stream as soon as they are written, while the triangulation kernels are still running.
 #include "lsn_common.hpp"
 
 #include <cstdlib>
@@ -55,10 +68,15 @@ extern "C" int lsnDeviceCount(void)
 namespace {
 
 struct Ctx {
-    std::mutex mu;
+    std::mutex mu;            // merge / single-sensor / radial / last-mesh calls and the pinned-block pool
+    std::mutex icp_mu;        // ICP: own buffers, own stream
+    std::mutex init_mu;
     bool ready = false;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, up = nullptr, down = nullptr, icp_stream = nullptr;
+    hipEvent_t ev_depth = nullptr, ev_col = nullptr, ev_counted = nullptr, ev_written = nullptr, ev_tri_counted = nullptr, ev_down = nullptr;
+    int *h_off = nullptr, *h_toff = nullptr;   // pinned: the offset tables of the call in progress
+    int h_off_cap = 0;
     std::map<std::vector<int>, LsnFusion *> plans;  // key: n_maps, widths..., heights...
     lsn::DevBuf d_depth, d_colors, d_out, d_off, d_tri, d_tri_off, d_v1, d_v2, d_Rt;
     LsnIcp *icp = nullptr;
@@ -72,17 +90,30 @@ struct Ctx {
     LsnTransfer *xfer = nullptr;
     int xfer_v = 0, xfer_t = 0;
     lsn::DevBuf d_wire;
+    // caller ranges registered with the runtime (opt-in, see the file comment)
+    struct Reg {
+        const char *base;
+        size_t bytes;
+        unsigned long long last_use;
+    };
+    std::vector<Reg> regs;
+    std::vector<std::pair<const void *, size_t>> seen;   // ranges of the last calls that are not registered (yet)
+    std::vector<std::pair<const void *, size_t>> refused; // ranges the runtime would not register: not tried again
+    unsigned long long use_clock = 0;
+    bool reg_enabled = false;   // $LSN_HOST_REGISTER=1
+    bool warned_flags = false;
 };
 
 Ctx &ctx()
 {
-    static Ctx c;
-    return c;
+    static Ctx *c = new Ctx();   // never destroyed: its HIP objects must not be released from a static destructor after the runtime is gone
+    return *c;
 }
 
-// requires c.mu held
+// Takes c.init_mu itself; callers may hold c.mu or c.icp_mu.
 int ensure_ready(Ctx &c)
 {
+    std::lock_guard<std::mutex> g(c.init_mu);
     if (c.ready) return hipSetDevice(c.device) == hipSuccess ? 0 : -1;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -97,9 +128,84 @@ int ensure_ready(Ctx &c)
         return -1;
     }
     LSN_HIP(hipSetDevice(c.device));
-    LSN_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (hipStream_t *s : {&c.stream, &c.up, &c.down, &c.icp_stream}) LSN_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&c.ev_depth, &c.ev_col, &c.ev_counted, &c.ev_written, &c.ev_tri_counted, &c.ev_down})
+        LSN_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (const char *e = getenv("LSN_HOST_REGISTER")) c.reg_enabled = atoi(e) != 0;
     c.ready = true;
     return 0;
+}
+
+constexpr size_t kPage = 4096;
+constexpr size_t kRegMaxRanges = 16;
+constexpr size_t kRegMaxBytes = (size_t)1 << 30;
+
+void reg_drop(Ctx &c, size_t i)
+{
+    (void)hipHostUnregister(const_cast<char *>(c.regs[i].base));  // fails when the caller has freed the memory meanwhile: nothing to undo then
+    (void)hipGetLastError();
+    c.regs.erase(c.regs.begin() + (long)i);
+}
+
+// True when [p, p + bytes) lies inside a range registered with the runtime (copies from it then run as DMA out of the
+// caller's pages).  A range is registered on its second sighting -- one-off buffers are not worth the ~millisecond the
+// registration costs.  may_register = false only looks the range up.  c.mu held.
+bool host_range_pinned(Ctx &c, const void *p, size_t bytes, bool may_register)
+{
+    if (!c.reg_enabled || !p || bytes < 65536) return false;
+    const char *b = static_cast<const char *>(p);
+    c.use_clock++;
+    for (auto &r : c.regs)
+        if (b >= r.base && b + bytes <= r.base + r.bytes) {
+            r.last_use = c.use_clock;
+            return true;
+        }
+    if (!may_register) return false;
+    for (auto &r : c.refused)
+        if (r.first == p && r.second == bytes) return false;
+    bool second = false;
+    for (auto &r : c.seen)
+        if (r.first == p && r.second == bytes) second = true;
+    if (!second) {
+        if (c.seen.size() >= 16) c.seen.erase(c.seen.begin());
+        c.seen.emplace_back(p, bytes);
+        return false;
+    }
+    // registered ranges may not overlap (page granularity): whatever the new range touches goes first
+    const uintptr_t lo = (uintptr_t)b & ~(kPage - 1), hi = ((uintptr_t)b + bytes + kPage - 1) & ~(kPage - 1);
+    for (size_t i = c.regs.size(); i-- > 0;) {
+        const uintptr_t rl = (uintptr_t)c.regs[i].base & ~(kPage - 1), rh = ((uintptr_t)c.regs[i].base + c.regs[i].bytes + kPage - 1) & ~(kPage - 1);
+        if (rl < hi && lo < rh) reg_drop(c, i);
+    }
+    size_t total = bytes;
+    for (auto &r : c.regs) total += r.bytes;
+    while (!c.regs.empty() && (c.regs.size() >= kRegMaxRanges || total > kRegMaxBytes)) {
+        size_t lru = 0;
+        for (size_t i = 1; i < c.regs.size(); i++)
+            if (c.regs[i].last_use < c.regs[lru].last_use) lru = i;
+        total -= c.regs[lru].bytes;
+        reg_drop(c, lru);
+    }
+    for (size_t i = c.seen.size(); i-- > 0;)
+        if (c.seen[i].first == p && c.seen[i].second == bytes) c.seen.erase(c.seen.begin() + (long)i);
+    if (hipHostRegister(const_cast<char *>(b), bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c.refused.size() >= 16) c.refused.erase(c.refused.begin());
+        c.refused.emplace_back(p, bytes);
+        return false;
+    }
+    c.regs.push_back({b, bytes, c.use_clock});
+    return true;
+}
+
+// waits for everything the context has in flight on the merge streams (error paths: no copy may touch the caller's arrays
+// or our buffers once the call has returned)
+void drain(Ctx &c)
+{
+    (void)hipStreamSynchronize(c.up);
+    (void)hipStreamSynchronize(c.stream);
+    (void)hipStreamSynchronize(c.down);
+    (void)hipGetLastError();
 }
 
 void *pinned_get(Ctx &c, size_t bytes)
@@ -163,11 +269,12 @@ LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, in
     return plan;
 }
 
-// Fuses n_maps sensors of one tick from host buffers into out_mesh.  first/count select the sensors
-// (generateVerticesFromDepthMap uses one).  c.mu held.
-int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
-              const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count,
-              bool with_triangles)
+// Fuses `count` sensors of one tick from host buffers into out_mesh.  first/count select the sensors
+// (generateVerticesFromDepthMap uses one); total_d / total_c are the bytes of the caller's whole arrays as far as the call
+// knows them (what gets registered).  c.mu held.
+int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char *depth_colors, size_t total_d, size_t total_c,
+                    const int *widths, const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first,
+                    int count, bool with_triangles)
 {
     LsnFusion *plan = get_plan(c, widths, heights, first, count);
     if (!plan) return -1;
@@ -181,50 +288,95 @@ int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const u
         dbytes += (size_t)widths[first + i] * heights[first + i] * 2;
         cbytes += (size_t)widths[first + i] * heights[first + i] * 3;
     }
-    (void)n_maps_total;
+    c.last_nv = -1;                                   // d_out / d_tri are about to be overwritten (or reallocated)
     const long long cap = lsnFusionTickCapacity(plan);
     if (c.d_depth.reserve(dbytes + 16) || c.d_colors.reserve(cbytes + 16) || c.d_out.reserve((size_t)cap * 16) ||
         c.d_off.reserve(sizeof(int) * (count + 1)))
         return -1;
-    LSN_HIP(hipMemcpyAsync(c.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, c.stream));
-    LSN_HIP(hipMemcpyAsync(c.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, c.stream));
+    if (c.h_off_cap < count + 1) {
+        if (c.h_off) (void)hipHostFree(c.h_off);
+        if (c.h_toff) (void)hipHostFree(c.h_toff);
+        c.h_off = c.h_toff = nullptr;
+        c.h_off_cap = 0;
+        LSN_HIP(hipHostMalloc((void **)&c.h_off, sizeof(int) * (size_t)(count + 1 + 64), hipHostMallocDefault));
+        LSN_HIP(hipHostMalloc((void **)&c.h_toff, sizeof(int) * (size_t)(count + 1 + 64), hipHostMallocDefault));
+        c.h_off_cap = count + 1 + 64;
+    }
+    // the merge call sees the whole arrays the caller keeps from tick to tick: those get registered; a single-sensor call
+    // (which only knows a prefix of them) profits when its slice lies inside
+    (void)host_range_pinned(c, depth_maps, total_d, with_triangles);
+    (void)host_range_pinned(c, depth_colors, total_c, with_triangles);
+
+    // depth first (the count pass needs nothing else), colours behind it on the same upload stream
+    LSN_HIP(hipMemcpyAsync(c.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, c.up));
+    LSN_HIP(hipEventRecord(c.ev_depth, c.up));
+    LSN_HIP(hipMemcpyAsync(c.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, c.up));
+    LSN_HIP(hipEventRecord(c.ev_col, c.up));
     if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, c.stream)) return -1;
-    std::vector<int> off(count + 1), toff(count + 1, 0);
+    LSN_HIP(hipStreamWaitEvent(c.stream, c.ev_depth, 0));
+    lsn::RunHooks hooks;
+    hooks.colours_ready = c.ev_col;
+    hooks.h_offsets = c.h_off;
+    hooks.counted = c.ev_counted;
+    hooks.written = c.ev_written;
+    c.h_toff[count] = 0;
     if (with_triangles) {
         const long long tcap = lsnFusionTickTriangleCapacity(plan);
         if (c.d_tri.reserve((size_t)tcap * 12) || c.d_tri_off.reserve(sizeof(int) * (count + 1))) return -1;
-        if (lsnFusionRunMesh(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.d_tri.p, c.d_tri_off.as<int>(), c.stream))
+        hooks.h_tri_offsets = c.h_toff;
+        hooks.tri_counted = c.ev_tri_counted;
+        if (lsn::run_mesh(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.d_tri.p, c.d_tri_off.as<int>(), c.stream, &hooks))
             return -1;
-        LSN_HIP(hipMemcpyAsync(toff.data(), c.d_tri_off.p, sizeof(int) * (count + 1), hipMemcpyDeviceToHost, c.stream));
     } else {
-        if (lsnFusionRun(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.stream)) return -1;
+        if (lsn::run_hooked(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.stream, &hooks)) return -1;
     }
-    c.last_nv = -1;                                   // d_out / d_tri are being overwritten
-    LSN_HIP(hipMemcpyAsync(off.data(), c.d_off.p, sizeof(int) * (count + 1), hipMemcpyDeviceToHost, c.stream));
-    LSN_HIP(hipStreamSynchronize(c.stream));
-    const int nv = off[count];
+    // the vertex count arrives while the write pass (and the triangulation) are still running
+    LSN_HIP(hipEventSynchronize(c.ev_counted));
+    const int nv = c.h_off[count];
     if (nv < 0 || nv > cap) {
         lsn::set_error("NativeUtils: device returned an impossible vertex count %d", nv);
         return -1;
     }
-    const int nt = toff[count];
-    if (nt < 0 || nt > 2 * cap) {
-        lsn::set_error("NativeUtils: device returned an impossible triangle count %d", nt);
-        return -1;
-    }
     void *host = pinned_get(c, (size_t)nv * sizeof(VertexC4ubV3f));
     if (!host) return -1;
-    void *host_tri = nullptr;
-    if (nt > 0) {
-        host_tri = pinned_get(c, (size_t)nt * 12);
-        if (!host_tri) {
+    if (nv > 0) {
+        // the vertices leave on their own stream as soon as the write pass is done
+        if (hipStreamWaitEvent(c.down, c.ev_written, 0) != hipSuccess ||
+            hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, c.down) != hipSuccess) {
+            lsn::set_error("NativeUtils: vertex download failed: %s", hipGetErrorString(hipGetLastError()));
+            drain(c);
             pinned_put(c, host);
             return -1;
         }
     }
-    if (nv > 0) LSN_HIP(hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, c.stream));
-    if (nt > 0) LSN_HIP(hipMemcpyAsync(host_tri, c.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, c.stream));
-    if (nv > 0 || nt > 0) LSN_HIP(hipStreamSynchronize(c.stream));
+    int nt = 0;
+    void *host_tri = nullptr;
+    if (with_triangles) {
+        bool bad = hipEventSynchronize(c.ev_tri_counted) != hipSuccess;
+        nt = bad ? 0 : c.h_toff[count];
+        if (!bad && (nt < 0 || nt > 2 * cap)) {
+            lsn::set_error("NativeUtils: device returned an impossible triangle count %d", nt);
+            bad = true;
+        }
+        if (!bad && nt > 0) {
+            host_tri = pinned_get(c, (size_t)nt * 12);
+            bad = !host_tri || hipMemcpyAsync(host_tri, c.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, c.stream) != hipSuccess;
+        }
+        if (bad) {
+            if (lsn::last_error().empty()) lsn::set_error("NativeUtils: triangle download failed: %s", hipGetErrorString(hipGetLastError()));
+            drain(c);
+            pinned_put(c, host);
+            if (host_tri) pinned_put(c, host_tri);
+            return -1;
+        }
+    }
+    if (hipStreamSynchronize(c.stream) != hipSuccess || hipStreamSynchronize(c.down) != hipSuccess) {
+        lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
+        drain(c);
+        pinned_put(c, host);
+        if (host_tri) pinned_put(c, host_tri);
+        return -1;
+    }
     c.last_nv = nv;
     c.last_nt = nt;
     out->nVertices = nv;
@@ -238,6 +390,21 @@ int fuse_host(Ctx &c, int n_maps_total, const unsigned char *depth_maps, const u
         if (tri) c.live_tri[tri] = 1;
     }
     return 0;
+}
+
+int fuse_host(Ctx &c, int n_maps_known, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
+              const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count,
+              bool with_triangles)
+{
+    size_t total_d = 0, total_c = 0;
+    for (int i = 0; i < n_maps_known; i++) {
+        total_d += (size_t)widths[i] * heights[i] * 2;
+        total_c += (size_t)widths[i] * heights[i] * 3;
+    }
+    const int rc = fuse_host_inner(c, depth_maps, depth_colors, total_d, total_c, widths, heights, intr, wt, out, bounds6, first, count,
+                                   with_triangles);
+    if (rc) drain(c);   // nothing of a failed call stays in flight
+    return rc;
 }
 
 }  // namespace
@@ -280,9 +447,19 @@ extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps,
         empty_mesh(c, out_mesh);
         return;
     }
-    if (bcolor_transfer || bgenerate_triangles)
+    if (bcolor_transfer || bgenerate_triangles) {
         lsn::set_error("generateMeshFromDepthMaps: colour transfer / overlay merge are outside this library's scope; "
                        "returned the cropped vertices of all sensors (flags false,false behaviour)");
+        if (!c.warned_flags) {
+            // nobody on the C# side reads lsnGetLastError, and bGenerateTriangles = true is LiveScanServer's default
+            // (KinectSettings.cs:50): say it once per process where an operator can see it
+            c.warned_flags = true;
+            fprintf(stderr, "[NativeUtils] generateMeshFromDepthMaps was called with bcolor_transfer=%d bgenerate_triangles=%d: this library "
+                            "implements the (false, false) behaviour only (no cross-view overlay merge, no colour transfer); the mesh "
+                            "returned is the unmerged one. Set bGenerateTriangles / bColorTransfer to false in LiveScanServer's settings.\n",
+                    (int)bcolor_transfer, (int)bgenerate_triangles);
+        }
+    }
 }
 
 extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
@@ -357,7 +534,7 @@ extern "C" float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2,
         return error;
     }
     Ctx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
+    std::lock_guard<std::mutex> g(c.icp_mu);   // not c.mu: merge calls go on while a refine call runs
     if (ensure_ready(c)) return error;
     if (!c.icp || nVerts1 > c.icp_n1 || nVerts2 > c.icp_n2) {
         if (c.icp) lsnIcpDestroy(c.icp);
@@ -374,22 +551,22 @@ extern "C" float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2,
     const char *env = getenv("LSN_NN");
     const int nn_mode = (env && strcmp(env, "brute") == 0) ? 0 : 1;
     auto fail = [&]() { return error; };
-    if (hipMemcpyAsync(c.d_v1.p, verts1, sizeof(float) * 3 * (size_t)nVerts1, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
-        hipMemcpyAsync(c.d_v2.p, verts2, sizeof(float) * 3 * (size_t)nVerts2, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
-        hipMemcpyAsync(c.d_Rt.p, R, sizeof(float) * 9, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
-        hipMemcpyAsync(c.d_Rt.as<float>() + 9, t, sizeof(float) * 3, hipMemcpyHostToDevice, c.stream) != hipSuccess) {
+    if (hipMemcpyAsync(c.d_v1.p, verts1, sizeof(float) * 3 * (size_t)nVerts1, hipMemcpyHostToDevice, c.icp_stream) != hipSuccess ||
+        hipMemcpyAsync(c.d_v2.p, verts2, sizeof(float) * 3 * (size_t)nVerts2, hipMemcpyHostToDevice, c.icp_stream) != hipSuccess ||
+        hipMemcpyAsync(c.d_Rt.p, R, sizeof(float) * 9, hipMemcpyHostToDevice, c.icp_stream) != hipSuccess ||
+        hipMemcpyAsync(c.d_Rt.as<float>() + 9, t, sizeof(float) * 3, hipMemcpyHostToDevice, c.icp_stream) != hipSuccess) {
         lsn::set_error("ICP: upload failed: %s", hipGetErrorString(hipGetLastError()));
         return fail();
     }
     if (lsnIcpRun(c.icp, c.d_v1.as<float>(), nVerts1, c.d_v2.as<float>(), nVerts2, c.d_Rt.as<float>(), c.d_Rt.as<float>() + 9, maxIter,
-                  nn_mode, c.stream))
+                  nn_mode, c.icp_stream))
         return fail();
     // results go to a scratch first so that the caller's buffers stay untouched when anything fails
     std::vector<float> v2((size_t)nVerts2 * 3);
     float Rt[12];
-    if (hipMemcpyAsync(v2.data(), c.d_v2.p, sizeof(float) * 3 * (size_t)nVerts2, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
-        hipMemcpyAsync(Rt, c.d_Rt.p, sizeof(float) * 12, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
-        hipStreamSynchronize(c.stream) != hipSuccess) {
+    if (hipMemcpyAsync(v2.data(), c.d_v2.p, sizeof(float) * 3 * (size_t)nVerts2, hipMemcpyDeviceToHost, c.icp_stream) != hipSuccess ||
+        hipMemcpyAsync(Rt, c.d_Rt.p, sizeof(float) * 12, hipMemcpyDeviceToHost, c.icp_stream) != hipSuccess ||
+        hipStreamSynchronize(c.icp_stream) != hipSuccess) {
         lsn::set_error("ICP: download failed: %s", hipGetErrorString(hipGetLastError()));
         return fail();
     }

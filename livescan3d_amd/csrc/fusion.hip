@@ -286,8 +286,12 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     int below, wave_total;
     rank_from_masks(keep, below, wave_total);
     if (lane == 0) s_wave_tot[wave] = wave_total;
-    int base = 0;
-    if (MODE == 1 || MODE == 3) base = a.tile_counts[blockIdx.x];  // scan_kernel left the exclusive prefix inside the tick here
+    int base = 0, counted = 0;
+    if (MODE == 1 || MODE == 3) {
+        base = a.tile_counts[blockIdx.x];  // scan_kernel left the exclusive prefix inside the tick here
+        // what the count pass saw in this tile = the next tile's prefix (the tick's total after the last tile) minus this one
+        counted = (tile + 1 < a.tiles_per_tick ? a.tile_counts[blockIdx.x + 1] : a.offsets[tick * (a.n_frames + 1) + a.n_frames]) - base;
+    }
     __syncthreads();
     int wave_off = 0, tile_tot = 0;
 #pragma unroll
@@ -301,6 +305,13 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
         return;
     }
     if (MODE == 3 && threadIdx.x == 0) a.tile_counts_next[blockIdx.x] = s_wave_next[0] + s_wave_next[1] + s_wave_next[2] + s_wave_next[3];
+    if (tile_tot != counted) {
+        // The inputs are not the ones the count pass read (a caller refilled a buffer that had been counted ahead by
+        // lsnFusionRunStreamed, or overwrote the inputs of a call in flight): the prefixes no longer fit, tiles would
+        // overlap and the last one would run past its tick's slab.  Write nothing, raise the flag (lsnFusionCheck).
+        if (threadIdx.x == 0) atomicExch(a.error_flag, 2);
+        return;
+    }
     if (a.pixmap) {
         // depth_to_vertices_map (depthprocessing.cpp:166), already rebased to the tick's merged cloud like formMesh
         // rebases triangle indices (:1614-1626): what the triangulation pass reads
@@ -864,6 +875,23 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         lsn::set_error("lsnFusionRun: null argument");
         return -1;
     }
+    std::lock_guard<std::mutex> g(p->mu);
+    return lsn::run_locked(p, d_depth, d_colors, d_vertices, d_offsets, lsn::as_stream(stream), false, nullptr);
+}
+
+int lsn::run_hooked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, hipStream_t s, const RunHooks *hooks)
+{
+    if (!p || !d_depth || !d_colors || !d_vertices || !d_offsets) {
+        lsn::set_error("lsnFusionRun: null argument");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    return lsn::run_locked(p, d_depth, d_colors, d_vertices, d_offsets, s, false, hooks);
+}
+
+int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, hipStream_t s, bool with_pixmap,
+                    const RunHooks *hooks)
+{
     if (!p->params_set) {
         lsn::set_error("lsnFusionRun: lsnFusionSetParams has not been called");
         return -1;
@@ -872,9 +900,12 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         lsn::set_error("lsnFusionRun: d_vertices must be 16-byte aligned");
         return -1;
     }
-    std::lock_guard<std::mutex> g(p->mu);
     LSN_HIP(hipSetDevice(p->device));
-    hipStream_t s = lsn::as_stream(stream);
+    struct PixmapScope {   // a.pixmap follows p->want_pixmap (fill_args); never left set behind an early return
+        LsnFusion *p;
+        PixmapScope(LsnFusion *q, bool on) : p(q) { p->want_pixmap = on; }
+        ~PixmapScope() { p->want_pixmap = false; }
+    } scope(p, with_pixmap);
 
     if (ensure_thresholds(p, s)) return -1;
     FuseArgs a;
@@ -884,11 +915,12 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
     const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 &&
                      (p->tick_depth_elems % 8) == 0;
     const int grid = p->tiles_per_tick * p->n_ticks;
+    const size_t off_bytes = sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (p->profile && next_event_pair(p, e0, e1)) return -1;
 
-    if (p->pipelined && p->mode == 0 && !p->want_pixmap) {
+    if (p->pipelined && p->mode == 0 && !with_pixmap && !hooks) {
         // Count + scan of THIS call go to the side stream: they only read the inputs (promised resident by
         // lsnFusionSetPipelined) and write this call's half of the double-buffered scratch, so they overlap with the
         // previous call's write kernel, which is still running on the caller's stream (a VALU-bound kernel beside an
@@ -911,13 +943,17 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
         if (e1) LSN_HIP(hipEventRecord(e1, s));
         LSN_HIP(hipEventRecord(p->ev_written[b], s));
         p->calls++;
-    } else if (p->mode == 0 || p->want_pixmap) {
+    } else if (p->mode == 0 || with_pixmap || hooks) {
         launch_count(p, vec, s, a);
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
                            a.offsets);
+        if (hooks && hooks->h_offsets) LSN_HIP(hipMemcpyAsync(hooks->h_offsets, d_offsets, off_bytes, hipMemcpyDeviceToHost, s));
+        if (hooks && hooks->counted) LSN_HIP(hipEventRecord(hooks->counted, s));
+        if (hooks && hooks->colours_ready) LSN_HIP(hipStreamWaitEvent(s, hooks->colours_ready, 0));
         if (e0) LSN_HIP(hipEventRecord(e0, s));
         launch<1>(vec, grid, s, a);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
+        if (hooks && hooks->written) LSN_HIP(hipEventRecord(hooks->written, s));
     } else {
         LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)grid, s));
         LSN_HIP(hipMemsetAsync(p->misc.as<char>() + 128, 0, 128 * (size_t)p->n_ticks, s));  // tickets; the error flag is sticky
@@ -1018,6 +1054,8 @@ extern "C" int lsnFusionThresholds(LsnFusion *p, unsigned int *out_host, float *
 }
 
 // Reads back the look-back error flag (diagnostics for tests); synchronises the stream.
+extern "C" int lsnFusionCheck(LsnFusion *p, void *stream) { return lsnFusionLookbackFailed(p, stream); }
+
 extern "C" int lsnFusionLookbackFailed(LsnFusion *p, void *stream)
 {
     if (!p) return -1;

@@ -391,7 +391,7 @@ struct LsnFusion {
     bool params_set = false;
     int mode = 0;
     int tiles_per_run_override = 0;  // $LSN_TILES_PER_RUN (tuning / tests)
-    bool want_pixmap = false;        // set by lsnFusionRunMesh around its vertex pass
+    bool want_pixmap = false;        // the run in progress also fills the pixel -> vertex map (set and cleared under mu by run_locked)
     float bounds[6] = {0, 0, 0, 0, 0, 0};
     lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: error flag (word 0) + tickets
     lsn::DevBuf xtab, ytab;

@@ -63,4 +63,22 @@ struct DevBuf {
 
 inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
+// Optional extras of one run, for hosts that overlap copies with the passes (abi.hip): all members may be null.
+struct RunHooks {
+    hipEvent_t colours_ready = nullptr;   // the write pass waits for it (the count pass only reads depth)
+    int *h_offsets = nullptr;             // pinned host copy of the offset table, issued right after the scan ...
+    hipEvent_t counted = nullptr;         // ... and this event recorded behind it (the vertex count is known before the write pass ends)
+    hipEvent_t written = nullptr;         // recorded after the write pass (the vertices may leave while the triangulation runs)
+    int *h_tri_offsets = nullptr;         // lsnFusionRunMesh: pinned host copy of the triangle offset table ...
+    hipEvent_t tri_counted = nullptr;     // ... and the event behind it
+};
+// lsnFusionRun with the plan's mutex already held; with_pixmap also fills the pixel -> vertex map the triangulation reads.
+int run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, hipStream_t s, bool with_pixmap,
+               const RunHooks *hooks);
+// lsnFusionRun with hooks (takes the mutex).
+int run_hooked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, hipStream_t s, const RunHooks *hooks);
+// lsnFusionRunMesh with hooks (takes the mutex once for the vertex and the triangle passes).
+int run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, void *d_triangles, int *d_tri_offsets,
+             hipStream_t s, const RunHooks *hooks);
+
 }  // namespace lsn

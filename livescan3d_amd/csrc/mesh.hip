@@ -315,25 +315,26 @@ extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d
                                 void *d_triangles, int *d_tri_offsets, void *stream)
 {
     lsn::clear_error();
-    if (!p || !d_triangles || !d_tri_offsets) {
+    return lsn::run_mesh(p, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, lsn::as_stream(stream), nullptr);
+}
+
+int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, void *d_triangles,
+                  int *d_tri_offsets, hipStream_t s, const RunHooks *hooks)
+{
+    if (!p || !d_depth || !d_colors || !d_vertices || !d_offsets || !d_triangles || !d_tri_offsets) {
         lsn::set_error("lsnFusionRunMesh: null argument");
         return -1;
     }
-    {
-        std::lock_guard<std::mutex> g(p->mu);
-        LSN_HIP(hipSetDevice(p->device));
-        if (p->pixmap.reserve(sizeof(int) * (size_t)p->cap * p->n_ticks) ||
-            p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks) ||
-            p->tri_codes.reserve(sizeof(unsigned int) * (size_t)p->tiles_per_tick * p->n_ticks * kThreads))
-            return -1;
-        p->want_pixmap = true;
-    }
-    // vertices + depth_to_vertices_map (count / scan / write launches)
-    const int rc = lsnFusionRun(p, d_depth, d_colors, d_vertices, d_offsets, stream);
+    // one critical section for the vertex pass (which fills the pixel -> vertex map) and the triangle passes (which read it):
+    // two threads sharing a plan cannot interleave between them
     std::lock_guard<std::mutex> g(p->mu);
-    p->want_pixmap = false;
-    if (rc) return rc;
-    hipStream_t s = lsn::as_stream(stream);
+    LSN_HIP(hipSetDevice(p->device));
+    if (p->pixmap.reserve(sizeof(int) * (size_t)p->cap * p->n_ticks) ||
+        p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks) ||
+        p->tri_codes.reserve(sizeof(unsigned int) * (size_t)p->tiles_per_tick * p->n_ticks * kThreads))
+        return -1;
+    // vertices + depth_to_vertices_map (count / scan / write launches)
+    if (lsn::run_locked(p, d_depth, d_colors, d_vertices, d_offsets, s, true, hooks)) return -1;
     TriArgs t;
     t.frames = p->frames.as<FrameDesc>();
     t.tiles = p->tile_frame.as<TileDesc>();
@@ -351,9 +352,11 @@ extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d
     else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
     hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, t.tile_counts, t.tiles_per_tick, t.frames, p->n_maps,
                        d_tri_offsets);
+    if (hooks && hooks->h_tri_offsets)
+        LSN_HIP(hipMemcpyAsync(hooks->h_tri_offsets, d_tri_offsets, sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1), hipMemcpyDeviceToHost, s));
+    if (hooks && hooks->tri_counted) LSN_HIP(hipEventRecord(hooks->tri_counted, s));
     if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), 0, s, t);
     else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), 0, s, t);
     LSN_HIP(hipGetLastError());
     return 0;
 }
-

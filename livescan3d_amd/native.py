@@ -23,7 +23,7 @@ EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
-    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionThresholds", "lsnMergeShards",
+    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
@@ -125,6 +125,8 @@ def lib():
     L.lsnFusionReconstruct.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_longlong, vp, vp, vp, vp, vp]
     L.lsnFusionLookbackFailed.restype = C.c_int
     L.lsnFusionLookbackFailed.argtypes = [vp, vp]
+    L.lsnFusionCheck.restype = C.c_int
+    L.lsnFusionCheck.argtypes = [vp, vp]
     L.lsnMergeShards.restype = C.c_int
     L.lsnMergeShards.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp]
     L.lsnIcpCreate.restype = vp
@@ -383,6 +385,10 @@ class FusionPlan:
 
     def lookback_failed(self, stream=0):
         return int(lib().lsnFusionLookbackFailed(self._h, stream))
+
+    def check(self, stream=0):
+        """The plan's sticky device-side error flag (0 fine, 1 look-back gave up, 2 inputs changed between count and write); clears it."""
+        return int(lib().lsnFusionCheck(self._h, stream))
 
     def run_streamed(self, d_depth, d_colors, d_vertices, d_offsets, d_next_depth=None, stream=0):
         """This batch is written while the next batch's depth (already resident) is counted in the same kernel."""

@@ -317,6 +317,43 @@ def test_streamed_calls_match(gpu, orc):
             assert v[k, :n].cpu().numpy().tobytes() == want.tobytes()
 
 
+def test_streamed_refilled_next_buffer_is_a_clean_error(gpu, orc):
+    """A caller that refills the buffer it announced as "next" after lsnFusionRunStreamed has counted it (the natural double-buffer
+    mistake) must get an error flag, not overlapping tiles and writes past the tick's slab: the write pass compares every tile's
+    survivors with what the count pass had seen and writes nothing where they differ."""
+    import torch
+    T, N, w, h = 2, 2, 512, 424
+    mk = lambda seed, kind: [synth.make_rig(kind, N, w, h, seed=seed, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+    up = lambda rigs: (torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda(),
+                       torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda())
+    ra, rb, rc = mk(70, "scene"), mk(71, "scene"), mk(72, "noise")        # rc: many more survivors than rb
+    da, ca = up(ra)
+    db, cb = up(rb)
+    dc, cc = up(rc)
+    plan = native.FusionPlan(0, T, [w] * N, [h] * N)
+    plan.set_params(ra[0].intr, ra[0].wt, synth.CROP_BOUNDS)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    guard = 4096
+    v = torch.zeros((T * plan.capacity + guard, 16), dtype=torch.uint8, device="cuda")
+    o = torch.zeros((T, N + 1), dtype=torch.int32, device="cuda")
+    plan.run_streamed(da.data_ptr(), ca.data_ptr(), v.data_ptr(), o.data_ptr(), db.data_ptr(), st)   # writes A, counts B
+    assert plan.check(st) == 0
+    db.copy_(dc); cb.copy_(cc)                                                # the caller refills "next" with other frames
+    v.zero_()
+    plan.run_streamed(db.data_ptr(), cb.data_ptr(), v.data_ptr(), o.data_ptr(), None, st)             # stale counts meet new pixels
+    assert plan.check(st) == 2
+    assert plan.check(st) == 0                                                # the flag is cleared by the check
+    assert int(v[T * plan.capacity:].count_nonzero()) == 0                    # nothing ran past the last tick's slab
+    # the same call again counts on the spot (nothing valid was counted ahead any more) and is right
+    plan.run_streamed(db.data_ptr(), cb.data_ptr(), v.data_ptr(), o.data_ptr(), None, st)
+    assert plan.check(st) == 0
+    oh = o.cpu().numpy()
+    for k in range(T):
+        want, counts = orc.generate_mesh_vertices(rc[k].depth_maps, rc[k].depth_colors, rc[k].widths, rc[k].heights, ra[0].intr, ra[0].wt, synth.CROP_BOUNDS)
+        n = int(oh[k, -1])
+        assert n == len(want) and v[k * plan.capacity:k * plan.capacity + n].cpu().numpy().tobytes() == want.tobytes()
+
+
 def test_triangles_match_reference_fixture(gpu):
     """tests/golden/tri_reference.npz::scene{0,1}_96x80 are the triangle lists the REFERENCE's own meshGenerator.cpp
     produced (tests/golden/make_tri_golden.py) for the two sensors of this rig; the export must return the same
