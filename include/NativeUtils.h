@@ -182,6 +182,43 @@ int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const
                          const void *d_rgb_c, long long slab, const int *d_tile_prefix, const int *d_shard_offsets, void *d_merged,
                          int *d_merged_offsets, void *stream);
 
+/* The same two ends with the streams laid out the way lsnShardStep sends them: all ticks of a shard back to back, ONE
+ * contiguous run per shard (d_depth_c / d_rgb_c as above but tick k's survivors start at d_tick_base[k], which the call
+ * fills, [n_ticks] ints), so that a collective can send the run as it is.  The gathered streams are [n_shards][run_len]
+ * (run_len >= the largest shard total); d_tick_base_scratch: [n_shards][n_ticks] ints. */
+int lsnFusionPackSurvivorsRun(LsnFusion *plan, const void *d_depth_maps, const void *d_depth_colors, void *d_mask, void *d_depth_c,
+                              void *d_rgb_c, int *d_tile_prefix, int *d_offsets, int *d_tick_base, void *stream);
+int lsnFusionReconstructRun(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
+                            const void *d_rgb_c, long long run_len, const int *d_tile_prefix, const int *d_shard_offsets, void *d_merged,
+                            int *d_merged_offsets, int *d_tick_base_scratch, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Part 2b -- the multi-GPU step (one process per GPU): this rank's block of sensors in, the merged cloud of ALL sensors out.
+ * Replaces the per-sensor thread fan-out and the concatenation of formMesh (src/NativeUtils/depthprocessing.cpp:708-733,
+ * :1594-1608) across GPUs: rank r owns sensors [r * n_maps / world, (r + 1) * n_maps / world) of every tick (rank order =
+ * sensor order); one exchange step over RCCL / xGMI (all-gathers of the survivors' inputs: 5 bytes per vertex + 1 bit per
+ * pixel instead of 16 bytes per vertex) and every rank rebuilds the whole merged cloud, bit-identical to a single-GPU
+ * lsnFusionRun over all sensors.  Needs identically sized sensors whose width is a multiple of 8.
+ *
+ * Rendezvous: rank 0 calls lsnShardUniqueId and hands the 128 bytes to the other ranks by whatever channel the host has
+ * (a file, a socket, torch.distributed); every rank then calls lsnShardCreate with the same id (collective: blocks until
+ * all ranks have arrived).  widths / heights / intr / wt describe ALL n_maps sensors on every rank.
+ * lsnShardStep is collective and asynchronous on `stream` except for one event wait on a small pinned read-back (the element
+ * count of a collective is a host-side argument; $LSN_SHARD_PADDED=1 trades it for full-capacity transfers).
+ * *d_merged: n_ticks x lsnShardMergedCapacity() VertexC4ubV3f, *d_merged_offsets: n_ticks x (n_maps + 1) ints, both owned
+ * by the handle and valid until its next step. */
+typedef struct LsnShard LsnShard;
+int lsnShardUniqueId(unsigned char *id128);
+LsnShard *lsnShardCreate(int device, int rank, int world, const unsigned char *id128, int n_ticks, int n_maps, const int *widths,
+                         const int *heights);
+void lsnShardDestroy(LsnShard *shard);
+long long lsnShardMergedCapacity(const LsnShard *shard);
+int lsnShardSetParams(LsnShard *shard, const float *intr_all, const float *wt_all, const float *bounds6, void *stream);
+int lsnShardStep(LsnShard *shard, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets,
+                 void *stream);
+/* bytes this rank contributed to the collectives of the last step (what every other rank received from it) */
+long long lsnShardLastBytesSent(const LsnShard *shard);
+
 /* The plan's sticky device-side error flag since the last check (synchronises `stream`, clears the flag):
  *   0 = fine; 1 = a look-back launch (mode 1) gave up on a bounded spin; 2 = a write pass found a tile whose survivors
  *   differ from what the count pass had counted (the inputs changed between the two passes: a buffer counted ahead by

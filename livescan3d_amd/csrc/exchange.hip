@@ -48,6 +48,8 @@ struct PackArgs {
     unsigned char *mask;      // [n_ticks][cap / 8]      bit (p & 7) of byte p >> 3 = pixel p of the tick survived
     unsigned short *depth_c;  // [n_ticks][cap]          survivors' depth, vertex order
     unsigned char *rgb_c;     // [n_ticks][cap][3]       survivors' colour, vertex order
+    const int *tick_base;     // null: tick k's survivors start at k * cap (layout above).  Else [n_ticks]: they start at tick_base[k] --
+                              // all ticks back to back, ONE contiguous run per shard: what the RCCL all-gather sends as it is
 };
 
 __global__ __launch_bounds__(kThreads) void pack_kernel(const FuseArgs a, const PackArgs pk)
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(const FuseArgs a, const 
 #pragma unroll
     for (int k = 0; k < kPxPerLane; k++) m8 |= (keep[k] ? 1u : 0u) << k;
     pk.mask[(tick * a.tick_depth_stride + t.pix_base + p0) >> 3] = (unsigned char)m8;
-    long long r = tick * a.tick_vert_stride + base + wave_off + below;
+    long long r = (pk.tick_base ? (long long)pk.tick_base[tick] : tick * a.tick_vert_stride) + base + wave_off + below;
 #pragma unroll
     for (int k = 0; k < kPxPerLane; k++) {
         if (keep[k]) {
@@ -106,7 +108,36 @@ struct ReconArgs {
     int *merged_off;                 // [n_ticks][n_maps + 1]
     long long slab, cap_loc;
     int tiles_loc, n_shards, maps_per_shard;
+    const int *tick_base;            // null: streams laid out [n_shards][n_ticks][slab].  Else [n_shards][n_ticks]: shard q's streams are ONE
+                                     // run of `slab` entries, tick k's survivors start at tick_base[q][k] inside it
 };
+
+// Exclusive prefix over the ticks of every shard's per-tick survivor count (the last entry of its offset rows): where each
+// tick starts in a shard's back-to-back streams.  One workgroup per shard.
+__global__ __launch_bounds__(kThreads) void tick_base_kernel(const int *shard_off /* [n_shards][n_ticks][mps + 1] */, int n_ticks, int mps,
+                                                             int *tick_base /* [n_shards][n_ticks] */)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int *off = shard_off + (long long)blockIdx.x * n_ticks * (mps + 1);
+    int *out = tick_base + (long long)blockIdx.x * n_ticks;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_ticks; c0 += kThreads) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < n_ticks ? off[(long long)i * (mps + 1) + mps] : 0;
+        const int incl = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int pre = s_carry;
+        for (int w = 0; w < wave; w++) pre += s_wave[w];
+        if (i < n_ticks) out[i] = pre + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kThreads - 1) s_carry = pre + incl;
+        __syncthreads();
+    }
+}
 
 // `a` describes the WHOLE rig (all sensors, their parameters, a.out = the merged cloud).
 __global__ __launch_bounds__(kThreads) void recon_kernel(const FuseArgs a, const ReconArgs r)
@@ -143,8 +174,9 @@ __global__ __launch_bounds__(kThreads) void recon_kernel(const FuseArgs a, const
         tile_tot += v;
     }
     // the lane's survivors are consecutive entries of the shard's compact streams
-    const unsigned short *dc = r.depth_c + st * r.slab;
-    const unsigned char *cc = r.rgb_c + 3 * st * r.slab;
+    const long long run = r.tick_base ? (long long)shard * r.slab + r.tick_base[st] : st * r.slab;
+    const unsigned short *dc = r.depth_c + run;
+    const unsigned char *cc = r.rgb_c + 3 * run;
     long long ci = tile_base + wave_off + below;
     unsigned int d[kPxPerLane], c[kPxPerLane];
 #pragma unroll
@@ -184,12 +216,19 @@ __global__ __launch_bounds__(kThreads) void recon_kernel(const FuseArgs a, const
 
 extern "C" int lsnFusionTilesPerTick(const LsnFusion *p) { return p ? p->tiles_per_tick : 0; }
 
-// Survivor exchange, sender side: count + scan as in lsnFusionRun, then the compact streams instead of vertices.
 extern "C" int lsnFusionPackSurvivors(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
                                       int *d_tile_prefix, int *d_offsets, void *stream)
 {
     lsn::clear_error();
-    if (!p || !d_depth || !d_colors || !d_mask || !d_depth_c || !d_rgb_c || !d_tile_prefix || !d_offsets) {
+    return lsn::pack_survivors(p, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, nullptr, stream);
+}
+
+// Survivor exchange, sender side: count + scan as in lsnFusionRun, then the compact streams instead of vertices.
+// d_tick_base (nullable, [n_ticks]): filled with every tick's start in the back-to-back layout, which the streams then use.
+int lsn::pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
+                        int *d_tile_prefix, int *d_offsets, int *d_tick_base, void *stream)
+{
+    if (!p || !d_depth || !d_colors || !d_mask || !d_depth_c || !d_rgb_c || !d_offsets || (!d_tile_prefix && !d_tick_base)) {
         lsn::set_error("lsnFusionPackSurvivors: null argument");
         return -1;
     }
@@ -214,9 +253,13 @@ extern "C" int lsnFusionPackSurvivors(LsnFusion *p, const void *d_depth, const v
     pk.mask = static_cast<unsigned char *>(d_mask);
     pk.depth_c = static_cast<unsigned short *>(d_depth_c);
     pk.rgb_c = static_cast<unsigned char *>(d_rgb_c);
+    pk.tick_base = d_tick_base;
+    if (d_tick_base) hipLaunchKernelGGL(tick_base_kernel, dim3(1), dim3(kThreads), 0, s, (const int *)d_offsets, p->n_ticks, p->n_maps, d_tick_base);
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)(p->tiles_per_tick * p->n_ticks)), dim3(kThreads), 0, s, a, pk);
     LSN_HIP(hipGetLastError());
-    LSN_HIP(hipMemcpyAsync(d_tile_prefix, p->tile_counts.p, sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks, hipMemcpyDeviceToDevice, s));
+    // (LsnShard sends the prefixes straight from the plan's scratch and passes no copy target)
+    if (d_tile_prefix)
+        LSN_HIP(hipMemcpyAsync(d_tile_prefix, p->tile_counts.p, sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
@@ -227,6 +270,40 @@ extern "C" int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_s
                                     void *d_merged, int *d_merged_offsets, void *stream)
 {
     lsn::clear_error();
+    return lsn::reconstruct(all, n_shards, maps_per_shard, d_masks, d_depth_c, d_rgb_c, slab, d_tile_prefix, d_shard_offsets, d_merged,
+                            d_merged_offsets, nullptr, stream);
+}
+
+extern "C" int lsnFusionPackSurvivorsRun(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
+                                         int *d_tile_prefix, int *d_offsets, int *d_tick_base, void *stream)
+{
+    lsn::clear_error();
+    if (!d_tick_base || !d_tile_prefix) {
+        lsn::set_error("lsnFusionPackSurvivorsRun: null argument");
+        return -1;
+    }
+    return lsn::pack_survivors(p, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, d_tick_base, stream);
+}
+
+extern "C" int lsnFusionReconstructRun(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
+                                       const void *d_rgb_c, long long run_len, const int *d_tile_prefix, const int *d_shard_offsets,
+                                       void *d_merged, int *d_merged_offsets, int *d_tick_base_scratch, void *stream)
+{
+    lsn::clear_error();
+    if (!d_tick_base_scratch) {
+        lsn::set_error("lsnFusionReconstructRun: null argument");
+        return -1;
+    }
+    return lsn::reconstruct(all, n_shards, maps_per_shard, d_masks, d_depth_c, d_rgb_c, run_len, d_tile_prefix, d_shard_offsets, d_merged,
+                            d_merged_offsets, d_tick_base_scratch, stream);
+}
+
+// d_tick_base (nullable, scratch [n_shards][n_ticks]): the gathered streams are one back-to-back run of `slab` entries per shard
+// (lsn::pack_survivors with a tick base); the per-shard tick starts are recomputed here from the gathered offset tables.
+int lsn::reconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c, const void *d_rgb_c,
+                     long long slab, const int *d_tile_prefix, const int *d_shard_offsets, void *d_merged, int *d_merged_offsets,
+                     int *d_tick_base, void *stream)
+{
     if (!all || !d_masks || !d_depth_c || !d_rgb_c || !d_tile_prefix || !d_shard_offsets || !d_merged || !d_merged_offsets) {
         lsn::set_error("lsnFusionReconstruct: null argument");
         return -1;
@@ -265,6 +342,10 @@ extern "C" int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_s
     r.tiles_loc = all->tiles_per_tick / n_shards;
     r.n_shards = n_shards;
     r.maps_per_shard = maps_per_shard;
+    r.tick_base = d_tick_base;
+    if (d_tick_base)
+        hipLaunchKernelGGL(tick_base_kernel, dim3((unsigned)n_shards), dim3(kThreads), 0, lsn::as_stream(stream), d_shard_offsets, all->n_ticks,
+                           maps_per_shard, d_tick_base);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (all->profile) {
         if (next_event_pair(all, e0, e1)) return -1;
@@ -308,3 +389,256 @@ extern "C" int lsnMergeShards(int device, int n_shards, int n_ticks, int maps_pe
     return 0;
 }
 
+
+
+// -------------------------------------------------------------------------------------------------------------------------
+// LsnShard: the whole multi-GPU step behind the C-ABI -- one process per GPU, this rank's block of sensors in, the merged
+// cloud of ALL sensors out, RCCL over xGMI in between (include/NativeUtils.h part 2b).
+//
+// The reference fans createVertices out over one std::thread per sensor and concatenates the per-sensor clouds in sensor
+// order (src/NativeUtils/depthprocessing.cpp:708-733, formMesh :1594-1608).  Across GPUs: rank r owns the contiguous block
+// [r * S / G, (r + 1) * S / G) of every tick's sensors (rank order = formMesh's sensor order) and ONE exchange step forms the
+// merged cloud on every rank.  What crosses the links is what the vertices are made of (5 bytes per survivor + 1 bit per
+// pixel instead of 16 bytes per vertex); every rank rebuilds all vertices with the arithmetic of the write kernel.
+//
+// Per step, on the caller's stream:  pack (count, scan, tick bases, compact streams -- all ticks of the rank back to back,
+// so the send buffer is one contiguous run and nothing is staged)  ->  ncclAllGather of the offset tables  ->  the host reads
+// them through pinned memory (one event wait: the element count of a collective is a host argument, and all ranks must pass
+// the same one, so the largest rank total has to be known on the host)  ->  ONE ncclGroup with the all-gathers of the tile
+// prefixes, the survivor masks and the two streams  ->  reconstruct.  $LSN_SHARD_PADDED=1 skips the host read and always
+// gathers full-capacity streams (no synchronisation at all, about twice the bytes on the links).
+// RCCL is loaded with dlopen on first use: a single-GPU host of this library never maps it.
+// -------------------------------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl *rccl()
+{
+    static std::mutex mu;
+    static Rccl *r = nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (r) return r;
+    void *lib = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+    }
+    if (!lib) {
+        lsn::set_error("lsnShard: cannot load librccl.so.1 (%s)", dlerror());
+        return nullptr;
+    }
+    Rccl *t = new Rccl();
+    t->lib = lib;
+    t->GetUniqueId = (decltype(t->GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    t->CommInitRank = (decltype(t->CommInitRank))dlsym(lib, "ncclCommInitRank");
+    t->CommDestroy = (decltype(t->CommDestroy))dlsym(lib, "ncclCommDestroy");
+    t->AllGather = (decltype(t->AllGather))dlsym(lib, "ncclAllGather");
+    t->GroupStart = (decltype(t->GroupStart))dlsym(lib, "ncclGroupStart");
+    t->GroupEnd = (decltype(t->GroupEnd))dlsym(lib, "ncclGroupEnd");
+    t->GetErrorString = (decltype(t->GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!t->GetUniqueId || !t->CommInitRank || !t->CommDestroy || !t->AllGather || !t->GroupStart || !t->GroupEnd || !t->GetErrorString) {
+        lsn::set_error("lsnShard: librccl.so.1 lacks an expected entry point");
+        delete t;
+        return nullptr;
+    }
+    r = t;
+    return r;
+}
+
+#define LSN_NCCL(expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t _r = (expr);                                                                          \
+        if (_r != ncclSuccess) {                                                                           \
+            lsn::set_error("%s failed: %s (%s:%d)", #expr, rccl()->GetErrorString(_r), __FILE__, __LINE__); \
+            return -1;                                                                                     \
+        }                                                                                                  \
+    } while (0)
+
+}  // namespace
+
+struct LsnShard {
+    int device = 0, rank = 0, world = 1;
+    int n_ticks = 0, n_maps = 0, mpr = 0;     // all sensors / sensors per rank
+    LsnFusion *local = nullptr, *whole = nullptr;
+    ncclComm_t comm = nullptr;
+    bool padded = false;                       // $LSN_SHARD_PADDED=1
+    long long cap_loc = 0;                     // vertices per tick of one rank's block
+    int tiles_loc = 0;
+    lsn::DevBuf mask, depth_c, rgb_c, offsets, tick_base;        // this rank's packed survivors
+    lsn::DevBuf g_off, g_tp, g_mask, g_dc, g_cc, g_tick_base;    // gathered, [world][...]
+    lsn::DevBuf merged, merged_off;
+    int *h_goff = nullptr;                     // pinned copy of the gathered offset tables
+    hipEvent_t ev_off = nullptr;
+    long long last_slab = 0, last_bytes_per_rank = 0;
+    std::mutex mu;
+};
+
+extern "C" int lsnShardUniqueId(unsigned char *id128)
+{
+    lsn::clear_error();
+    if (!id128) return -1;
+    Rccl *r = rccl();
+    if (!r) return -1;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    LSN_NCCL(r->GetUniqueId(&id));
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+extern "C" void lsnShardDestroy(LsnShard *sh)
+{
+    if (!sh) return;
+    (void)hipSetDevice(sh->device);
+    if (sh->comm && rccl()) (void)rccl()->CommDestroy(sh->comm);
+    if (sh->local) lsnFusionDestroy(sh->local);
+    if (sh->whole) lsnFusionDestroy(sh->whole);
+    if (sh->h_goff) (void)hipHostFree(sh->h_goff);
+    if (sh->ev_off) (void)hipEventDestroy(sh->ev_off);
+    delete sh;
+}
+
+extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsigned char *id128, int n_ticks, int n_maps, const int *widths,
+                                    const int *heights)
+{
+    lsn::clear_error();
+    if (world <= 0 || rank < 0 || rank >= world || !id128 || n_ticks <= 0 || n_maps <= 0 || !widths || !heights || n_maps % world != 0) {
+        lsn::set_error("lsnShardCreate: bad arguments (rank %d of %d, %d sensors must split evenly)", rank, world, n_maps);
+        return nullptr;
+    }
+    for (int i = 0; i < n_maps; i++)
+        if (widths[i] != widths[0] || heights[i] != heights[0] || widths[i] % 8 != 0) {
+            lsn::set_error("lsnShardCreate: the survivor exchange needs identically sized sensors whose width is a multiple of 8");
+            return nullptr;
+        }
+    Rccl *r = rccl();
+    if (!r) return nullptr;
+    LSN_HIP_NULL(hipSetDevice(device));
+    LsnShard *sh = new (std::nothrow) LsnShard();
+    if (!sh) return nullptr;
+    sh->device = device;
+    sh->rank = rank;
+    sh->world = world;
+    sh->n_ticks = n_ticks;
+    sh->n_maps = n_maps;
+    sh->mpr = n_maps / world;
+    if (const char *e = getenv("LSN_SHARD_PADDED")) sh->padded = atoi(e) != 0;
+    sh->local = lsnFusionCreate(device, n_ticks, sh->mpr, widths + rank * sh->mpr, heights + rank * sh->mpr);
+    sh->whole = lsnFusionCreate(device, n_ticks, n_maps, widths, heights);
+    bool bad = !sh->local || !sh->whole;
+    if (!bad) {
+        sh->cap_loc = sh->local->cap;
+        sh->tiles_loc = sh->local->tiles_per_tick;
+        const size_t T = (size_t)n_ticks, W = (size_t)world, cap = (size_t)sh->cap_loc;
+        bad |= sh->mask.reserve(T * cap / 8) != 0;
+        bad |= sh->depth_c.reserve(T * cap * 2 + 64) != 0;
+        bad |= sh->rgb_c.reserve(T * cap * 3 + 64) != 0;
+        bad |= sh->offsets.reserve(sizeof(int) * T * (sh->mpr + 1)) != 0;
+        bad |= sh->tick_base.reserve(sizeof(int) * T) != 0;
+        bad |= sh->g_off.reserve(sizeof(int) * W * T * (sh->mpr + 1)) != 0;
+        bad |= sh->g_tp.reserve(sizeof(int) * W * T * sh->tiles_loc) != 0;
+        bad |= sh->g_mask.reserve(W * T * cap / 8) != 0;
+        bad |= sh->g_dc.reserve(W * (T * cap * 2 + 64)) != 0;
+        bad |= sh->g_cc.reserve(W * (T * cap * 3 + 64)) != 0;
+        bad |= sh->g_tick_base.reserve(sizeof(int) * W * T) != 0;
+        bad |= sh->merged.reserve((size_t)sh->whole->cap * 16 * T) != 0;
+        bad |= sh->merged_off.reserve(sizeof(int) * T * (n_maps + 1)) != 0;
+        bad |= hipHostMalloc((void **)&sh->h_goff, sizeof(int) * W * T * (sh->mpr + 1), hipHostMallocDefault) != hipSuccess;
+        bad |= hipEventCreateWithFlags(&sh->ev_off, hipEventDisableTiming) != hipSuccess;
+    }
+    if (!bad) {
+        ncclUniqueId id;
+        memcpy(&id, id128, 128);
+        const ncclResult_t rc = r->CommInitRank(&sh->comm, world, id, rank);
+        if (rc != ncclSuccess) {
+            lsn::set_error("lsnShardCreate: ncclCommInitRank failed: %s", r->GetErrorString(rc));
+            sh->comm = nullptr;
+            bad = true;
+        }
+    }
+    if (bad) {
+        if (lsn::last_error().empty()) lsn::set_error("lsnShardCreate: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        lsnShardDestroy(sh);
+        return nullptr;
+    }
+    return sh;
+}
+
+extern "C" long long lsnShardMergedCapacity(const LsnShard *sh) { return sh && sh->whole ? sh->whole->cap : 0; }
+extern "C" long long lsnShardLastBytesSent(const LsnShard *sh) { return sh ? sh->last_bytes_per_rank : 0; }
+
+extern "C" int lsnShardSetParams(LsnShard *sh, const float *intr_all, const float *wt_all, const float *bounds6, void *stream)
+{
+    lsn::clear_error();
+    if (!sh || !intr_all || !wt_all || !bounds6) {
+        lsn::set_error("lsnShardSetParams: null argument");
+        return -1;
+    }
+    if (lsnFusionSetParams(sh->whole, intr_all, wt_all, bounds6, stream)) return -1;
+    return lsnFusionSetParams(sh->local, intr_all + 7 * (size_t)sh->rank * sh->mpr, wt_all + 12 * (size_t)sh->rank * sh->mpr, bounds6, stream);
+}
+
+extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets,
+                            void *stream)
+{
+    lsn::clear_error();
+    if (!sh || !d_depth_local || !d_colors_local) {
+        lsn::set_error("lsnShardStep: null argument");
+        return -1;
+    }
+    Rccl *r = rccl();
+    if (!r) return -1;
+    std::lock_guard<std::mutex> g(sh->mu);
+    LSN_HIP(hipSetDevice(sh->device));
+    hipStream_t s = lsn::as_stream(stream);
+    const size_t T = (size_t)sh->n_ticks, W = (size_t)sh->world, cap = (size_t)sh->cap_loc;
+    const size_t off_ints = T * (sh->mpr + 1);
+    if (lsn::pack_survivors(sh->local, d_depth_local, d_colors_local, sh->mask.p, sh->depth_c.p, sh->rgb_c.p, nullptr, sh->offsets.as<int>(),
+                            sh->tick_base.as<int>(), stream))
+        return -1;
+    LSN_NCCL(r->AllGather(sh->offsets.p, sh->g_off.p, off_ints, ncclInt32, sh->comm, s));
+    long long slab = (long long)(T * cap);   // entries of one rank's streams that travel
+    if (!sh->padded) {
+        LSN_HIP(hipMemcpyAsync(sh->h_goff, sh->g_off.p, sizeof(int) * W * off_ints, hipMemcpyDeviceToHost, s));
+        LSN_HIP(hipEventRecord(sh->ev_off, s));
+        LSN_HIP(hipEventSynchronize(sh->ev_off));
+        long long most = 1;
+        for (size_t q = 0; q < W; q++) {
+            long long tot = 0;
+            for (size_t k = 0; k < T; k++) tot += sh->h_goff[(q * T + k) * (sh->mpr + 1) + sh->mpr];
+            most = tot > most ? tot : most;
+        }
+        if (most > slab) {
+            lsn::set_error("lsnShardStep: a rank reports %lld survivors, more than its %lld pixels", most, slab);
+            return -1;
+        }
+        slab = (most + 7) & ~7ll;   // the colour stream of every rank then starts 8-byte aligned
+    }
+    sh->last_slab = slab;
+    sh->last_bytes_per_rank = (long long)(sizeof(int) * off_ints + sizeof(int) * T * sh->tiles_loc + T * cap / 8 + (size_t)slab * 5);
+    LSN_NCCL(r->GroupStart());
+    LSN_NCCL(r->AllGather(sh->local->tile_counts.p, sh->g_tp.p, T * sh->tiles_loc, ncclInt32, sh->comm, s));
+    LSN_NCCL(r->AllGather(sh->mask.p, sh->g_mask.p, T * cap / 8, ncclUint8, sh->comm, s));
+    LSN_NCCL(r->AllGather(sh->depth_c.p, sh->g_dc.p, (size_t)slab * 2, ncclUint8, sh->comm, s));
+    LSN_NCCL(r->AllGather(sh->rgb_c.p, sh->g_cc.p, (size_t)slab * 3, ncclUint8, sh->comm, s));
+    LSN_NCCL(r->GroupEnd());
+    if (lsn::reconstruct(sh->whole, sh->world, sh->mpr, sh->g_mask.p, sh->g_dc.p, sh->g_cc.p, slab, sh->g_tp.as<int>(), sh->g_off.as<int>(),
+                         sh->merged.p, sh->merged_off.as<int>(), sh->g_tick_base.as<int>(), stream))
+        return -1;
+    if (d_merged) *d_merged = sh->merged.p;
+    if (d_merged_offsets) *d_merged_offsets = sh->merged_off.as<int>();
+    return 0;
+}

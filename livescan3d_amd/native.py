@@ -25,6 +25,7 @@ EXPORTS = [
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
+    "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardCreate", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
@@ -139,6 +140,24 @@ def lib():
     L.lsnIcpNearest.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     L.lsnRefine.restype = C.c_int
     L.lsnRefine.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.lsnFusionPackSurvivorsRun.restype = C.c_int
+    L.lsnFusionPackSurvivorsRun.argtypes = [vp] * 10
+    L.lsnFusionReconstructRun.restype = C.c_int
+    L.lsnFusionReconstructRun.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_longlong, vp, vp, vp, vp, vp, vp]
+    L.lsnShardUniqueId.restype = C.c_int
+    L.lsnShardUniqueId.argtypes = [vp]
+    L.lsnShardCreate.restype = vp
+    L.lsnShardCreate.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    L.lsnShardDestroy.restype = None
+    L.lsnShardDestroy.argtypes = [vp]
+    L.lsnShardMergedCapacity.restype = C.c_longlong
+    L.lsnShardMergedCapacity.argtypes = [vp]
+    L.lsnShardLastBytesSent.restype = C.c_longlong
+    L.lsnShardLastBytesSent.argtypes = [vp]
+    L.lsnShardSetParams.restype = C.c_int
+    L.lsnShardSetParams.argtypes = [vp, vp, vp, vp, vp]
+    L.lsnShardStep.restype = C.c_int
+    L.lsnShardStep.argtypes = [vp, vp, vp, vp, vp, vp]
     L.lsnIcpTrace.restype = C.c_int
     L.lsnIcpTrace.argtypes = [vp, vp, C.c_int, vp]
     L.lsnIcpSetProfiling.restype = C.c_int
@@ -383,6 +402,17 @@ class FusionPlan:
         _check(lib().lsnFusionReconstruct(self._h, int(n_shards), int(maps_per_shard), d_masks, d_depth_c, d_rgb_c, int(slab), d_tile_prefix,
                                           d_shard_offsets, d_merged, d_merged_offsets, stream or None), "lsnFusionReconstruct")
 
+    def pack_survivors_run(self, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, d_tick_base, stream=0):
+        """pack_survivors with all ticks back to back (one contiguous run per shard); fills d_tick_base [n_ticks]."""
+        _check(lib().lsnFusionPackSurvivorsRun(self._h, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, d_tick_base,
+                                               stream or None), "lsnFusionPackSurvivorsRun")
+
+    def reconstruct_run(self, n_shards, maps_per_shard, d_masks, d_depth_c, d_rgb_c, run_len, d_tile_prefix, d_shard_offsets, d_merged,
+                        d_merged_offsets, d_tick_base_scratch, stream=0):
+        _check(lib().lsnFusionReconstructRun(self._h, int(n_shards), int(maps_per_shard), d_masks, d_depth_c, d_rgb_c, int(run_len), d_tile_prefix,
+                                             d_shard_offsets, d_merged, d_merged_offsets, d_tick_base_scratch, stream or None),
+               "lsnFusionReconstructRun")
+
     def lookback_failed(self, stream=0):
         return int(lib().lsnFusionLookbackFailed(self._h, stream))
 
@@ -420,6 +450,53 @@ def merge_shards(device, n_shards, n_ticks, maps_per_shard, d_shards, shard_cap,
                  d_merged_offsets, stream=0):
     _check(lib().lsnMergeShards(int(device), int(n_shards), int(n_ticks), int(maps_per_shard), d_shards, int(shard_cap),
                                 d_shard_offsets, d_merged, int(merged_cap), d_merged_offsets, stream), "lsnMergeShards")
+
+
+def shard_unique_id():
+    """128 bytes from rank 0's RCCL (lsnShardUniqueId); every rank passes the same ones to Shard()."""
+    require_gpu()
+    buf = (C.c_ubyte * 128)()
+    _check(lib().lsnShardUniqueId(buf), "lsnShardUniqueId")
+    return bytes(buf)
+
+
+class Shard:
+    """lsnShard*: this rank's block of sensors in, the merged cloud of all sensors out (RCCL all-gathers inside the library)."""
+
+    def __init__(self, device, rank, world, unique_id, n_ticks, widths, heights):
+        require_gpu()
+        w, h = _as(widths, np.int32), _as(heights, np.int32)
+        self.n_ticks, self.n_maps, self.world, self.rank = int(n_ticks), len(w), int(world), int(rank)
+        idb = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        self._h = lib().lsnShardCreate(int(device), self.rank, self.world, idb, self.n_ticks, self.n_maps, _ptr(w), _ptr(h))
+        if not self._h:
+            raise NativeUtilsError(f"lsnShardCreate failed: {last_error()}")
+        self.capacity = int(lib().lsnShardMergedCapacity(self._h))
+
+    def set_params(self, intr_all, wt_all, bounds, stream=0):
+        intr, wt, b = _as(intr_all, np.float32).ravel(), _as(wt_all, np.float32).ravel(), _as(bounds, np.float32).ravel()
+        assert intr.size == 7 * self.n_maps and wt.size == 12 * self.n_maps and b.size == 6
+        _check(lib().lsnShardSetParams(self._h, _ptr(intr), _ptr(wt), _ptr(b), stream), "lsnShardSetParams")
+
+    def step(self, d_depth_local, d_colors_local, stream=0):
+        """Returns (device pointer of the merged cloud [n_ticks][capacity] vertices, device pointer of its offsets [n_ticks][n_maps + 1])."""
+        mv, mo = C.c_void_p(), C.c_void_p()
+        _check(lib().lsnShardStep(self._h, d_depth_local, d_colors_local, C.byref(mv), C.byref(mo), stream), "lsnShardStep")
+        return mv.value, mo.value
+
+    def last_bytes_sent(self):
+        return int(lib().lsnShardLastBytesSent(self._h))
+
+    def close(self):
+        if self._h:
+            lib().lsnShardDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 NN_BRUTE, NN_GRID = 0, 1

@@ -1,4 +1,10 @@
-"""One block of sensors per GPU + all-gather of the merged cloud (torch.distributed; backend "nccl" = RCCL over xGMI).
+"""One block of sensors per GPU + all-gather of the merged cloud.
+
+The product path is ShardedFusion: a thin caller of the library's lsnShard* exports (C++ host glue + RCCL inside
+libNativeUtils.so, include/NativeUtils.h part 2b); torch.distributed is only used to hand rank 0's 128-byte RCCL id to the
+other ranks.  MergedCloudExchange / SurvivorExchange are the same protocol driven from Python over torch.distributed
+(backend "nccl" = RCCL, or gloo on host copies): they rehearse the N > 1 logic on CPU (tests/test_sharding_gloo.py) and serve
+as comparison legs in bench.py.
 
 The reference fans createVertices out over one std::thread per sensor and concatenates the per-sensor clouds in
 sensor order (src/NativeUtils/depthprocessing.cpp:708-733, formMesh :1594-1608).  Across GPUs the same structure is:
@@ -19,6 +25,49 @@ def sensor_block(n_sensors, world, rank):
         raise ValueError(f"{n_sensors} sensors cannot be split evenly over {world} GPUs")
     per = n_sensors // world
     return rank * per, (rank + 1) * per
+
+
+class ShardedFusion:
+    """lsnShard* (native.Shard): this rank's block of sensors in, the merged cloud of all sensors out.
+
+    group: a torch.distributed process group used ONLY for the rendezvous (broadcast of rank 0's unique id); None with
+    world == 1.  depth_local [T, mpr*P] u16-pattern, rgb_local [T, mpr*P*3] u8, resident on this rank's GPU."""
+
+    def __init__(self, rank, world, n_ticks, widths, heights, device, group=None):
+        self.rank, self.world, self.n_ticks = rank, world, n_ticks
+        self.device = torch.device(device)
+        ids = [native.shard_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0, group=group)
+        self.shard = native.Shard(self.device.index, rank, world, ids[0], n_ticks, widths, heights)
+        self.n_maps = self.shard.n_maps
+        self.capacity = self.shard.capacity
+
+    def set_params(self, intr_all, wt_all, bounds):
+        self.shard.set_params(intr_all, wt_all, bounds, int(torch.cuda.current_stream().cuda_stream))
+
+    def step(self, depth_local, rgb_local, stream=None):
+        """Returns (merged [T, capacity, 16] u8, merged_offsets [T, n_maps + 1] i32) as torch views of the handle's buffers
+        (valid until the next step)."""
+        st = int(torch.cuda.current_stream().cuda_stream) if stream is None else stream
+        mv, mo = self.shard.step(depth_local.data_ptr(), rgb_local.data_ptr(), st)
+        return _device_view(mv, (self.n_ticks, self.capacity, 16), torch.uint8, self.device), \
+            _device_view(mo, (self.n_ticks, self.n_maps + 1), torch.int32, self.device)
+
+    def close(self):
+        self.shard.close()
+
+
+class _Span:
+    """Just enough of the CUDA array interface for torch.as_tensor to wrap library-owned device memory without a copy."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _device_view(ptr, shape, dtype, device):
+    typestr = {torch.uint8: "|u1", torch.int32: "<i4"}[dtype]
+    return torch.as_tensor(_Span(ptr, shape, typestr), device=device)
 
 
 class MergedCloudExchange:
@@ -123,9 +172,13 @@ class SurvivorExchange:
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
 
-    def exchange(self, depth, rgb, stream=0):
-        """depth [T, mpr*P] u16, rgb [T, mpr*P*3] u8 (the rank's resident inputs).  Returns (merged, merged_offsets)."""
+    def exchange(self, depth, rgb, stream=None):
+        """depth [T, mpr*P] u16, rgb [T, mpr*P*3] u8 (the rank's resident inputs).  Returns (merged, merged_offsets).
+        stream: HIP stream handle of the pack / reconstruct launches; default = torch's current stream, the one the staging
+        copies and the collectives are ordered on."""
         T, W = self.T, self.world
+        if stream is None:
+            stream = int(torch.cuda.current_stream().cuda_stream) if self.pack_fn is None or self.recon_fn is None else 0
         if self.pack_fn is not None:
             self.pack_fn(depth, rgb, self.mask, self.depth_c, self.rgb_c, self.tile_prefix, self.offsets)
         else:

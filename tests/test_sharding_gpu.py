@@ -87,7 +87,7 @@ def test_survivor_exchange_kernels_on_one_gpu(gpu, S, G, w, h):
     whole.set_params(intr, wt, bounds)
     cap_loc = mpr * P
     tiles_loc = None
-    masks, dcs, ccs, tps, offs = [], [], [], [], []
+    masks, dcs, ccs, tps, offs, runs = [], [], [], [], [], []
     for r in range(G):
         s0, s1 = r * mpr, (r + 1) * mpr
         local = DeviceFusion(T, [w] * mpr, [h] * mpr)
@@ -103,6 +103,14 @@ def test_survivor_exchange_kernels_on_one_gpu(gpu, S, G, w, h):
         for _ in range(2 if r == 0 else 1):                      # shard 0 twice: the second pack counts from the depth thresholds
             local.plan.pack_survivors(d.data_ptr(), c.data_ptr(), mask.data_ptr(), dc.data_ptr(), cc.data_ptr(), tp.data_ptr(), off.data_ptr(), st)
         masks.append(mask); dcs.append(dc); ccs.append(cc); tps.append(tp); offs.append(off)
+        # the layout lsnShardStep sends: all ticks of the shard back to back, one contiguous run
+        rdc = torch.zeros((T * cap_loc,), dtype=torch.int16, device="cuda")
+        rcc = torch.zeros((T * cap_loc, 3), dtype=torch.uint8, device="cuda")
+        rmask, rtp, roff = torch.zeros_like(mask), torch.zeros_like(tp), torch.zeros_like(off)
+        tb = torch.zeros((T,), dtype=torch.int32, device="cuda")
+        local.plan.pack_survivors_run(d.data_ptr(), c.data_ptr(), rmask.data_ptr(), rdc.data_ptr(), rcc.data_ptr(), rtp.data_ptr(), roff.data_ptr(),
+                                      tb.data_ptr(), st)
+        runs.append((rdc, rcc, rmask, rtp, roff, tb))
     torch.cuda.synchronize()
     g_off = torch.stack(offs)                                     # [G, T, mpr+1]
     m = int(g_off[:, :, mpr].max().item())
@@ -122,6 +130,27 @@ def test_survivor_exchange_kernels_on_one_gpu(gpu, S, G, w, h):
         assert n > 0 and torch.equal(merged[k, :n], want_v[k, :n]), f"tick {k}"
         ov, _ = orc.generate_mesh_vertices(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, intr, wt, bounds)
         assert merged[k, :n].cpu().numpy().tobytes() == ov.tobytes(), f"tick {k} vs oracle"
+    # the same with the run layout: identical masks / prefixes / offsets, tick bases = prefix sums of the tick totals, and the
+    # whole-rig plan rebuilds the same merged cloud from [G][run_len] streams
+    for r in range(G):
+        rdc, rcc, rmask, rtp, roff, tb = runs[r]
+        assert torch.equal(rmask, masks[r]) and torch.equal(rtp, tps[r]) and torch.equal(roff, offs[r])
+        tot = offs[r][:, mpr].cpu().numpy()
+        assert list(tb.cpu().numpy()) == list(np.concatenate([[0], np.cumsum(tot)[:-1]]))
+    run_len = (max(int(o[:, mpr].sum()) for o in offs) + 7) & ~7
+    assert run_len < T * cap_loc
+    g_rdc = torch.stack([x[0][:run_len] for x in runs]).contiguous()
+    g_rcc = torch.stack([x[1][:run_len] for x in runs]).contiguous()
+    merged2 = torch.zeros_like(merged)
+    moff2 = torch.zeros_like(moff)
+    scratch = torch.zeros((G, T), dtype=torch.int32, device="cuda")
+    whole.plan.reconstruct_run(G, mpr, g_mask.data_ptr(), g_rdc.data_ptr(), g_rcc.data_ptr(), run_len, g_tp.data_ptr(), g_off.data_ptr(),
+                               merged2.data_ptr(), moff2.data_ptr(), scratch.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(moff2, want_o)
+    for k in range(T):
+        n = int(want_o[k, -1])
+        assert torch.equal(merged2[k, :n], want_v[k, :n]), f"run layout, tick {k}"
 
 
 def _survivor_worker(rank, port, out):
@@ -167,4 +196,57 @@ def test_rccl_survivor_exchange_world1(gpu, tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
     mp.spawn(_survivor_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert open(out).read() == "ok"
+
+
+def _shard_worker(rank, padded, out):
+    sys.path.insert(0, ROOT)
+    if padded:
+        os.environ["LSN_SHARD_PADDED"] = "1"
+    import numpy as np
+    import torch
+    from livescan3d_amd import synth
+    from livescan3d_amd.fusion import DeviceFusion
+    from livescan3d_amd.sharding import ShardedFusion
+    from oracle import orc
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    T, S, w, h = 3, 4, 256, 212
+    rigs = [synth.make_rig("noise" if k % 2 else "scene", S, w, h, seed=31, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+    intr, wt, bounds = rigs[0].intr, rigs[0].wt, rigs[0].bounds
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).to(dev)
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).to(dev)
+    sf = ShardedFusion(0, 1, T, [w] * S, [h] * S, dev)             # lsnShardUniqueId / lsnShardCreate: RCCL communicator of one rank
+    sf.set_params(intr, wt, bounds)
+    ok = True
+    for rep in range(3):                                            # the second step on counts from the depth thresholds
+        merged, moff = sf.step(depth, rgb)
+        torch.cuda.synchronize()
+        oh = moff.cpu().numpy()
+        for k in range(T):
+            want, counts = orc.generate_mesh_vertices(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, intr, wt, bounds)
+            n = int(oh[k, -1])
+            ok = ok and n == len(want) and list(np.diff(oh[k])) == list(counts) and merged[k, :n].cpu().numpy().tobytes() == want.tobytes()
+    whole = DeviceFusion(T, [w] * S, [h] * S, device=0)
+    whole.set_params(intr, wt, bounds)
+    want_v, want_o = whole.run(depth, rgb)
+    torch.cuda.synchronize()
+    ok = ok and bool(torch.equal(moff, want_o))
+    sent = sf.shard.last_bytes_sent()
+    full = T * S * w * h * 5
+    ok = ok and (sent > full if padded else sent < 0.8 * full)      # compact: survivors only; padded: whole capacity, no host read
+    sf.close()
+    with open(out, "w") as f:
+        f.write("ok" if ok else "mismatch")
+
+
+@pytest.mark.parametrize("padded", [False, True])
+def test_shard_exports_rccl_world1(gpu, tmp_path, padded):
+    """lsnShardUniqueId / lsnShardCreate / lsnShardSetParams / lsnShardStep: the multi-GPU step behind the C-ABI (C++ host glue +
+    RCCL inside libNativeUtils.so, no torch.distributed) with a communicator of one rank: pack, the grouped all-gathers, the
+    pinned read-back of the offset tables (or none with $LSN_SHARD_PADDED=1) and the reconstruction must give exactly what a
+    single-plan fusion and the oracle give."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_shard_worker, args=(padded, out), nprocs=1, join=True)
     assert open(out).read() == "ok"
