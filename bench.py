@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--exchange", choices=["survivors", "vertices"], default="survivors",
-                    help="N > 1: what the all-gathers carry (survivors: 5 B + 1 bit per pixel, rebuilt on every GPU; vertices: 16 B)")
+    ap.add_argument("--exchange", choices=["survivors", "survivors-python", "vertices"], default="survivors",
+                    help="N > 1: what the all-gathers carry (survivors: 5 B + 1 bit per pixel, rebuilt on every GPU, through the library's "
+                         "lsnShard* exports; survivors-python: the same protocol driven over torch.distributed; vertices: 16 B)")
     ap.add_argument("--no-mesh", action="store_true")
     ap.add_argument("--core-only", action="store_true", help="only the timed region behind `value` (for rocprofv3 summaries): no extra legs")
     ap.add_argument("--padded-exchange", action="store_true", help="N > 1: all-gather full-capacity slabs (no host sync)")
@@ -93,6 +94,10 @@ def main():
     # was launched, including 1 -- the only way to drive the RCCL calls on a one-GPU box
     multi = world > 1 or os.environ.get("LSN_BENCH_FORCE_DIST") == "1"
     if multi:
+        # RCCL prints a version banner on STDOUT when the first communicator of a process is created under NCCL_DEBUG=VERSION
+        # (what this image exports): stdout must carry the one JSON line only
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
@@ -131,17 +136,26 @@ def main():
     # N > 1: one exchange step per step forms the merged cloud on every GPU (sensor order = rank order).  Default: the
     # all-gathers carry the survivors' inputs (5 B + a 1-bit/pixel mask) and every GPU rebuilds all vertices with the same
     # arithmetic; --exchange vertices (and rigs whose widths are not multiples of 8) all-gather the 16-byte vertices.
-    xch = sx = whole = None
-    use_sx = multi and args.exchange == "survivors" and w % 8 == 0 and args.mode == 0
+    # The headline N > 1 step goes through the library's own lsnShard* exports (C++ host glue + RCCL inside libNativeUtils.so);
+    # `--exchange survivors-python` drives the same protocol from Python over torch.distributed instead (also what a gloo
+    # rehearsal with LSN_BENCH_SHARE_GPU=1 uses: RCCL refuses two ranks on one device).
+    xch = sx = whole = shard = None
+    survivors_ok = multi and w % 8 == 0 and args.mode == 0
+    use_shard = survivors_ok and args.exchange == "survivors" and not share
+    use_sx = survivors_ok and not use_shard and args.exchange in ("survivors", "survivors-python")
     if multi:
-        from livescan3d_amd.sharding import SurvivorExchange
-        if use_sx:
+        from livescan3d_amd.sharding import ShardedFusion, SurvivorExchange
+        if use_shard:
+            shard = ShardedFusion(rank, world, B, [w] * S, [h] * S, dev)
+            shard.set_params(intr_all, wt_all, bounds)
+        elif use_sx:
             whole = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
             whole.set_params(intr_all, wt_all, bounds)
             sx = SurvivorExchange(world, fus, whole, via_host=share)
         else:
             xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
-    prof_plan = whole.plan if use_sx else fus.plan
+    prof_plan = shard.shard.plan(True) if use_shard else (whole.plan if use_sx else fus.plan)
+    merged_out = [None, None]
 
     # Two resident input sets, used alternately: a real stream brings new frames every step, so nothing a step leaves in
     # L2 / Infinity Cache may serve the next one (the same buffer every step would let the count pass hit the cache).
@@ -151,7 +165,9 @@ def main():
     def step():
         d_in, c_in = (depth, rgb) if step_no[0] & 1 == 0 else (depth_b, rgb_b)
         step_no[0] += 1
-        if use_sx:
+        if use_shard:
+            merged_out[0], merged_out[1] = shard.step(d_in, c_in, stream)
+        elif use_sx:
             sx.exchange(d_in, c_in, stream)
         else:
             fus.run(d_in, c_in)
@@ -182,11 +198,15 @@ def main():
     thr_table, thr_build_ms = fus.plan.thresholds(copy=False)   # already built by the second warm-up run; reports its build time
 
     # algorithmic bytes of one launch of the dominant kernel on this rank
-    off = (sx.offsets if use_sx else fus.offsets).cpu().numpy().astype(np.int64)
+    if use_shard:
+        moff = merged_out[1].cpu().numpy().astype(np.int64)
+        off = moff[:, s0:s1 + 1] - moff[:, s0:s0 + 1]          # this rank's block inside the merged offsets
+    else:
+        off = (sx.offsets if use_sx else fus.offsets).cpu().numpy().astype(np.int64)
     V_local = int(off[:, -1].sum())
-    if use_sx:
+    if use_shard or use_sx:
         # recon_kernel rebuilds the WHOLE merged cloud on every GPU: 5 B read + 16 B written per vertex, 1 bit per pixel of mask
-        V_total = int(sx.merged_off[:, -1].sum().item())
+        V_total = int(merged_out[1][:, -1].sum().item()) if use_shard else int(sx.merged_off[:, -1].sum().item())
         alg_bytes = 21 * V_total + (B * S * P) // 8
     else:
         alg_bytes = 2 * P * S_loc * B + 19 * V_local            # fuse_kernel<1>: sum over its sensor-frames of 2P + 19V
@@ -221,7 +241,8 @@ def main():
                 "count_pass": ("arithmetic (LSN_NO_THRESHOLDS=1)" if os.environ.get("LSN_NO_THRESHOLDS", "0") not in ("", "0")
                                else "per-pixel depth thresholds"),
                 "threshold_build_ms_once_per_calibration": thr_build_ms,
-                "parallelism": f"sensor-shard{world}" + (("+allgather(survivors)" if use_sx else "+allgather(vertices)") if multi else ""),
+                "parallelism": f"sensor-shard{world}" + (("+allgather(survivors; lsnShard* = C++ host glue + RCCL inside the library)" if use_shard else
+                                                          "+allgather(survivors; Python over torch.distributed)" if use_sx else "+allgather(vertices)") if multi else ""),
                 "bounds": [float(x) for x in bounds],
             },
             "roofline": {
@@ -231,7 +252,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None if use_sx else pmc_traffic(args, S_loc, B, w, h),
+                "traffic": None if (use_sx or use_shard) else pmc_traffic(args, S_loc, B, w, h),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_avg_ms": kstats["avg_ms"],
                 "kernel_launches": kstats["launches"],
@@ -309,8 +330,13 @@ def main():
             del d2
 
     # ---- N > 1, extra leg: the exchange step carrying 16-byte vertices (what the survivor exchange is compared with) ------
-    if use_sx and not args.no_tick_parallel:
+    if (use_sx or use_shard) and not args.no_tick_parallel:
         vx = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
+        # the headline step once more on `depth` / `rgb`, the inputs the comparison legs use
+        if use_shard:
+            m_v, m_o = shard.step(depth, rgb, stream)
+        else:
+            m_v, m_o = sx.exchange(depth, rgb, stream)
 
         def vstep():
             fus.run(depth, rgb)
@@ -324,17 +350,41 @@ def main():
         sync()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        same = bool(torch.equal(sx.merged_off, vx.merged_off))
+        same = bool(torch.equal(m_o, vx.merged_off))
         for k in (0, B - 1):
-            n_chk = int(sx.merged_off[k, -1].item())
-            same = same and bool(torch.equal(sx.merged[k, :n_chk], vx.merged[k, :n_chk]))
+            n_chk = int(m_o[k, -1].item())
+            same = same and bool(torch.equal(m_v[k, :n_chk], vx.merged[k, :n_chk]))
         if rank == 0:
             result["vertex_exchange"] = {
                 "value": B * args.steps / float(el.item()), "unit": "frames/s", "scaling": "strong", "ms_per_step": 1e3 * float(el.item()) / args.steps,
                 "merged_cloud_identical_to_survivor_exchange": same, "slab_vertices": vx.last_slab,
                 "note": "the same step with all-gathers of the 16-byte vertices + lsnMergeShards (bench.py --exchange vertices makes it `value`)"}
-            result["config"]["exchange_slab_survivors"] = sx.last_slab
+            if use_shard:
+                result["config"]["exchange_bytes_sent_per_rank_per_step"] = shard.shard.last_bytes_sent()
+            else:
+                result["config"]["exchange_slab_survivors"] = sx.last_slab
         del vx
+        if use_shard and survivors_ok:
+            # the same protocol driven from Python over torch.distributed (round 1's path): what moving the host glue into the library bought
+            whole_p = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
+            whole_p.set_params(intr_all, wt_all, bounds)
+            sxp = SurvivorExchange(world, fus, whole_p)
+            for _ in range(max(1, args.warmup)):
+                sxp.exchange(depth, rgb, stream)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sxp.exchange(depth, rgb, stream)
+            sync()
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            same = bool(torch.equal(m_o, sxp.merged_off))
+            if rank == 0:
+                result["python_survivor_exchange"] = {
+                    "value": B * args.steps / float(el.item()), "unit": "frames/s", "ms_per_step": 1e3 * float(el.item()) / args.steps,
+                    "merged_offsets_identical": same,
+                    "note": "the same survivor exchange driven from Python: five torch.distributed all-gathers, two staging copies and a .item() per step"}
+            del sxp, whole_p
 
     # ---- N > 1, extra leg: the same ticks spread over the GPUs instead of the sensors (no exchange step at all) ------
     if multi and not args.no_tick_parallel:

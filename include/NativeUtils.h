@@ -216,6 +216,9 @@ long long lsnShardMergedCapacity(const LsnShard *shard);
 int lsnShardSetParams(LsnShard *shard, const float *intr_all, const float *wt_all, const float *bounds6, void *stream);
 int lsnShardStep(LsnShard *shard, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets,
                  void *stream);
+/* The handle's two plans, for lsnFusionProfile / lsnFusionKernelStats / lsnFusionCheck only (owned by the handle):
+ * whole = 0: this rank's block of sensors (count / pack kernels), whole != 0: the whole rig (recon_kernel). */
+LsnFusion *lsnShardPlan(LsnShard *shard, int whole);
 /* bytes this rank contributed to the collectives of the last step (what every other rank received from it) */
 long long lsnShardLastBytesSent(const LsnShard *shard);
 

@@ -577,6 +577,7 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
     return sh;
 }
 
+extern "C" LsnFusion *lsnShardPlan(LsnShard *sh, int whole) { return sh ? (whole ? sh->whole : sh->local) : nullptr; }
 extern "C" long long lsnShardMergedCapacity(const LsnShard *sh) { return sh && sh->whole ? sh->whole->cap : 0; }
 extern "C" long long lsnShardLastBytesSent(const LsnShard *sh) { return sh ? sh->last_bytes_per_rank : 0; }
 

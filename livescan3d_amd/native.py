@@ -25,7 +25,7 @@ EXPORTS = [
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
-    "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardCreate", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
+    "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
@@ -148,6 +148,8 @@ def lib():
     L.lsnShardUniqueId.argtypes = [vp]
     L.lsnShardCreate.restype = vp
     L.lsnShardCreate.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    L.lsnShardPlan.restype = vp
+    L.lsnShardPlan.argtypes = [vp, C.c_int]
     L.lsnShardDestroy.restype = None
     L.lsnShardDestroy.argtypes = [vp]
     L.lsnShardMergedCapacity.restype = C.c_longlong
@@ -486,6 +488,13 @@ class Shard:
 
     def last_bytes_sent(self):
         return int(lib().lsnShardLastBytesSent(self._h))
+
+    def plan(self, whole=True):
+        """A non-owning FusionPlan view of one of the handle's plans (profile / kernel_stats / check only)."""
+        v = object.__new__(FusionPlan)
+        v._h = lib().lsnShardPlan(self._h, 1 if whole else 0)
+        v.close = lambda: None
+        return v
 
     def close(self):
         if self._h:
