@@ -60,6 +60,20 @@ def parse():
 
 
 @contextlib.contextmanager
+def stdout_to_stderr():
+    """File-descriptor level: whatever native code prints on stdout inside the block lands on stderr."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+@contextlib.contextmanager
 def leg(result, name):
     """An extra leg of the bench line must never cost the headline: a failure is recorded under its name instead."""
     try:
@@ -146,7 +160,8 @@ def main():
     if multi:
         from livescan3d_amd.sharding import ShardedFusion, SurvivorExchange
         if use_shard:
-            shard = ShardedFusion(rank, world, B, [w] * S, [h] * S, dev)
+            with stdout_to_stderr():   # RCCL's banner (see above) goes wherever fd 1 points while the communicator is created
+                shard = ShardedFusion(rank, world, B, [w] * S, [h] * S, dev)
             shard.set_params(intr_all, wt_all, bounds)
         elif use_sx:
             whole = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
