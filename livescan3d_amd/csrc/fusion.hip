@@ -233,7 +233,10 @@ __global__ __launch_bounds__(kThreads) void count_thr_kernel(const FuseArgs a)
 // MODE 0 = count only (writes tile_counts), 1 = write with offsets from tile_counts (exclusive prefixes by then),
 // 3 = streamed: mode 1 for this batch AND the count of the same tile of the NEXT batch (depth_next) in one workgroup --
 // the count pass is VALU-bound, the write pass HBM-bound, and inside one kernel they share every CU all the time.
-template <int MODE, bool VEC>
+// LAZY (write pass only): the colours are loaded after the keep predicates are known, by the lanes that kept a pixel --
+// spatially coherent frames (real scenes: background beyond the crop box, invalid regions) then never fetch the colour
+// lines of rejected areas; the price is that the colour load no longer flies together with the depth load.
+template <int MODE, bool VEC, bool LAZY = false>
 __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
 {
     constexpr bool kWrite = MODE != 0;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
 
     const Tile t = locate(a, tick, tile);
     Inputs in;
-    load_inputs<VEC, kWrite>(t, in);
+    load_inputs<VEC, kWrite && !LAZY>(t, in);
     Inputs nx;
     if (MODE == 3) {
         // the next batch's tile: same geometry, other depth buffer; its loads fly together with this tile's
@@ -261,6 +264,16 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     bool keep[kPxPerLane];
     uint4 vert[kPxPerLane];
     compute_pixels<kWrite>(a, P, in, xf, yf, keep, vert);
+    if (kWrite && LAZY) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) any |= keep[k];
+        if (any) {
+            load_rgb<VEC>(t, in);
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) vert[k].x = rgba_of(in, k);
+        }
+    }
     if (MODE == 3) {
         int wt = 0;
         bool arithmetic = true;
@@ -533,6 +546,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
     p->device = device;
     if (const char *env = getenv("LSN_TILES_PER_RUN")) p->tiles_per_run_override = atoi(env);
     if (const char *env = getenv("LSN_NO_THRESHOLDS")) p->thr_enabled = atoi(env) == 0;
+    if (const char *env = getenv("LSN_LAZY_RGB")) p->lazy_rgb = atoi(env) != 0;
     p->n_ticks = n_ticks;
     p->n_maps = n_maps;
     std::vector<FrameDesc> fr(n_maps);
@@ -861,8 +875,13 @@ int lsn::next_event_pair(LsnFusion *p, hipEvent_t &e0, hipEvent_t &e1)
 }
 
 template <int MODE>
-static void launch(bool vec, int grid, hipStream_t s, const FuseArgs &a)
+static void launch(bool vec, int grid, hipStream_t s, const FuseArgs &a, bool lazy_rgb = false)
 {
+    if (MODE == 1 && lazy_rgb) {
+        if (vec) hipLaunchKernelGGL((fuse_kernel<1, true, true>), dim3(grid), dim3(kThreads), 0, s, a);
+        else     hipLaunchKernelGGL((fuse_kernel<1, false, true>), dim3(grid), dim3(kThreads), 0, s, a);
+        return;
+    }
     if (vec) hipLaunchKernelGGL((fuse_kernel<MODE, true>), dim3(grid), dim3(kThreads), 0, s, a);
     else     hipLaunchKernelGGL((fuse_kernel<MODE, false>), dim3(grid), dim3(kThreads), 0, s, a);
 }
@@ -951,7 +970,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         if (hooks && hooks->counted) LSN_HIP(hipEventRecord(hooks->counted, s));
         if (hooks && hooks->colours_ready) LSN_HIP(hipStreamWaitEvent(s, hooks->colours_ready, 0));
         if (e0) LSN_HIP(hipEventRecord(e0, s));
-        launch<1>(vec, grid, s, a);
+        launch<1>(vec, grid, s, a, p->lazy_rgb);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
         if (hooks && hooks->written) LSN_HIP(hipEventRecord(hooks->written, s));
     } else {

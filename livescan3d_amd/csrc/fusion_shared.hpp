@@ -230,6 +230,40 @@ __device__ __forceinline__ void load_inputs(const Tile &t, Inputs &in)
     }
 }
 
+// The colours alone (the lazy-colour write pass loads them after the keep predicates are known, for the lanes that kept anything).
+template <bool VEC>
+__device__ __forceinline__ void load_rgb(const Tile &t, Inputs &in)
+{
+    const int p0 = t.px0 + threadIdx.x * kPxPerLane;
+    if (VEC) {
+        if (p0 < t.npix) {
+            const uint2 *cp = reinterpret_cast<const uint2 *>(t.cptr + 3ll * p0);
+            const uint2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+            in.cw[0] = c0.x; in.cw[1] = c0.y; in.cw[2] = c1.x; in.cw[3] = c1.y; in.cw[4] = c2.x; in.cw[5] = c2.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            if (p0 + k < t.npix) {
+                const unsigned char *c = t.cptr + 3ll * (p0 + k);
+                const unsigned int rgb = c[0] | (c[1] << 8) | (c[2] << 16);
+                const int b = 3 * k;
+                in.cw[b >> 2] |= rgb << ((b & 3) * 8);
+                if ((b & 3) > 1) in.cw[(b >> 2) + 1] |= rgb >> ((4 - (b & 3)) * 8);
+            }
+        }
+    }
+}
+
+// {R, G, B, A = 255} of pixel k of the lane (depthprocessing.cpp:1598-1601)
+__device__ __forceinline__ unsigned int rgba_of(const Inputs &in, int k)
+{
+    const int b = 3 * k;
+    const unsigned int lo = in.cw[b >> 2];
+    const unsigned int hi = in.cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
+    return (__funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu) | 0xFF000000u;
+}
+
 // Keep predicates (wave-wide lane masks in SGPR pairs) and, when WRITE, the assembled vertices of a lane's 8 pixels.
 // Branch-free: a zero depth (invalid pixel, :144, or a lane past the frame end) is computed and then dropped.
 // The column / row factors of a lane's 8 pixels (they depend on the tile geometry only, not on the tick or the batch).
@@ -286,10 +320,7 @@ __device__ __forceinline__ void compute_pixels(const FuseArgs &a, const SensorPa
         if (WRITE) {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int b = 3 * (k + j);
-                const unsigned int lo = in.cw[b >> 2];
-                const unsigned int hi = in.cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
-                vert[k + j].x = (__funnelshift_r(lo, hi, (b & 3) * 8) & 0x00FFFFFFu) | 0xFF000000u;  // A = 255 (:1601)
+                vert[k + j].x = rgba_of(in, k + j);  // A = 255 (:1601)
                 vert[k + j].y = __float_as_uint(j ? ox.y : ox.x);
                 vert[k + j].z = __float_as_uint(j ? oy.y : oy.x);
                 vert[k + j].w = __float_as_uint(j ? oz.y : oz.x);
@@ -414,6 +445,7 @@ struct LsnFusion {
     lsn::DevBuf thr;
     bool thr_valid = false;
     bool thr_enabled = true;             // $LSN_NO_THRESHOLDS=1 keeps the arithmetic count pass (ablation / tests)
+    bool lazy_rgb = true;                // the write pass loads colours only where a lane kept a pixel; $LSN_LAZY_RGB=0 loads them with the depth (ablation)
     int runs_with_params = 0;
     std::vector<float> last_intr, last_wt;
     float thr_build_ms = 0;

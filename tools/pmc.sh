@@ -36,7 +36,11 @@ if fetch is not None and write is not None:
     path = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_traffic.json")
     d = json.load(open(path)) if os.path.exists(path) else {}
     T = int(os.environ.get("PMC_TICKS", "64"))
-    d[f"mode$mode-8x512x424-ticks{T}"] = {"kernel": kernel, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("fusion.hip", "fusion_shared.hpp"):
+        hsh.update(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "livescan3d_amd", "csrc", f), "rb").read())
+    d[f"mode$mode-8x512x424-ticks{T}"] = {"kernel": kernel, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "kernel_sources_sha256": hsh.hexdigest(),
         "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "note": "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read); WRITE_SIZE as read"}
     json.dump(d, open(path, "w"), indent=1, sort_keys=True)
     print("traffic", d)
