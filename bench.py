@@ -60,20 +60,6 @@ def parse():
 
 
 @contextlib.contextmanager
-def stdout_to_stderr():
-    """File-descriptor level: whatever native code prints on stdout inside the block lands on stderr."""
-    sys.stdout.flush()
-    saved = os.dup(1)
-    try:
-        os.dup2(2, 1)
-        yield
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(saved)
-
-
-@contextlib.contextmanager
 def leg(result, name):
     """An extra leg of the bench line must never cost the headline: a failure is recorded under its name instead."""
     try:
@@ -84,6 +70,11 @@ def leg(result, name):
 
 def main():
     args = parse()
+    # stdout carries the ONE JSON line and nothing else: RCCL (version banner, "NCCL WARN ..." lines) and other native code
+    # print on fd 1, so fd 1 is pointed at stderr for the whole run and the line goes out through a private copy of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from livescan3d_amd import native, synth
@@ -108,10 +99,6 @@ def main():
     # was launched, including 1 -- the only way to drive the RCCL calls on a one-GPU box
     multi = world > 1 or os.environ.get("LSN_BENCH_FORCE_DIST") == "1"
     if multi:
-        # RCCL prints a version banner on STDOUT when the first communicator of a process is created under NCCL_DEBUG=VERSION
-        # (what this image exports): stdout must carry the one JSON line only
-        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
@@ -160,8 +147,7 @@ def main():
     if multi:
         from livescan3d_amd.sharding import ShardedFusion, SurvivorExchange
         if use_shard:
-            with stdout_to_stderr():   # RCCL's banner (see above) goes wherever fd 1 points while the communicator is created
-                shard = ShardedFusion(rank, world, B, [w] * S, [h] * S, dev)
+            shard = ShardedFusion(rank, world, B, [w] * S, [h] * S, dev)
             shard.set_params(intr_all, wt_all, bounds)
         elif use_sx:
             whole = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
@@ -510,7 +496,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
 
 
 PCIE_GBS = 63.0   # MI355X_MICROARCH.md: PCIe 5.0 x16, per direction

@@ -20,7 +20,7 @@ src0 = xyz[int(off[0]):int(off[1])].contiguous()          # sensor 0 is refined 
 tgt = xyz[int(off[1]):].contiguous()
 n1, n2 = tgt.shape[0], src0.shape[0]
 ws = native.IcpWorkspace(0, n1, n2)
-for rep in range(3):
+for rep in range(int(os.environ.get("ICP_REPS", "3"))):
     src = src0.clone()
     Rt = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device="cuda")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
