@@ -4,10 +4,13 @@ The product is the C-ABI shared library livescan3d_amd/lib/libNativeUtils.so (HI
 include/NativeUtils.h.  This package only holds what surrounds it:
 
   csrc/      hand-written HIP kernels + the C-ABI
-  native.py  ctypes binding of the C-ABI (mirror of LiveScanServer's P/Invoke declarations)
-  server.py  host-side mirror of the reference callers (KinectServer.GenerateMesh, refineWorker_DoWork)
-  sharding.py one-sensor-per-GPU sharding + all-gather of the merged cloud (torch.distributed / RCCL)
-  synth.py   seeded synthetic Kinect-like inputs
+  native.py   ctypes binding of the C-ABI (mirror of LiveScanServer's P/Invoke declarations; generate_mesh_from_depth_maps /
+              icp / refine mirror KinectServer.GenerateMesh, MainWindowForm's ICP call and refineWorker_DoWork)
+  fusion.py   torch-buffer convenience wrapper around native.FusionPlan (device-resident batches)
+  sharding.py ShardedFusion = thin caller of the library's lsnShard* exports (sensor block per GPU, RCCL inside the
+              library); the same protocol over torch.distributed for CPU rehearsals and comparison legs
+  replay.py   the reference's capture / replay file format (depthprocessing.cpp:1316-1341)
+  synth.py    seeded synthetic Kinect-like inputs
 
 There is no CPU fallback: every compute entry point raises when the HIP library or a GPU is missing.
 """
