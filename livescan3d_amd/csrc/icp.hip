@@ -523,7 +523,7 @@ __device__ __forceinline__ void scan_points(const float4 *__restrict__ sorted, i
 //   nn_cull_kernel    one wave per group: seed every query with its previous neighbour (a REAL target point, so the
 //                     result does not depend on it), W, the largest bound; emits (group, super-block) items
 //   nn_blocks_kernel  one wave per item: the super-block's 64 block boxes, one per lane, against W, then against every
-//                     query's own bound; emits (group, point range) items, at most kChunk points each
+//                     query's own bound; emits (group, point range) items, at most 128 points each
 //   nn_scan_kernel    one wave per item: 64 queries x the range's points through LDS, packed f32; the lexicographic
 //                     (distance, index) minimum is merged into the query's 64-bit key with atomicMin
 //   nn_finish_kernel  one thread per query: index / distance out (original order) + the one-to-one claim
@@ -563,6 +563,7 @@ struct NnWork {  // device work lists of one ICP workspace
     uint2 *list_a;      // (group, super-block), segment s = entries [s * seg_a, (s + 1) * seg_a)
     int4 *list_b;       // (group, first point, end point, -)
     int seg_a, seg_b;   // segment capacities
+    int item_points;    // points per scan item (a multiple of 64, <= kChunk)
     int *counters;      // two banks of kBankInts
 };
 
@@ -589,11 +590,11 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane)
     return incl - v;
 }
 
-// Appends the point range [js, je) of every lane with `take` set to list B as (group, range) items of <= kChunk points.
+// Appends the point range [js, je) of every lane with `take` set to list B as (group, range) items of <= item_points points.
 // `spread` picks the segment: a heavy group's ranges are spread over the segments by its super-blocks.
 __device__ __forceinline__ void emit_ranges(const NnWork &wk, int *bank, int which, int g, int spread, bool take, int js, int je, int lane)
 {
-    const int n_items = take ? (je - js + kChunk - 1) / kChunk : 0;
+    const int n_items = take ? (je - js + wk.item_points - 1) / wk.item_points : 0;
     const int before = wave_excl_scan_i(n_items, lane);
     const int total = __shfl(before + n_items, 63, 64);
     if (total == 0) return;  // wave-uniform
@@ -606,8 +607,8 @@ __device__ __forceinline__ void emit_ranges(const NnWork &wk, int *bank, int whi
         return;
     }
     for (int c = 0; c < n_items; c++) {
-        const int a = js + c * kChunk;
-        wk.list_b[(size_t)seg * wk.seg_b + base + before + c] = make_int4(g, a, min(a + kChunk, je), 0);
+        const int a = js + c * wk.item_points;
+        wk.list_b[(size_t)seg * wk.seg_b + base + before + c] = make_int4(g, a, min(a + wk.item_points, je), 0);
     }
 }
 
@@ -1274,6 +1275,7 @@ struct LsnIcp {
     lsn::DevBuf idx, dist, keys, counters, part1, part3, state, trace;
     lsn::DevBuf best_key, groups, list_a, list_b;   // the NN step's per-query keys, per-group boxes and work lists
     int seg_a = 0, seg_b = 0;   // capacity of one list segment
+    int item_points = 128;      // points per scan item; $LSN_ICP_ITEM (tuning): 64, 128, 192 or 256.  128 instead of 256: 0.094 -> 0.089 ms/iteration (configs[1])
     // optional phase timing of lsnIcpRun (lsnIcpSetProfiling): HIP events on the caller's stream around
     // [0] grid build + source sort, [1] the NN steps (incl. the fused apply), [2] statistics + Kabsch sums + solve, [3] final apply
     bool profiling = false;
@@ -1316,6 +1318,10 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
         const int n_groups = (max_n2 + 63) / 64;
         // generous: a seeded group needs ~5 super-blocks and ~10 point ranges; $LSN_ICP_TINY_LISTS=1 forces the overflow path (tests)
         const bool tiny = getenv("LSN_ICP_TINY_LISTS") && atoi(getenv("LSN_ICP_TINY_LISTS")) != 0;
+        if (const char *e = getenv("LSN_ICP_ITEM")) {
+            const int v = atoi(e);
+            if (v == 64 || v == 128 || v == 192 || v == 256) w->item_points = v;
+        }
         w->seg_a = tiny ? 2 : 1024 + n_groups / 4;   // x 64 segments: 64 k + 16 per group
         w->seg_b = tiny ? 2 : 8192 + 2 * n_groups;   // x 64 segments: 512 k + 128 per group
         bad |= w->best_key.reserve(sizeof(unsigned long long) * (size_t)max_n2) != 0;
@@ -1419,6 +1425,7 @@ static NnWork work_of(LsnIcp *w)
     wk.list_b = w->list_b.as<int4>();
     wk.seg_a = w->seg_a;
     wk.seg_b = w->seg_b;
+    wk.item_points = w->item_points;
     wk.counters = w->counters.as<int>();
     return wk;
 }
