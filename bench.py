@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--exchange", choices=["survivors", "survivors-python", "vertices"], default="survivors",
                     help="N > 1: what the all-gathers carry (survivors: 5 B + 1 bit per pixel, rebuilt on every GPU, through the library's "
                          "lsnShard* exports; survivors-python: the same protocol driven over torch.distributed; vertices: 16 B)")
+    ap.add_argument("--compare-exchanges", action="store_true",
+                    help="N > 1: also time the vertex exchange and the Python-driven survivor exchange (more collectives through "
+                         "torch.distributed after the headline; always on under LSN_BENCH_FORCE_DIST=1)")
     ap.add_argument("--no-mesh", action="store_true")
     ap.add_argument("--core-only", action="store_true", help="only the timed region behind `value` (for rocprofv3 summaries): no extra legs")
     ap.add_argument("--padded-exchange", action="store_true", help="N > 1: all-gather full-capacity slabs (no host sync)")
@@ -147,8 +150,23 @@ def main():
     if multi:
         from livescan3d_amd.sharding import ShardedFusion, SurvivorExchange
         if use_shard:
-            shard = ShardedFusion(rank, world, B, [w] * S, [h] * S, dev)
-            shard.set_params(intr_all, wt_all, bounds)
+            # the library's own RCCL step; if it cannot be set up on ANY rank (e.g. librccl missing), every rank falls back to the
+            # Python-driven protocol together -- the decision is collective, so no rank is left waiting in a communicator
+            err = None
+            try:
+                shard = ShardedFusion(rank, world, B, [w] * S, [h] * S, dev)
+                shard.set_params(intr_all, wt_all, bounds)
+            except Exception as ex:  # noqa: BLE001
+                err, shard = f"{type(ex).__name__}: {ex}", None
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                print(f"[bench rank {rank}] lsnShard* unavailable ({err}); falling back to the Python-driven survivor exchange", file=sys.stderr)
+                if shard is not None:
+                    shard.close()
+                shard, use_shard, use_sx = None, False, True
+        if use_shard:
+            pass
         elif use_sx:
             whole = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
             whole.set_params(intr_all, wt_all, bounds)
@@ -341,7 +359,8 @@ def main():
             del d2
 
     # ---- N > 1, extra leg: the exchange step carrying 16-byte vertices (what the survivor exchange is compared with) ------
-    if (use_sx or use_shard) and not args.no_tick_parallel:
+    compare = args.compare_exchanges or os.environ.get("LSN_BENCH_FORCE_DIST") == "1" or share
+    if (use_sx or use_shard) and compare and not args.no_tick_parallel:
         vx = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
         # the headline step once more on `depth` / `rgb`, the inputs the comparison legs use
         if use_shard:

@@ -94,6 +94,18 @@ int lsnGetLastError(char *buf, int len);
 /* Number of visible HIP devices (0 when there is none or the runtime cannot initialise). */
 int lsnDeviceCount(void);
 
+/* Device memory and streams for hosts that speak nothing but this C-ABI (a C# or plain C host of the device-resident API has
+ * no HIP of its own): thin wrappers over hipMalloc / hipFree / hipMemcpyAsync / hipStreamCreate / hipStreamSynchronize.
+ * Copies are asynchronous on `stream` (0 = the null stream); host buffers must stay valid until the stream has been
+ * synchronised.  All return 0 / a non-null pointer on success. */
+void *lsnDeviceMalloc(int device, long long bytes);
+int lsnDeviceFree(int device, void *d_ptr);
+int lsnDeviceUpload(int device, void *d_dst, const void *h_src, long long bytes, void *stream);
+int lsnDeviceDownload(int device, void *h_dst, const void *d_src, long long bytes, void *stream);
+void *lsnStreamCreate(int device);
+int lsnStreamDestroy(int device, void *stream);
+int lsnStreamSynchronize(int device, void *stream);
+
 /* A fusion plan: fixed rig geometry (n_maps sensors with widths/heights, as in the reference call) replicated
  * over n_ticks ticks that are fused by ONE launch sequence.  Holds the geometry tables and scan scratch in HBM. */
 typedef struct LsnFusion LsnFusion;

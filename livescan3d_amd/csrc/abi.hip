@@ -65,6 +65,80 @@ extern "C" int lsnDeviceCount(void)
     return n;
 }
 
+// ---- device memory / streams for hosts without a HIP of their own ------------------------------------------------------------
+
+extern "C" void *lsnDeviceMalloc(int device, long long bytes)
+{
+    lsn::clear_error();
+    if (bytes <= 0) {
+        lsn::set_error("lsnDeviceMalloc: bad size %lld", bytes);
+        return nullptr;
+    }
+    LSN_HIP_NULL(hipSetDevice(device));
+    void *p = nullptr;
+    LSN_HIP_NULL(hipMalloc(&p, (size_t)bytes));
+    return p;
+}
+
+extern "C" int lsnDeviceFree(int device, void *d_ptr)
+{
+    lsn::clear_error();
+    if (!d_ptr) return 0;
+    LSN_HIP(hipSetDevice(device));
+    LSN_HIP(hipFree(d_ptr));
+    return 0;
+}
+
+extern "C" int lsnDeviceUpload(int device, void *d_dst, const void *h_src, long long bytes, void *stream)
+{
+    lsn::clear_error();
+    if (!d_dst || !h_src || bytes < 0) {
+        lsn::set_error("lsnDeviceUpload: bad arguments");
+        return -1;
+    }
+    LSN_HIP(hipSetDevice(device));
+    if (bytes > 0) LSN_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, lsn::as_stream(stream)));
+    return 0;
+}
+
+extern "C" int lsnDeviceDownload(int device, void *h_dst, const void *d_src, long long bytes, void *stream)
+{
+    lsn::clear_error();
+    if (!h_dst || !d_src || bytes < 0) {
+        lsn::set_error("lsnDeviceDownload: bad arguments");
+        return -1;
+    }
+    LSN_HIP(hipSetDevice(device));
+    if (bytes > 0) LSN_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, lsn::as_stream(stream)));
+    return 0;
+}
+
+extern "C" void *lsnStreamCreate(int device)
+{
+    lsn::clear_error();
+    LSN_HIP_NULL(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    LSN_HIP_NULL(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+
+extern "C" int lsnStreamDestroy(int device, void *stream)
+{
+    lsn::clear_error();
+    if (!stream) return 0;
+    LSN_HIP(hipSetDevice(device));
+    LSN_HIP(hipStreamDestroy(lsn::as_stream(stream)));
+    return 0;
+}
+
+extern "C" int lsnStreamSynchronize(int device, void *stream)
+{
+    lsn::clear_error();
+    LSN_HIP(hipSetDevice(device));
+    LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
+    return 0;
+}
+
 namespace {
 
 struct Ctx {

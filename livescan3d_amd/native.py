@@ -25,6 +25,7 @@ EXPORTS = [
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
+    "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
     "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
@@ -140,6 +141,20 @@ def lib():
     L.lsnIcpNearest.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     L.lsnRefine.restype = C.c_int
     L.lsnRefine.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.lsnDeviceMalloc.restype = vp
+    L.lsnDeviceMalloc.argtypes = [C.c_int, C.c_longlong]
+    L.lsnDeviceFree.restype = C.c_int
+    L.lsnDeviceFree.argtypes = [C.c_int, vp]
+    L.lsnDeviceUpload.restype = C.c_int
+    L.lsnDeviceUpload.argtypes = [C.c_int, vp, vp, C.c_longlong, vp]
+    L.lsnDeviceDownload.restype = C.c_int
+    L.lsnDeviceDownload.argtypes = [C.c_int, vp, vp, C.c_longlong, vp]
+    L.lsnStreamCreate.restype = vp
+    L.lsnStreamCreate.argtypes = [C.c_int]
+    L.lsnStreamDestroy.restype = C.c_int
+    L.lsnStreamDestroy.argtypes = [C.c_int, vp]
+    L.lsnStreamSynchronize.restype = C.c_int
+    L.lsnStreamSynchronize.argtypes = [C.c_int, vp]
     L.lsnFusionPackSurvivorsRun.restype = C.c_int
     L.lsnFusionPackSurvivorsRun.argtypes = [vp] * 10
     L.lsnFusionReconstructRun.restype = C.c_int

@@ -36,9 +36,16 @@ class ShardedFusion:
     def __init__(self, rank, world, n_ticks, widths, heights, device, group=None):
         self.rank, self.world, self.n_ticks = rank, world, n_ticks
         self.device = torch.device(device)
-        ids = [native.shard_unique_id() if rank == 0 else None]
+        ids = [None]
+        if rank == 0:
+            try:
+                ids = [native.shard_unique_id()]
+            except native.NativeUtilsError as ex:      # e.g. librccl cannot be loaded: tell the other ranks instead of leaving them waiting
+                ids = [str(ex)]
         if world > 1:
             dist.broadcast_object_list(ids, src=0, group=group)
+        if not isinstance(ids[0], (bytes, bytearray)):
+            raise native.NativeUtilsError(f"lsnShardUniqueId failed on rank 0: {ids[0]}")
         self.shard = native.Shard(self.device.index, rank, world, ids[0], n_ticks, widths, heights)
         self.n_maps = self.shard.n_maps
         self.capacity = self.shard.capacity

@@ -70,6 +70,20 @@ def test_golden_replay_fixture_against_the_oracle(orc):
 def test_cpp_example_host_builds():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "all"], stdout=subprocess.DEVNULL)
     assert os.path.exists(os.path.join(ROOT, "examples", "replay")) and os.path.exists(os.path.join(ROOT, "examples", "stream"))
+    assert os.path.exists(os.path.join(ROOT, "examples", "shard"))
+
+
+@pytest.mark.gpu
+def test_cpp_shard_host_one_rank(gpu, tmp_path):
+    """examples/shard.cpp: one rank of the multi-GPU step from a C++ process that links nothing but libNativeUtils.so (device
+    memory, streams, the RCCL rendezvous and the step all through the C-ABI); with one rank the merged cloud must be the golden
+    fixture's vertices."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "shard"], stdout=subprocess.DEVNULL)
+    b = [str(float(x)) for x in synth.CROP_BOUNDS]
+    out = subprocess.run([os.path.join(ROOT, "examples", "shard"), os.path.join(GOLD, "replay_scene_2x96x80.bin"), "--rank", "0", "--world", "1",
+                          "--device", "0", "--id-file", str(tmp_path / "id.bin"), "--bounds", *b,
+                          "--expect", os.path.join(GOLD, "replay_scene_2x96x80_mesh.bin")], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and "Test PASSED" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu
