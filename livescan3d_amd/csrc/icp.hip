@@ -66,6 +66,11 @@ struct IcpState {
     float Rn[9];
     float mean, stddev, thresh;
     int m, mk;
+    // warm start of the next iteration's Jacobi SVD: the right singular vectors of this iteration's cross-covariance (the
+    // clouds barely move between iterations, so the next matrix is almost diagonalised by them); v_valid is cleared at the
+    // start of every lsnIcpRun, which keeps a call's result independent of what the workspace ran before
+    int v_valid;
+    double Vprev[9];
 };
 
 // ---- small helpers ------------------------------------------------------------------------------------------
@@ -115,17 +120,44 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double *lds /* [4*N
     __syncthreads();
 }
 
-// Deterministic sum of n_parts partial vectors (stride NV) by one workgroup; result valid in every thread.
-template <int NV>
-__device__ __forceinline__ void reduce_partials(const double *parts, int n_parts, double (&out)[NV], double *lds)
+// Deterministic sum of n_parts partial vectors (stride NVP, a power of two >= NV) by one workgroup; result valid in every
+// thread.  Thread t sums component t % NVP of the partials t / NVP, t / NVP + G, ... (G = kThreads / NVP groups; NVP
+// consecutive threads read one partial: coalesced, all loads independent), the G group sums meet in LDS and thread c adds
+// those of component c in a fixed order.  (One partial vector per thread and a shuffle tree over 16 doubles took 5.8 us in
+// solve_kernel and in EVERY workgroup of accum_kernel: strided loads, 192 dependent cross-lane moves.)
+template <int NV, int NVP>
+__device__ __forceinline__ void reduce_partials(const double *parts, int n_parts, double (&out)[NV], double *lds /* [kThreads + NVP] */)
 {
-#pragma unroll
-    for (int i = 0; i < NV; i++) out[i] = 0;
-    for (int b = threadIdx.x; b < n_parts; b += kThreads) {
-#pragma unroll
-        for (int i = 0; i < NV; i++) out[i] += parts[(size_t)b * NV + i];
+    constexpr int G = kThreads / NVP;
+    const int c = threadIdx.x & (NVP - 1), g = threadIdx.x / NVP;
+    // eight loads in flight per thread (a plain loop would wait for each load before issuing the next: n_parts / G round trips)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    int p = g;
+    for (; p + 7 * G < n_parts; p += 8 * G) {
+        const double v0 = parts[(size_t)p * NVP + c], v1 = parts[(size_t)(p + G) * NVP + c], v2 = parts[(size_t)(p + 2 * G) * NVP + c],
+                     v3 = parts[(size_t)(p + 3 * G) * NVP + c], v4 = parts[(size_t)(p + 4 * G) * NVP + c], v5 = parts[(size_t)(p + 5 * G) * NVP + c],
+                     v6 = parts[(size_t)(p + 6 * G) * NVP + c], v7 = parts[(size_t)(p + 7 * G) * NVP + c];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3; a4 += v4; a5 += v5; a6 += v6; a7 += v7;
     }
-    block_sum_d<NV>(out, lds);
+    {   // the tail, predicated: still eight independent loads
+        const double v0 = p < n_parts ? parts[(size_t)p * NVP + c] : 0.0, v1 = p + G < n_parts ? parts[(size_t)(p + G) * NVP + c] : 0.0;
+        const double v2 = p + 2 * G < n_parts ? parts[(size_t)(p + 2 * G) * NVP + c] : 0.0, v3 = p + 3 * G < n_parts ? parts[(size_t)(p + 3 * G) * NVP + c] : 0.0;
+        const double v4 = p + 4 * G < n_parts ? parts[(size_t)(p + 4 * G) * NVP + c] : 0.0, v5 = p + 5 * G < n_parts ? parts[(size_t)(p + 5 * G) * NVP + c] : 0.0;
+        const double v6 = p + 6 * G < n_parts ? parts[(size_t)(p + 6 * G) * NVP + c] : 0.0;
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3; a4 += v4; a5 += v5; a6 += v6;
+    }
+    const double acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    lds[threadIdx.x] = acc;  // [g][c]
+    __syncthreads();
+    if (threadIdx.x < NVP) {
+        double t = 0;
+        for (int k = 0; k < G; k++) t += lds[k * NVP + threadIdx.x];
+        lds[kThreads + threadIdx.x] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) out[i] = lds[kThreads + i];
+    __syncthreads();
 }
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int n)
@@ -442,14 +474,6 @@ __device__ __forceinline__ f4v dist2x4(f2v qx, f2v qy, f2v qz, f4v X, f4v Y, f4v
     return d;
 }
 
-__device__ __forceinline__ void lex_update(float d, int k, float &best, int &best_i)
-{
-    if (d < best || (d == best && k < best_i)) {
-        best = d;
-        best_i = k;
-    }
-}
-
 __device__ __forceinline__ void scan_batch(const float4 &p, int cnt, WaveStage &st, int lane, f2v qx2, f2v qy2, f2v qz2, float &best, int &best_i)
 {
     st.x[lane] = p.x;
@@ -464,16 +488,17 @@ __device__ __forceinline__ void scan_batch(const float4 &p, int cnt, WaveStage &
                               *reinterpret_cast<const f4v *>(&st.z[t + 4]));
         const float m = fminf(fminf(fminf(d.x, d.y), fminf(d.z, d.w)), fminf(fminf(e.x, e.y), fminf(e.z, e.w)));  // fminf skips NaN
         if (__ballot(m <= best)) {                                                                                 // wave-uniform branch
+            // some lane is improved or tied: the step's candidate of a lane is (m, lowest index among its points at distance m),
+            // branch-free (16 compares / selects and a min tree instead of eight conditional updates)
             const i4v K = *reinterpret_cast<const i4v *>(&st.i[t]);
             const i4v L = *reinterpret_cast<const i4v *>(&st.i[t + 4]);
-            lex_update(d.x, K.x, best, best_i);
-            lex_update(d.y, K.y, best, best_i);
-            lex_update(d.z, K.z, best, best_i);
-            lex_update(d.w, K.w, best, best_i);
-            lex_update(e.x, L.x, best, best_i);
-            lex_update(e.y, L.y, best, best_i);
-            lex_update(e.z, L.z, best, best_i);
-            lex_update(e.w, L.w, best, best_i);
+            const int none = 0x7FFFFFFF;
+            const int k0 = d.x == m ? K.x : none, k1 = d.y == m ? K.y : none, k2 = d.z == m ? K.z : none, k3 = d.w == m ? K.w : none;
+            const int k4 = e.x == m ? L.x : none, k5 = e.y == m ? L.y : none, k6 = e.z == m ? L.z : none, k7 = e.w == m ? L.w : none;
+            const int km = min(min(min(k0, k1), min(k2, k3)), min(min(k4, k5), min(k6, k7)));
+            const bool take = (m < best) | ((m == best) & (km < best_i));
+            best = take ? m : best;
+            best_i = take ? km : best_i;
         }
     }
     wave_lds_fence();
@@ -1006,7 +1031,7 @@ __device__ __forceinline__ bool is_winner(const unsigned long long *keys, const 
 
 // pass 1: m = number of one-to-one matches, the sum of their squared distances and the sum of the squares of those
 __global__ __launch_bounds__(kThreads) void stats_kernel(const int *idx, const float *dist, const unsigned long long *keys, int n2,
-                                                         double *part /* [blocks][3] */)
+                                                         double *part /* [blocks][4]: count, sum d, sum d^2, - */)
 {
     __shared__ double lds[4 * 3];
     double v[3] = {0, 0, 0};
@@ -1023,7 +1048,7 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(const int *idx, const f
         double out = v[0];
         if (threadIdx.x == 1) out = v[1];
         if (threadIdx.x == 2) out = v[2];
-        part[blockIdx.x * 3 + threadIdx.x] = out;
+        part[blockIdx.x * 4 + threadIdx.x] = out;
     }
 }
 
@@ -1037,8 +1062,9 @@ __global__ __launch_bounds__(kThreads) void accum_kernel(const float *verts1, co
                                                          double *part /* [blocks][16] */, IcpState *st)
 {
     __shared__ double lds[4 * 16];
+    __shared__ double red[kThreads + 4];
     double s1[3];
-    reduce_partials<3>(part1, n_part1, s1, lds);
+    reduce_partials<3, 4>(part1, n_part1, s1, red);
     const float mean = (float)(s1[1] / s1[0]);
     const float m_f = (float)(int)s1[0];
     const double dev = s1[2] - 2.0 * (double)mean * s1[1] + s1[0] * (double)mean * (double)mean;
@@ -1080,10 +1106,17 @@ __global__ __launch_bounds__(kThreads) void accum_kernel(const float *verts1, co
 }
 
 // 3x3 SVD by one-sided Jacobi (double).  A = U diag(w) V^T, singular values sorted descending.
-__device__ void svd3(const double A[9], double U[9], double w[3], double V[9])
+// V0 (nullable): an orthonormal matrix to start from (B = A V0): any orthonormal start gives the same decomposition up to
+// rounding; a good one saves sweeps.
+__device__ void svd3(const double A[9], double U[9], double w[3], double V[9], const double *V0)
 {
     double B[9];
     for (int i = 0; i < 9; i++) { B[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    if (V0) {
+        for (int i = 0; i < 9; i++) V[i] = V0[i];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) B[3 * r + c] = A[3 * r] * V0[c] + A[3 * r + 1] * V0[3 + c] + A[3 * r + 2] * V0[6 + c];
+    }
     for (int sweep = 0; sweep < 60; sweep++) {
         int rotations = 0;
         for (int p = 0; p < 2; p++)
@@ -1162,9 +1195,9 @@ __device__ void svd3(const double A[9], double U[9], double w[3], double V[9])
 __global__ __launch_bounds__(kThreads) void solve_kernel(const double *part3, int n_part3, float *R, float *t, IcpState *st, float *trace,
                                                          int iter)
 {
-    __shared__ double lds[4 * 16];
+    __shared__ double red[kThreads + 16];
     double s[16];
-    reduce_partials<16>(part3, n_part3, s, lds);
+    reduce_partials<16, 16>(part3, n_part3, s, red);
     if (threadIdx.x != 0) return;
     const int mk = (int)s[0];
     st->mk = mk;
@@ -1177,7 +1210,9 @@ __global__ __launch_bounds__(kThreads) void solve_kernel(const double *part3, in
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) M[3 * a + b] = (double)(float)(s[7 + 3 * a + b] + (double)T[a] * s[1 + b]);
         double U[9], w[3], V[9];
-        svd3(M, U, w, V);
+        svd3(M, U, w, V, st->v_valid == 1 ? st->Vprev : nullptr);
+        for (int i = 0; i < 9; i++) st->Vprev[i] = V[i];
+        st->v_valid = 1;
         float Uf[9], Vtf[9];
         for (int r = 0; r < 3; r++)
             for (int c = 0; c < 3; c++) {
@@ -1329,7 +1364,7 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
         bad |= w->list_a.reserve(sizeof(uint2) * (size_t)w->seg_a * kSegs) != 0;
         bad |= w->list_b.reserve(sizeof(int4) * (size_t)w->seg_b * kSegs) != 0;
     }
-    bad |= w->part1.reserve(sizeof(double) * 3 * kMaxBlocks) != 0;
+    bad |= w->part1.reserve(sizeof(double) * 4 * kMaxBlocks) != 0;
     bad |= w->part3.reserve(sizeof(double) * 16 * kMaxBlocks) != 0;
     bad |= w->state.reserve(sizeof(IcpState)) != 0;
     bad |= w->trace.reserve(sizeof(float) * 16 * kTraceCap) != 0;
@@ -1550,6 +1585,7 @@ extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_vert
     IcpState *st = w->state.as<IcpState>();
     LSN_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)n1, s));
     LSN_HIP(hipMemsetAsync(w->counters.p, 0, sizeof(int) * 2 * kBankInts, s));
+    LSN_HIP(hipMemsetAsync(&st->v_valid, 0, sizeof(int), s));   // the first iteration's SVD starts cold
     for (int iter = 0; iter < maxIter; iter++) {
         // from the second iteration on idx[] still holds every query's previous neighbour: the search is seeded with it, and
         // its first launch also carries out the previous iteration's motion and clears the match keys
