@@ -1285,6 +1285,7 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(float4 *src, float *ver
 // One voxel grid over a cloud: the cell-sorted copy (x, y, z, original index) and, for a target, the box hierarchy.
 struct GridBufs {
     lsn::DevBuf gp, cell_of, cell_cnt, cell_start, sorted, boxes, supers;
+    bool counts_clear = false;   // cell_cnt is all zero (cell_scatter_kernel runs every count back down to zero: one memset per workspace, not per build)
     int reserve(int max_n, bool with_boxes)
     {
         int bad = 0;
@@ -1434,7 +1435,8 @@ static int build_grid(LsnIcp *w, GridBufs &g, const float *d_pts, int n, bool wi
     GridParams *gp = g.gp.as<GridParams>();
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kThreads), 0, s, d_pts, n, w->bbox_part.as<float>());
     hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, s, w->bbox_part.as<float>(), nb, n, w->cell_override, gp);
-    LSN_HIP(hipMemsetAsync(g.cell_cnt.p, 0, sizeof(int) * (size_t)kMaxCells, s));
+    if (!g.counts_clear) LSN_HIP(hipMemsetAsync(g.cell_cnt.p, 0, sizeof(int) * (size_t)kMaxCells, s));
+    g.counts_clear = false;   // dirty until the scatter below has been enqueued
     hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(kThreads), 0, s, d_pts, n, gp, g.cell_of.as<int>(), g.cell_cnt.as<int>());
     const int sb = kMaxCells / kScanBlock;  // 1024
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sb), dim3(kThreads), 0, s, g.cell_cnt.as<int>(), gp, w->block_sums.as<int>());
@@ -1443,6 +1445,8 @@ static int build_grid(LsnIcp *w, GridBufs &g, const float *d_pts, int n, bool wi
                        g.cell_start.as<int>());
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(kThreads), 0, s, d_pts, n, g.cell_of.as<int>(), g.cell_start.as<int>(),
                        g.cell_cnt.as<int>(), g.sorted.as<float4>());
+    LSN_HIP(hipGetLastError());   // (a failed launch leaves counts_clear false: the next build clears them again)
+    g.counts_clear = true;
     if (with_boxes) {
         hipLaunchKernelGGL(block_box_kernel, dim3(2048), dim3(kThreads), 0, s, (const GridParams *)gp, (const int *)g.cell_start.as<int>(),
                            (const float4 *)g.sorted.as<float4>(), g.boxes.as<Box>());
