@@ -53,6 +53,9 @@ def test_nn_matches_oracle_bitexact(gpu, orc, mode):
         (np.repeat(rng.uniform(-1, 1, size=(50, 3)).astype(np.float32), 4, axis=0), rng.uniform(-1, 1, size=(300, 3)).astype(np.float32)),  # duplicated targets: ties -> lowest index
         ((rng.uniform(0, 1, size=(4000, 3)) * [1, 1, 0]).astype(np.float32), rng.uniform(-0.5, 1.5, size=(1500, 3)).astype(np.float32)),  # flat cloud (zero extent in z)
     ]
+    for n2 in (63, 64, 65, 128, 129):                                    # query counts around the 64-query group size
+        cases.append((rng.uniform(-1, 1, size=(777, 3)).astype(np.float32), rng.uniform(-1.1, 1.1, size=(n2, 3)).astype(np.float32)))
+    cases.append((np.full((300, 3), 0.25, np.float32), rng.uniform(-1, 1, size=(200, 3)).astype(np.float32)))   # every target the same point
     for k, (t, q) in enumerate(cases):
         want_i, want_d = orc.nn(t, q, mode="brute", n_threads=8)
         got_i, got_d = _gpu_nn(t, q, mode)
