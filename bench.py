@@ -263,6 +263,10 @@ def main():
                 "parallelism": f"sensor-shard{world}" + (("+allgather(survivors; lsnShard* = C++ host glue + RCCL inside the library)" if use_shard else
                                                           "+allgather(survivors; Python over torch.distributed)" if use_sx else "+allgather(vertices)") if multi else ""),
                 "bounds": [float(x) for x in bounds],
+                "parity": "outputs bit-identical to the CPU restatement of the reference (tests/, -m gpu); that restatement is PARITY UNPINNED for "
+                          "the depth -> cloud path, the radial correction and the non-NN part of ICP (the reference ships no fixtures and "
+                          "depthprocessing.cpp / icp.cpp cannot be built here without stand-ins); nearest neighbour and triangulation are "
+                          "pinned to the reference's own code (oracle/_ref, tests/golden)",
             },
             "roofline": {
                 "bound": "hbm",
