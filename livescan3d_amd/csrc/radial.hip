@@ -122,9 +122,10 @@ __global__ __launch_bounds__(kThreads) void radial_cand_sort_kernel(uint4 *cand,
     cand[i] = c;
 }
 
-__global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const FrameDesc *frames, const TileDesc *tiles, const unsigned short *depth,
-                                                                      const unsigned char *rgb, const uint4 *cand, unsigned short *map_copy,
-                                                                      unsigned char *colors_copy, int tiles_per_tick, long long tick_pix_stride)
+__global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const FrameDesc *__restrict__ frames, const TileDesc *__restrict__ tiles,
+                                                                      const unsigned short *__restrict__ depth, const unsigned char *__restrict__ rgb,
+                                                                      const uint4 *__restrict__ cand, unsigned short *__restrict__ map_copy,
+                                                                      unsigned char *__restrict__ colors_copy, int tiles_per_tick, long long tick_pix_stride)
 {
     const int tick = blockIdx.x / tiles_per_tick;
     const int tile = blockIdx.x - tick * tiles_per_tick;
@@ -132,28 +133,54 @@ __global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const Fram
     const FrameDesc fd = frames[td.frame];
     const long long fb = tick * tick_pix_stride + fd.depth_off;
     const int p0 = (tile - fd.tile_start) * kTile;
-    for (int i = threadIdx.x; i < kTile; i += kThreads) {
-        const int p = p0 + i;
-        if (p >= fd.npix) break;
-        const uint4 c = cand[fd.depth_off + p];
-        // all four candidate depths are fetched at once (independent loads); the first non-zero one wins
-        const unsigned short d0 = c.x ? depth[fb + (c.x - 1u)] : 0, d1 = c.y ? depth[fb + (c.y - 1u)] : 0;
-        const unsigned short d2 = c.z ? depth[fb + (c.z - 1u)] : 0, d3 = c.w ? depth[fb + (c.w - 1u)] : 0;
-        unsigned int src = 0;
-        unsigned short d = 0;
-        if (d0) { src = c.x; d = d0; }
-        else if (d1) { src = c.y; d = d1; }
-        else if (d2) { src = c.z; d = d2; }
-        else if (d3) { src = c.w; d = d3; }
-        unsigned char c0 = 0, c1 = 0, c2 = 0;
-        if (src) {
-            const long long sidx = fb + (long long)(src - 1u);
-            c0 = rgb[3 * sidx]; c1 = rgb[3 * sidx + 1]; c2 = rgb[3 * sidx + 2];
+    // A pixel is a chain of three dependent loads (candidates -> their depths -> the winner's colour); the kernel is bound by
+    // that latency (PMC: 87 % of the wave-cycles waiting), so a thread keeps FOUR pixels in flight: all candidate loads, then
+    // all depth loads, then all colour loads (the restrict qualifiers let the compiler keep them that way).
+    constexpr int kFly = 4;
+    for (int i0 = threadIdx.x; i0 < kTile; i0 += kFly * kThreads) {
+        uint4 c[kFly];
+        bool in[kFly];
+#pragma unroll
+        for (int k = 0; k < kFly; k++) {
+            const int p = p0 + i0 + k * kThreads;
+            in[k] = i0 + k * kThreads < kTile && p < fd.npix;
+            c[k] = in[k] ? cand[fd.depth_off + p] : make_uint4(0, 0, 0, 0);
         }
-        map_copy[fb + p] = d;
-        colors_copy[3 * (fb + p)] = c0;
-        colors_copy[3 * (fb + p) + 1] = c1;
-        colors_copy[3 * (fb + p) + 2] = c2;
+        unsigned short d0[kFly], d1[kFly], d2[kFly], d3[kFly];
+#pragma unroll
+        for (int k = 0; k < kFly; k++) {
+            // all four candidate depths are fetched at once (independent loads); the first non-zero one wins
+            d0[k] = c[k].x ? depth[fb + (c[k].x - 1u)] : 0;
+            d1[k] = c[k].y ? depth[fb + (c[k].y - 1u)] : 0;
+            d2[k] = c[k].z ? depth[fb + (c[k].z - 1u)] : 0;
+            d3[k] = c[k].w ? depth[fb + (c[k].w - 1u)] : 0;
+        }
+        unsigned int src[kFly];
+        unsigned short d[kFly];
+        unsigned char r0[kFly], r1[kFly], r2[kFly];
+#pragma unroll
+        for (int k = 0; k < kFly; k++) {
+            src[k] = 0;
+            d[k] = 0;
+            if (d0[k]) { src[k] = c[k].x; d[k] = d0[k]; }
+            else if (d1[k]) { src[k] = c[k].y; d[k] = d1[k]; }
+            else if (d2[k]) { src[k] = c[k].z; d[k] = d2[k]; }
+            else if (d3[k]) { src[k] = c[k].w; d[k] = d3[k]; }
+            r0[k] = r1[k] = r2[k] = 0;
+            if (src[k]) {
+                const long long sidx = fb + (long long)(src[k] - 1u);
+                r0[k] = rgb[3 * sidx]; r1[k] = rgb[3 * sidx + 1]; r2[k] = rgb[3 * sidx + 2];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kFly; k++) {
+            if (!in[k]) continue;
+            const long long q = fb + p0 + i0 + k * kThreads;
+            map_copy[q] = d[k];
+            colors_copy[3 * q] = r0[k];
+            colors_copy[3 * q + 1] = r1[k];
+            colors_copy[3 * q + 2] = r2[k];
+        }
     }
 }
 
