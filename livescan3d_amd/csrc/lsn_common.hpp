@@ -85,6 +85,7 @@ int run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_ve
 int pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c, int *d_tile_prefix,
                    int *d_offsets, int *d_tick_base, void *stream);
 int reconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c, const void *d_rgb_c, long long slab,
-                const int *d_tile_prefix, const int *d_shard_offsets, void *d_merged, int *d_merged_offsets, int *d_tick_base, void *stream);
+                const int *d_tile_prefix, const int *d_shard_offsets, void *d_merged, int *d_merged_offsets, int *d_tick_base, void *stream,
+                int tick0 = 0, int n_chunk_ticks = 0, bool fill_tick_base = true);
 
 }  // namespace lsn

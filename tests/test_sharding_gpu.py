@@ -199,10 +199,11 @@ def test_rccl_survivor_exchange_world1(gpu, tmp_path):
     assert open(out).read() == "ok"
 
 
-def _shard_worker(rank, padded, out):
+def _shard_worker(rank, padded, chunks, out):
     sys.path.insert(0, ROOT)
     if padded:
         os.environ["LSN_SHARD_PADDED"] = "1"
+    os.environ["LSN_SHARD_CHUNKS"] = str(chunks)
     import numpy as np
     import torch
     from livescan3d_amd import synth
@@ -240,13 +241,14 @@ def _shard_worker(rank, padded, out):
         f.write("ok" if ok else "mismatch")
 
 
-@pytest.mark.parametrize("padded", [False, True])
-def test_shard_exports_rccl_world1(gpu, tmp_path, padded):
+@pytest.mark.parametrize("padded,chunks", [(False, 1), (False, 3), (False, 2), (True, 1)])
+def test_shard_exports_rccl_world1(gpu, tmp_path, padded, chunks):
     """lsnShardUniqueId / lsnShardCreate / lsnShardSetParams / lsnShardStep: the multi-GPU step behind the C-ABI (C++ host glue +
     RCCL inside libNativeUtils.so, no torch.distributed) with a communicator of one rank: pack, the grouped all-gathers, the
     pinned read-back of the offset tables (or none with $LSN_SHARD_PADDED=1) and the reconstruction must give exactly what a
-    single-plan fusion and the oracle give."""
+    single-plan fusion and the oracle give.  chunks > 1: the streams travel in groups of ticks on a second stream while the
+    previous group is reconstructed (the default with more than one rank)."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
-    mp.spawn(_shard_worker, args=(padded, out), nprocs=1, join=True)
+    mp.spawn(_shard_worker, args=(padded, chunks, out), nprocs=1, join=True)
     assert open(out).read() == "ok"
