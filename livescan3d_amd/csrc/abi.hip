@@ -327,8 +327,12 @@ void empty_mesh(Ctx &c, Mesh *m)
 // The cached single-tick plan for sensors [first, first + count) of a call.  c.mu held.
 LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, int count)
 {
+    // `first` is part of the key: generateVerticesFromDepthMap is called for sensor 0, 1, ... in turn (KinectServer.cs:527-554) and every
+    // sensor keeps its own plan, so its calibration stays set (no parameter upload, no table rebuild per call) and its count pass
+    // can run from the per-pixel depth thresholds from the second round on
     std::vector<int> key;
     key.push_back(count);
+    key.push_back(first);
     for (int i = 0; i < count; i++) key.push_back(widths[first + i]);
     for (int i = 0; i < count; i++) key.push_back(heights[first + i]);
     auto it = c.plans.find(key);
@@ -381,15 +385,19 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
     (void)host_range_pinned(c, depth_maps, total_d, with_triangles);
     (void)host_range_pinned(c, depth_colors, total_c, with_triangles);
 
-    // depth first (the count pass needs nothing else), colours behind it on the same upload stream
-    LSN_HIP(hipMemcpyAsync(c.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, c.up));
-    LSN_HIP(hipEventRecord(c.ev_depth, c.up));
-    LSN_HIP(hipMemcpyAsync(c.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, c.up));
-    LSN_HIP(hipEventRecord(c.ev_col, c.up));
+    // A small call (one sensor: ~1 MB up, ~2 MB down) is all fixed latency: every hand-over between streams costs more than the
+    // overlap could win, so it runs on ONE stream.  A big call goes depth first (the count pass needs nothing else), colours
+    // behind it on the upload stream, kernels on the main stream, vertices home on the download stream.
+    const bool small = dbytes + cbytes < ((size_t)4 << 20);
+    hipStream_t up = small ? c.stream : c.up, down = small ? c.stream : c.down;
+    LSN_HIP(hipMemcpyAsync(c.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, up));
+    if (!small) LSN_HIP(hipEventRecord(c.ev_depth, up));
+    LSN_HIP(hipMemcpyAsync(c.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, up));
+    if (!small) LSN_HIP(hipEventRecord(c.ev_col, up));
     if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, c.stream)) return -1;
-    LSN_HIP(hipStreamWaitEvent(c.stream, c.ev_depth, 0));
+    if (!small) LSN_HIP(hipStreamWaitEvent(c.stream, c.ev_depth, 0));
     lsn::RunHooks hooks;
-    hooks.colours_ready = c.ev_col;
+    hooks.colours_ready = small ? nullptr : c.ev_col;
     hooks.h_offsets = c.h_off;
     hooks.counted = c.ev_counted;
     hooks.written = c.ev_written;
@@ -415,8 +423,8 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
     if (!host) return -1;
     if (nv > 0) {
         // the vertices leave on their own stream as soon as the write pass is done
-        if (hipStreamWaitEvent(c.down, c.ev_written, 0) != hipSuccess ||
-            hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, c.down) != hipSuccess) {
+        if ((!small && hipStreamWaitEvent(down, c.ev_written, 0) != hipSuccess) ||
+            hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, down) != hipSuccess) {
             lsn::set_error("NativeUtils: vertex download failed: %s", hipGetErrorString(hipGetLastError()));
             drain(c);
             pinned_put(c, host);
