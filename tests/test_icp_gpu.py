@@ -134,6 +134,20 @@ def test_nn_non_finite_points_do_not_derail_the_search(gpu, orc):
         assert ((got_i >= 0) & (got_i < len(t))).all()
 
 
+def test_nn_large_clouds(gpu, orc):
+    """2 sensors x 1024x1024 (configs[4]'s frame size): half a million points per cloud -- grid NN == oracle kd-tree NN, bit-exact,
+    and one ICP call stays inside the tolerance."""
+    clouds = _scene_clouds(orc, 2, 1024, 1024)
+    assert min(len(c) for c in clouds) > 300000
+    want_i, want_d = orc.nn(clouds[0], clouds[1], mode="kdtree", n_threads=8)
+    got_i, got_d = _gpu_nn(clouds[0], clouds[1], native.NN_GRID)
+    assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
+    assert np.array_equal(got_i, want_i)
+    got_v, got_R, got_t = native.icp(clouds[0], clouds[1], max_iter=3)
+    ref_v, ref_R, ref_t = orc.icp(clouds[0], clouds[1], max_iter=3, n_threads=8)
+    assert np.abs(got_v - ref_v).max() <= TOL and np.abs(got_R - ref_R).max() <= TOL and np.abs(got_t - ref_t).max() <= TOL
+
+
 def test_nn_full_size(gpu, orc):
     """config-2 sized clouds (2 x 512x424): grid NN == oracle kd-tree NN, bit-exact."""
     clouds = _scene_clouds(orc, 2, 512, 424)
