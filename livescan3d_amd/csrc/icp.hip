@@ -803,7 +803,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *v
     unsigned long long key = kNoKey;
     if (seed_targets) {
         if (part) {
-            const int k = idx[orig];
+            const int k = idx[j];   // the sorted-order copy of the previous neighbours (nn_finish_kernel): loaded together with src[j]
             if ((unsigned int)k < (unsigned int)n1) {
                 const float d = dist2(qx, qy, qz, seed_targets[3 * (size_t)k], seed_targets[3 * (size_t)k + 1], seed_targets[3 * (size_t)k + 2]);
                 if (d == d) key = pack_key(d, k);  // not NaN
@@ -823,13 +823,27 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *v
     if (!(gi.rmax >= 0.0f)) return;
     const int n_supers = gp->ncells / 4096;
     int *cnt = wk.counters + kBankInts * bank;
-    // two passes over the super-block boxes (count, then write) so that the append costs the wave ONE atomicAdd
+    // two passes over the super-block boxes (count, then write) so that the append costs the wave ONE atomicAdd; the boxes of
+    // four chunks (256 super-blocks) are loaded at once: one memory round trip per four chunks instead of one per chunk
+    auto chunk_dist = [&](int c0, float (&m)[4]) {
+        Box b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int sl = c0 + 64 * k + lane;
+            if (sl < n_supers) b[k] = supers[sl];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int sl = c0 + 64 * k + lane;
+            m[k] = sl < n_supers ? boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, b[k]) : INFINITY;
+        }
+    };
     int total = 0;
-    for (int c0 = 0; c0 < n_supers; c0 += 64) {
-        const int sl = c0 + lane;
-        float m = INFINITY;
-        if (sl < n_supers) m = boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, supers[sl]);
-        total += __popcll(__ballot(m <= gi.rmax && m < INFINITY));
+    for (int c0 = 0; c0 < n_supers; c0 += 256) {
+        float m[4];
+        chunk_dist(c0, m);
+#pragma unroll
+        for (int k = 0; k < 4; k++) total += __popcll(__ballot(m[k] <= gi.rmax && m[k] < INFINITY));
     }
     if (total == 0) return;
     const int seg = g & (kSegs - 1);
@@ -841,14 +855,16 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *v
         return;
     }
     uint2 *out = wk.list_a + (size_t)seg * wk.seg_a + base;
-    for (int c0 = 0; c0 < n_supers; c0 += 64) {
-        const int sl = c0 + lane;
-        float m = INFINITY;
-        if (sl < n_supers) m = boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, supers[sl]);
-        const bool open = m <= gi.rmax && m < INFINITY;
-        const unsigned long long mask = __ballot(open);
-        if (open) out[__popcll(mask & ((1ull << lane) - 1))] = make_uint2((unsigned int)g, (unsigned int)sl);
-        out += __popcll(mask);
+    for (int c0 = 0; c0 < n_supers; c0 += 256) {
+        float m[4];
+        chunk_dist(c0, m);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool open = m[k] <= gi.rmax && m[k] < INFINITY;
+            const unsigned long long mask = __ballot(open);
+            if (open) out[__popcll(mask & ((1ull << lane) - 1))] = make_uint2((unsigned int)g, (unsigned int)(c0 + 64 * k + lane));
+            out += __popcll(mask);
+        }
     }
 }
 
@@ -933,7 +949,7 @@ __global__ __launch_bounds__(64) void nn_scan_kernel(const float4 *__restrict__ 
 __global__ __launch_bounds__(kThreads) void nn_finish_kernel(const float4 *__restrict__ src, int n2, const GridParams *__restrict__ gp,
                                                              const float4 *__restrict__ sorted, const Box *__restrict__ boxes,
                                                              const Box *__restrict__ supers, const unsigned long long *best_key, int *idx,
-                                                             float *dist, unsigned long long *keys, NnWork wk, int bank)
+                                                             float *dist, int *idx_sorted, unsigned long long *keys, NnWork wk, int bank)
 {
     __shared__ WaveStage s_stage[kThreads / 64];
     __shared__ int s_claim_k[kClaimSlots];
@@ -960,6 +976,7 @@ __global__ __launch_bounds__(kThreads) void nn_finish_kernel(const float4 *__res
         if (best_i == 0x7FFFFFFF) best_i = 0;  // nothing comparable (NaN everywhere): keep the index in range
         idx[orig] = best_i;
         dist[orig] = best;
+        if (idx_sorted) idx_sorted[j] = best_i;   // the next iteration's seeds, where nn_cull_kernel reads them with the queries
     }
     if (keys) claim_targets(keys, active, best_i, best, orig, s_claim_k, s_claim_v);
 }
@@ -1309,7 +1326,7 @@ struct LsnIcp {
     GridBufs tgt, src;    // tgt: cell-sorted target + boxes; src.sorted: the spatially sorted working copy of the source
     lsn::DevBuf bbox_part, block_sums;
     lsn::DevBuf idx, dist, keys, counters, part1, part3, state, trace;
-    lsn::DevBuf best_key, groups, list_a, list_b;   // the NN step's per-query keys, per-group boxes and work lists
+    lsn::DevBuf best_key, groups, list_a, list_b, idx_sorted;   // the NN step's per-query keys, per-group boxes and work lists
     int seg_a = 0, seg_b = 0;   // capacity of one list segment
     int item_points = 128;      // points per scan item; $LSN_ICP_ITEM (tuning): 64, 128, 192 or 256.  128 instead of 256: 0.094 -> 0.089 ms/iteration (configs[1])
     // optional phase timing of lsnIcpRun (lsnIcpSetProfiling): HIP events on the caller's stream around
@@ -1361,6 +1378,7 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
         w->seg_a = tiny ? 2 : 1024 + n_groups / 4;   // x 64 segments: 64 k + 16 per group
         w->seg_b = tiny ? 2 : 8192 + 2 * n_groups;   // x 64 segments: 512 k + 128 per group
         bad |= w->best_key.reserve(sizeof(unsigned long long) * (size_t)max_n2) != 0;
+        bad |= w->idx_sorted.reserve(sizeof(int) * (size_t)max_n2) != 0;
         bad |= w->groups.reserve(sizeof(GroupInfo) * (size_t)n_groups) != 0;
         bad |= w->list_a.reserve(sizeof(uint2) * (size_t)w->seg_a * kSegs) != 0;
         bad |= w->list_b.reserve(sizeof(int4) * (size_t)w->seg_b * kSegs) != 0;
@@ -1496,7 +1514,7 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
     const dim3 blocks_grid(64 * ((6 * n_groups + 63) / 64)), scan_grid(64 * ((8 * n_groups + 63) / 64));
     if (seeded) {
         hipLaunchKernelGGL(nn_cull_kernel<true>, per_group, dim3(kThreads), 0, s, src, d_verts2, n2, st, keys, n1, gp, supers, d_verts1, n1,
-                           (const int *)d_idx, best_key, groups, wk, bank);
+                           (const int *)w->idx_sorted.as<int>(), best_key, groups, wk, bank);
     } else {
         hipLaunchKernelGGL(nn_seedless_kernel, per_group, dim3(kThreads), 0, s, (const float4 *)src, n2, gp, boxes, supers, best_key, wk, bank);
         hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(64), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntSeed);
@@ -1507,7 +1525,7 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
                        (const unsigned long long *)best_key, (const GroupInfo *)groups, wk, bank);
     hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(64), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntB);
     hipLaunchKernelGGL(nn_finish_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, (const float4 *)src, n2, gp, sorted, boxes, supers,
-                       (const unsigned long long *)best_key, d_idx, d_dist, keys, wk, bank);
+                       (const unsigned long long *)best_key, d_idx, d_dist, keys ? w->idx_sorted.as<int>() : (int *)nullptr, keys, wk, bank);
     LSN_HIP(hipGetLastError());
     static const bool debug = getenv("LSN_ICP_DEBUG") != nullptr;   // dev aid: synchronises and prints the work-list sizes and the grid
     if (debug) {
