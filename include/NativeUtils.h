@@ -210,7 +210,10 @@ int lsnFusionReconstructRun(LsnFusion *all, int n_shards, int maps_per_shard, co
  * :1594-1608) across GPUs: rank r owns sensors [r * n_maps / world, (r + 1) * n_maps / world) of every tick (rank order =
  * sensor order); one exchange step over RCCL / xGMI (all-gathers of the survivors' inputs: 5 bytes per vertex + 1 bit per
  * pixel instead of 16 bytes per vertex) and every rank rebuilds the whole merged cloud, bit-identical to a single-GPU
- * lsnFusionRun over all sensors.  Needs identically sized sensors whose width is a multiple of 8.
+ * lsnFusionRun over all sensors.  That exchange needs identically sized sensors whose width is a multiple of 8; any other rig
+ * whose rank blocks hold the same number of pixels (or any rig with $LSN_SHARD_VERTICES=1) exchanges the 16-byte vertices
+ * instead (lsnFusionRun on the block, one all-gather per tick cut to the step's largest shard, lsnMergeShards' packing pass):
+ * the same merged cloud for about three times the bytes on the links.
  *
  * Rendezvous: rank 0 calls lsnShardUniqueId and hands the 128 bytes to the other ranks by whatever channel the host has
  * (a file, a socket, torch.distributed); every rank then calls lsnShardCreate with the same id (collective: blocks until

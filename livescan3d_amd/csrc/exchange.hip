@@ -11,6 +11,7 @@ struct MergeArgs {
     int *merged_off;         // [n_ticks][n_shards * maps_per_shard + 1]
     long long shard_cap, merged_cap;
     int n_shards, n_ticks, maps_per_shard;
+    int tick_major;          // shards laid out [n_ticks][n_shards][shard_cap] instead (what per-tick all-gathers produce)
 };
 
 __global__ __launch_bounds__(kThreads) void merge_shards_kernel(const MergeArgs a)
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(kThreads) void merge_shards_kernel(const MergeArgs 
     for (int r = 0; r < shard; r++) base += a.shard_off[((long long)r * a.n_ticks + tick) * mps1 + a.maps_per_shard];
     const int *my_off = a.shard_off + ((long long)shard * a.n_ticks + tick) * mps1;
     const int count = my_off[a.maps_per_shard];
-    const uint4 *src = a.shards + ((long long)shard * a.n_ticks + tick) * a.shard_cap;
+    const uint4 *src = a.shards + (a.tick_major ? (long long)tick * a.n_shards + shard : (long long)shard * a.n_ticks + tick) * a.shard_cap;
     uint4 *dst = a.merged + (long long)tick * a.merged_cap + base;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < count; i += gridDim.x * kThreads) {
         const uint4 v = src[i];                               // streaming stores, like the write kernel (kNontemporalStores)
@@ -370,6 +371,13 @@ extern "C" int lsnMergeShards(int device, int n_shards, int n_ticks, int maps_pe
                               const int *d_shard_offsets, void *d_merged, long long merged_cap, int *d_merged_offsets, void *stream)
 {
     lsn::clear_error();
+    return lsn::merge_shards(device, n_shards, n_ticks, maps_per_shard, d_shards, shard_cap, d_shard_offsets, d_merged, merged_cap, d_merged_offsets,
+                             false, stream);
+}
+
+int lsn::merge_shards(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap,
+                      const int *d_shard_offsets, void *d_merged, long long merged_cap, int *d_merged_offsets, bool tick_major, void *stream)
+{
     if (n_shards <= 0 || n_ticks <= 0 || maps_per_shard <= 0 || maps_per_shard >= kThreads || !d_shards || !d_shard_offsets || !d_merged ||
         !d_merged_offsets || shard_cap <= 0 || merged_cap < shard_cap) {
         lsn::set_error("lsnMergeShards: bad arguments");
@@ -390,6 +398,7 @@ extern "C" int lsnMergeShards(int device, int n_shards, int n_ticks, int maps_pe
     a.n_shards = n_shards;
     a.n_ticks = n_ticks;
     a.maps_per_shard = maps_per_shard;
+    a.tick_major = tick_major ? 1 : 0;
     long long chunks = (shard_cap + kThreads * 8 - 1) / (kThreads * 8);
     if (chunks > 256) chunks = 256;
     hipLaunchKernelGGL(merge_shards_kernel, dim3((unsigned)chunks, (unsigned)(n_shards * n_ticks)), dim3(kThreads), 0, lsn::as_stream(stream), a);
@@ -483,6 +492,11 @@ struct LsnShard {
     LsnFusion *local = nullptr, *whole = nullptr;
     ncclComm_t comm = nullptr;
     bool padded = false;                       // $LSN_SHARD_PADDED=1
+    // Rigs the survivor exchange cannot serve (sensors of different sizes, widths that are not multiples of 8) exchange the
+    // 16-byte vertices instead: lsnFusionRun on the rank's block, one all-gather per tick (all ticks in one ncclGroup) of slabs
+    // cut to the largest shard of the step, then the packing pass of lsnMergeShards.  Same merged cloud, ~3x the bytes.
+    bool vertex_mode = false;
+    lsn::DevBuf v_local, v_gathered;           // [n_ticks][cap_loc] vertices of this rank / [n_ticks][world][slab]
     long long cap_loc = 0;                     // vertices per tick of one rank's block
     int tiles_loc = 0;
     lsn::DevBuf mask, depth_c, rgb_c, offsets, tick_base;        // this rank's packed survivors
@@ -535,11 +549,21 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
         lsn::set_error("lsnShardCreate: bad arguments (rank %d of %d, %d sensors must split evenly)", rank, world, n_maps);
         return nullptr;
     }
-    for (int i = 0; i < n_maps; i++)
-        if (widths[i] != widths[0] || heights[i] != heights[0] || widths[i] % 8 != 0) {
-            lsn::set_error("lsnShardCreate: the survivor exchange needs identically sized sensors whose width is a multiple of 8");
+    bool uniform = true;
+    for (int i = 0; i < n_maps; i++) uniform = uniform && widths[i] == widths[0] && heights[i] == heights[0] && widths[i] % 8 == 0;
+    const int per_rank = n_maps / world;
+    // the vertex exchange needs equally shaped shards as well (an all-gather moves equal blocks): every rank's block must have
+    // the same pixel capacity
+    long long cap0 = 0;
+    for (int q = 0; q < world; q++) {
+        long long capq = 0;
+        for (int i = 0; i < per_rank; i++) capq += (long long)widths[q * per_rank + i] * heights[q * per_rank + i];
+        if (q == 0) cap0 = capq;
+        if (capq != cap0) {
+            lsn::set_error("lsnShardCreate: the ranks' sensor blocks must hold the same number of pixels (%lld vs %lld)", cap0, capq);
             return nullptr;
         }
+    }
     Rccl *r = rccl();
     if (!r) return nullptr;
     LSN_HIP_NULL(hipSetDevice(device));
@@ -551,6 +575,7 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
     sh->n_ticks = n_ticks;
     sh->n_maps = n_maps;
     sh->mpr = n_maps / world;
+    sh->vertex_mode = !uniform || (getenv("LSN_SHARD_VERTICES") && atoi(getenv("LSN_SHARD_VERTICES")) != 0);
     if (const char *e = getenv("LSN_SHARD_PADDED")) sh->padded = atoi(e) != 0;
     sh->chunks = world > 1 ? 4 : 1;   // nothing to overlap with one rank: its "transfer" is a local copy (measured: 0.89 ms in one shot, 0.98 in four chunks)
     if (const char *e = getenv("LSN_SHARD_CHUNKS")) sh->chunks = atoi(e);
@@ -564,6 +589,10 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
         sh->cap_loc = sh->local->cap;
         sh->tiles_loc = sh->local->tiles_per_tick;
         const size_t T = (size_t)n_ticks, W = (size_t)world, cap = (size_t)sh->cap_loc;
+        if (sh->vertex_mode) {
+            bad |= sh->v_local.reserve(T * cap * 16) != 0;
+            bad |= sh->v_gathered.reserve(W * T * cap * 16) != 0;
+        }
         bad |= sh->mask.reserve(T * cap / 8) != 0;
         // a chunk's send starts at the rank's own tick start and is as long as the LONGEST rank's chunk: room to read past the end
         const size_t chunk_cap = ((T + sh->chunks - 1) / sh->chunks) * cap + 64;
@@ -637,6 +666,39 @@ extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void 
     hipStream_t s = lsn::as_stream(stream);
     const size_t T = (size_t)sh->n_ticks, W = (size_t)sh->world, cap = (size_t)sh->cap_loc;
     const size_t off_ints = T * (sh->mpr + 1);
+    if (sh->vertex_mode) {
+        if (lsn::run_hooked(sh->local, d_depth_local, d_colors_local, sh->v_local.p, sh->offsets.as<int>(), s, nullptr)) return -1;
+        LSN_NCCL(r->AllGather(sh->offsets.p, sh->g_off.p, off_ints, ncclInt32, sh->comm, s));
+        long long slab = (long long)cap;
+        if (!sh->padded) {
+            LSN_HIP(hipMemcpyAsync(sh->h_goff, sh->g_off.p, sizeof(int) * W * off_ints, hipMemcpyDeviceToHost, s));
+            LSN_HIP(hipEventRecord(sh->ev_off, s));
+            LSN_HIP(hipEventSynchronize(sh->ev_off));
+            long long most = 1;
+            for (size_t q = 0; q < W * T; q++) {
+                const long long n = sh->h_goff[q * (sh->mpr + 1) + sh->mpr];
+                most = n > most ? n : most;
+            }
+            if (most > slab) {
+                lsn::set_error("lsnShardStep: a shard reports %lld vertices, more than its %lld pixels", most, slab);
+                return -1;
+            }
+            slab = most;
+        }
+        LSN_NCCL(r->GroupStart());
+        for (size_t k = 0; k < T; k++)
+            LSN_NCCL(r->AllGather(sh->v_local.as<uint4>() + k * cap, sh->v_gathered.as<uint4>() + k * W * (size_t)slab, (size_t)slab * 16, ncclUint8,
+                                  sh->comm, s));
+        LSN_NCCL(r->GroupEnd());
+        sh->last_slab = slab;
+        sh->last_bytes_per_rank = (long long)(sizeof(int) * off_ints + T * (size_t)slab * 16);
+        if (lsn::merge_shards(sh->device, sh->world, sh->n_ticks, sh->mpr, sh->v_gathered.p, slab, sh->g_off.as<int>(), sh->merged.p, sh->whole->cap,
+                              sh->merged_off.as<int>(), true, stream))
+            return -1;
+        if (d_merged) *d_merged = sh->merged.p;
+        if (d_merged_offsets) *d_merged_offsets = sh->merged_off.as<int>();
+        return 0;
+    }
     if (lsn::pack_survivors(sh->local, d_depth_local, d_colors_local, sh->mask.p, sh->depth_c.p, sh->rgb_c.p, nullptr, sh->offsets.as<int>(),
                             sh->tick_base.as<int>(), stream))
         return -1;

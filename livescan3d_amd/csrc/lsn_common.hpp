@@ -88,4 +88,8 @@ int reconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_
                 const int *d_tile_prefix, const int *d_shard_offsets, void *d_merged, int *d_merged_offsets, int *d_tick_base, void *stream,
                 int tick0 = 0, int n_chunk_ticks = 0, bool fill_tick_base = true);
 
+// lsnMergeShards, optionally for shards laid out [n_ticks][n_shards][shard_cap] (per-tick all-gathers).
+int merge_shards(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap, const int *d_shard_offsets,
+                 void *d_merged, long long merged_cap, int *d_merged_offsets, bool tick_major, void *stream);
+
 }  // namespace lsn

@@ -254,6 +254,61 @@ def test_shard_exports_rccl_world1(gpu, tmp_path, padded, chunks):
     assert open(out).read() == "ok"
 
 
+def _shard_worker_ragged(rank, padded, out):
+    sys.path.insert(0, ROOT)
+    if padded:
+        os.environ["LSN_SHARD_PADDED"] = "1"
+    import numpy as np
+    import torch
+    from livescan3d_amd import synth
+    from livescan3d_amd.sharding import ShardedFusion
+    from oracle import orc
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    T = 2
+    sizes = [(61, 37), (512, 424), (100, 3), (250, 120)]          # sensors of different sizes, widths that are not multiples of 8
+    rigs = []
+    for k in range(T):
+        depths, rgbs, intr, wt = [], [], [], []
+        for s, (w, h) in enumerate(sizes):
+            d, c = synth.noise_frame(17, k, s, w, h)
+            depths.append(d); rgbs.append(c)
+            intr.append(synth.kinect_intrinsics(w, h))
+            wt.append(synth.pack_pose(*synth.ring_pose(s, len(sizes))))
+        rigs.append(synth.Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), [-1.0, -1.2, -1.5, 1.3, 1.1, 1.6]))
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).to(dev)
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).to(dev)
+    sf = ShardedFusion(0, 1, T, [w for w, _ in sizes], [h for _, h in sizes], dev)
+    sf.set_params(rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+    ok = True
+    for rep in range(2):
+        merged, moff = sf.step(depth, rgb)
+        torch.cuda.synchronize()
+        oh = moff.cpu().numpy()
+        for k in range(T):
+            r = rigs[k]
+            want, counts = orc.generate_mesh_vertices(r.depth_maps, r.depth_colors, r.widths, r.heights, r.intr, r.wt, r.bounds)
+            n = int(oh[k, -1])
+            ok = ok and n == len(want) and list(np.diff(oh[k])) == list(counts) and merged[k, :n].cpu().numpy().tobytes() == want.tobytes()
+    cap = sum(w * h for w, h in sizes)
+    sent = sf.shard.last_bytes_sent()
+    ok = ok and (sent >= T * cap * 16 if padded else 0 < sent < T * cap * 16)
+    sf.close()
+    with open(out, "w") as f:
+        f.write("ok" if ok else "mismatch")
+
+
+@pytest.mark.parametrize("padded", [False, True])
+def test_shard_exports_ragged_rig_world1(gpu, tmp_path, padded):
+    """A rig the survivor exchange cannot serve (sensors of different sizes, widths not multiples of 8): lsnShardCreate falls back
+    to exchanging the 16-byte vertices (lsnFusionRun on the block, one all-gather per tick cut to the step's largest shard, the
+    packing pass of lsnMergeShards) and the merged cloud is still the oracle's, byte for byte."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_shard_worker_ragged, args=(padded, out), nprocs=1, join=True)
+    assert open(out).read() == "ok"
+
+
 def _shard_worker_big(rank, out):
     sys.path.insert(0, ROOT)
     import numpy as np
