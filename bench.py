@@ -145,7 +145,8 @@ def main():
     # rehearsal with LSN_BENCH_SHARE_GPU=1 uses: RCCL refuses two ranks on one device).
     xch = sx = whole = shard = None
     survivors_ok = multi and w % 8 == 0 and args.mode == 0
-    use_shard = survivors_ok and args.exchange == "survivors" and not share
+    fake_rccl = bool(os.environ.get("LSN_RCCL_LIBRARY"))   # tests/fake_rccl: the C++ step with several ranks on one GPU (rehearsal only)
+    use_shard = survivors_ok and args.exchange == "survivors" and (not share or fake_rccl)
     use_sx = survivors_ok and not use_shard and args.exchange in ("survivors", "survivors-python")
     if multi:
         from livescan3d_amd.sharding import ShardedFusion, SurvivorExchange
@@ -158,7 +159,7 @@ def main():
                 shard.set_params(intr_all, wt_all, bounds)
             except Exception as ex:  # noqa: BLE001
                 err, shard = f"{type(ex).__name__}: {ex}", None
-            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cpu" if share else dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()):
                 print(f"[bench rank {rank}] lsnShard* unavailable ({err}); falling back to the Python-driven survivor exchange", file=sys.stderr)
@@ -405,7 +406,7 @@ def main():
             # the same protocol driven from Python over torch.distributed (round 1's path): what moving the host glue into the library bought
             whole_p = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
             whole_p.set_params(intr_all, wt_all, bounds)
-            sxp = SurvivorExchange(world, fus, whole_p)
+            sxp = SurvivorExchange(world, fus, whole_p, via_host=share)
             for _ in range(max(1, args.warmup)):
                 sxp.exchange(depth, rgb, stream)
             sync()

@@ -449,12 +449,19 @@ Rccl *rccl()
     std::lock_guard<std::mutex> g(mu);
     if (r) return r;
     void *lib = nullptr;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (lib) break;
+    // $LSN_RCCL_LIBRARY: an RCCL build outside the loader path -- or the shared-memory test double of tests/fake_rccl, which
+    // lets several ranks share one GPU (RCCL itself refuses that)
+    const char *custom = getenv("LSN_RCCL_LIBRARY");
+    if (custom && *custom) {
+        lib = dlopen(custom, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
     }
     if (!lib) {
-        lsn::set_error("lsnShard: cannot load librccl.so.1 (%s)", dlerror());
+        lsn::set_error("lsnShard: cannot load %s (%s)", custom && *custom ? custom : "librccl.so.1", dlerror());
         return nullptr;
     }
     Rccl *t = new Rccl();

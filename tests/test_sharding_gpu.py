@@ -309,6 +309,90 @@ def test_shard_exports_ragged_rig_world1(gpu, tmp_path, padded):
     assert open(out).read() == "ok"
 
 
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
+def _shard_worker_multi(rank, world, port, sizes, chunks, padded, out):
+    sys.path.insert(0, ROOT)
+    os.environ["LSN_RCCL_LIBRARY"] = FAKE_RCCL                      # the shared-memory test double: several ranks on this one GPU
+    os.environ["LSN_SHARD_CHUNKS"] = str(chunks)
+    if padded:
+        os.environ["LSN_SHARD_PADDED"] = "1"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from livescan3d_amd import synth
+    from livescan3d_amd.fusion import DeviceFusion
+    from livescan3d_amd.sharding import ShardedFusion
+    dist.init_process_group("gloo", rank=rank, world_size=world)    # carries the 128-byte id only
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    T, S = 5, len(sizes)
+    mpr = S // world
+    rigs = []
+    for k in range(T):
+        depths, rgbs, intr, wt = [], [], [], []
+        for s, (w, h) in enumerate(sizes):
+            d, c = synth.noise_frame(29, k, s, w, h) if (k + s) % 3 else synth.scene_frame(29, k, s, S, w, h)
+            depths.append(d); rgbs.append(c)
+            intr.append(synth.kinect_intrinsics(w, h))
+            wt.append(synth.pack_pose(*synth.ring_pose(s, S)))
+        rigs.append(synth.Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), synth.CROP_BOUNDS))
+    pix = [w * h for w, h in sizes]
+    p0, p1 = sum(pix[:rank * mpr]), sum(pix[:(rank + 1) * mpr])
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).to(dev)
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).to(dev)
+    mine_d = depth[:, p0:p1].contiguous()
+    mine_c = rgb[:, 3 * p0:3 * p1].contiguous()
+    widths, heights = [w for w, _ in sizes], [h for _, h in sizes]
+    sf = ShardedFusion(rank, world, T, widths, heights, dev)
+    sf.set_params(rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+    whole = DeviceFusion(T, widths, heights, device=0)
+    whole.set_params(rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+    want_v, want_o = whole.run(depth, rgb)
+    torch.cuda.synchronize()
+    ok = True
+    for rep in range(3):
+        merged, moff = sf.step(mine_d, mine_c)
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.equal(moff, want_o))
+        for k in range(T):
+            n = int(want_o[k, -1])
+            ok = ok and n > 0 and bool(torch.equal(merged[k, :n], want_v[k, :n]))
+    sent = sf.shard.last_bytes_sent()
+    ok = ok and sent > 0
+    sf.close()
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    dist.destroy_process_group()
+    if rank == 0:
+        with open(out, "w") as f:
+            f.write("ok" if all(flags) else f"mismatch {flags}")
+
+
+UNIFORM4 = [(256, 212)] * 4
+UNIFORM8 = [(128, 96)] * 8
+RAGGED4 = [(61, 37), (250, 120), (250, 120), (61, 37)]               # equal pixel totals per rank for world 2; not for world 4
+
+
+@pytest.mark.parametrize("world,sizes,chunks,padded", [
+    (2, UNIFORM4, 1, False), (2, UNIFORM4, 3, False), (4, UNIFORM8, 4, False), (4, UNIFORM4, 1, True), (2, UNIFORM8, 5, False),
+    (2, RAGGED4, 1, False), (2, RAGGED4, 1, True)])
+def test_shard_step_several_ranks_on_one_gpu(gpu, tmp_path, world, sizes, chunks, padded):
+    """lsnShardStep with world > 1.  RCCL refuses two ranks on one device, so the library is pointed ($LSN_RCCL_LIBRARY) at
+    tests/fake_rccl -- the seven nccl* entry points over a shared-memory segment -- and `world` processes share this GPU:
+    rank offsets, the grouped all-gathers, the chunked second-stream pipeline, the reconstruction of every rank's sensors
+    (or the vertex exchange on the ragged rig) all run as they would on `world` GPUs, and every rank must end up with the
+    single-plan merged cloud."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_shard_worker_multi, args=(world, _free_port(), sizes, chunks, padded, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
 def _shard_worker_big(rank, out):
     sys.path.insert(0, ROOT)
     import numpy as np
