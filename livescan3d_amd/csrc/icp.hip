@@ -43,7 +43,6 @@ constexpr int kScanBlock = kThreads * kScanItems;  // 4096
 constexpr int kSuper = 16;            // cells per super-block edge
 constexpr int kMaxSupers = kMaxCells / (kSuper * kSuper * kSuper);  // 1024
 constexpr int kMaxBlocks3 = kMaxCells / 64;                          // 4^3-cell blocks
-constexpr int kBfTile = 1024;         // targets per LDS tile in the brute-force kernel
 constexpr int kChunk = 256;            // points per scan item (4 LDS batches of 64)
 constexpr int kSeedBlocks = 4;        // blocks nearest to a query patch that are scanned first when it has no candidates yet
 
@@ -981,62 +980,96 @@ __global__ __launch_bounds__(kThreads) void nn_finish_kernel(const float4 *__res
     if (keys) claim_targets(keys, active, best_i, best, orig, s_claim_k, s_claim_v);
 }
 
-// LDS-tiled brute force (nn_mode 0, the ablation leg): a workgroup owns 256 queries and streams the whole target cloud
-// through LDS; every lane reads the same LDS address (broadcast, conflict-free), four targets per 16-byte read, the
-// arithmetic in packed f32 pairs.  Targets are visited in index order and a lane is only updated on a strictly smaller
-// distance, so the lowest index wins ties.
+// Brute force (nn_mode 0, the ablation leg).  A lane owns one query; the targets of a step are wave-uniform, so they are fetched
+// with scalar loads (s_load_dwordx16 + x8 = 8 points of the AoS cloud as it stands) and enter the VALU ops as SGPR operands:
+// no tile loads, no barriers, no LDS traffic in the loop.  Targets are visited in index order and a lane is only updated on
+// a strictly smaller distance, so the lowest index wins ties inside a slice; the launch cuts the target cloud into slices
+// (grid.y) whose (distance, index) keys are combined with a 64-bit atomicMin (lexicographic: smaller distance, then lower
+// index) and nn_brute_finish_kernel writes the results.
+// Measured on the way (configs[1], 1.2e10 pairs): LDS-tiled with broadcast ds_read_b128 and packed f32, one workgroup per 256
+// queries over all targets 2.79 ms (435 workgroups = 1.7 waves per SIMD, the kernel lasting as long as its busiest CU);
+// the same in 5 slices with the next step's LDS reads prefetched 2.40; scalar loads 2.13; ~75 slices (32 k workgroups of
+// ~1500 points) 1.77 ms = 54 TFLOP/s.  Ceiling (tools/pk_rate.hip): packed or not, dependent f32 add / mul chains retire at
+// 60-61 TFLOP/s chip-wide -- without FMA (contraction is off by contract) half of the nominal 157 is out of reach.
 __global__ __launch_bounds__(kThreads) void nn_brute_kernel(const float *__restrict__ targets, int n1, const float4 *__restrict__ src, int n2,
-                                                            int *idx, float *dist, unsigned long long *keys)
+                                                            int slice_points /* a multiple of 8 */, unsigned long long *best_key)
 {
-    __shared__ alignas(16) float tiles[3 * kBfTile];
-    float *tx = tiles, *ty = tiles + kBfTile, *tz = tiles + 2 * kBfTile;
     const int j = blockIdx.x * kThreads + threadIdx.x;
-    const bool active = j < n2;
-    float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
-    if (active) q4 = src[j];
+    const float4 q4 = j < n2 ? src[j] : make_float4(NAN, NAN, NAN, 0.0f);
     const float qx = q4.x, qy = q4.y, qz = q4.z;
-    const f2v qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     float best = INFINITY;
     int best_i = 0x7FFFFFFF;
-    for (int t0 = 0; t0 < n1; t0 += kBfTile) {
-        const int nt = min(kBfTile, n1 - t0);
-        __syncthreads();
-        for (int t = threadIdx.x; t < kBfTile; t += kThreads) {
-            const bool in = t < nt;  // the tail of the last tile is padded with NaN: its distances are NaN, never taken
-            tx[t] = in ? targets[3 * (size_t)(t0 + t)] : NAN;
-            ty[t] = in ? targets[3 * (size_t)(t0 + t) + 1] : NAN;
-            tz[t] = in ? targets[3 * (size_t)(t0 + t) + 2] : NAN;
+    const int first = (int)min((long long)n1, (long long)blockIdx.y * slice_points);
+    const int last = (int)min((long long)n1, (long long)first + slice_points);
+    const int full = first + ((last - first) & ~7);   // whole steps of 8 points
+    const float *__restrict__ tp = targets + 3 * (size_t)first;
+    // two register (SGPR) buffers used alternately, so the prefetched step needs no copy
+    float bufA[24], bufB[24];
+    const int last_step = max(full - 8, first);
+    auto fetch = [&](float (&buf)[24], int t) {   // unconditional (a prefetch past the end re-reads the last step): no wait lands behind the loads
+        const float *__restrict__ p = tp + 3 * (min(t, last_step) - first);
+#pragma unroll
+        for (int c = 0; c < 24; c++) buf[c] = p[c];
+    };
+    auto step = [&](const float (&buf)[24], int t) {
+        float d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {   // the order (dx*dx + dy*dy) + dz*dz of PointCloud::kdtree_distance (icp.h:40-47); contraction is off
+            const float dx = qx - buf[3 * k], dy = qy - buf[3 * k + 1], dz = qz - buf[3 * k + 2];
+            d[k] = dx * dx + dy * dy + dz * dz;
         }
-        __syncthreads();
-        for (int t = 0; t < nt; t += 8) {  // two independent groups of four per step
-            const f4v d = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&tx[t]), *reinterpret_cast<const f4v *>(&ty[t]),
-                                  *reinterpret_cast<const f4v *>(&tz[t]));
-            const f4v e = dist2x4(qx2, qy2, qz2, *reinterpret_cast<const f4v *>(&tx[t + 4]), *reinterpret_cast<const f4v *>(&ty[t + 4]),
-                                  *reinterpret_cast<const f4v *>(&tz[t + 4]));
-            const float m = fminf(fminf(fminf(d.x, d.y), fminf(d.z, d.w)), fminf(fminf(e.x, e.y), fminf(e.z, e.w)));
-            if (__ballot(m < best)) {  // wave-uniform; rare once the running minima have settled
-                const int k = t0 + t;
-                if (d.x < best) { best = d.x; best_i = k; }
-                if (d.y < best) { best = d.y; best_i = k + 1; }
-                if (d.z < best) { best = d.z; best_i = k + 2; }
-                if (d.w < best) { best = d.w; best_i = k + 3; }
-                if (e.x < best) { best = e.x; best_i = k + 4; }
-                if (e.y < best) { best = e.y; best_i = k + 5; }
-                if (e.z < best) { best = e.z; best_i = k + 6; }
-                if (e.w < best) { best = e.w; best_i = k + 7; }
-            }
+        const float m = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));   // fminf skips NaN
+        if (__ballot(m < best)) {   // wave-uniform; rare once the running minima have settled
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (d[k] < best) { best = d[k]; best_i = t + k; }
         }
+    };
+    if (first < full) fetch(bufA, first);
+    for (int t = first; t < full; t += 16) {
+        // scalar loads return out of order, so the only wait is "all of them": a buffer's first use must come BEFORE the next
+        // fetch is issued, or that wait would cover the fresh loads too (the empty asm pins that order)
+        fetch(bufB, t + 8);
+        step(bufA, t);
+        asm volatile("" ::"s"(bufB[0]));
+        fetch(bufA, t + 16);
+        if (t + 8 < full) step(bufB, t + 8);
+        asm volatile("" ::"s"(bufA[0]));
     }
-    const int orig = __float_as_int(q4.w);
+    for (int t = full; t < last; t++) {   // the cloud's last < 8 points
+        const float dx = qx - targets[3 * (size_t)t], dy = qy - targets[3 * (size_t)t + 1], dz = qz - targets[3 * (size_t)t + 2];
+        const float d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; best_i = t; }
+    }
+    if (j < n2 && best_i != 0x7FFFFFFF) atomicMin(&best_key[j], pack_key(best, best_i));
+}
+
+__global__ __launch_bounds__(kThreads) void nn_brute_init_kernel(unsigned long long *best_key, int n2)
+{
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j < n2) best_key[j] = kNoKey;
+}
+
+// after a sliced brute-force search: results to the queries' original positions + the one-to-one claims
+__global__ __launch_bounds__(kThreads) void nn_brute_finish_kernel(const float4 *__restrict__ src, int n2, const unsigned long long *best_key, int *idx,
+                                                                   float *dist, unsigned long long *keys)
+{
+    __shared__ int s_claim_k[kClaimSlots];
+    __shared__ unsigned long long s_claim_v[kClaimSlots];
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    const bool active = j < n2;
+    int orig = 0, best_i = 0;
+    float best = INFINITY;
     if (active) {
+        const unsigned long long key = best_key[j];
+        orig = __float_as_int(src[j].w);
+        best = key_dist(key);
+        best_i = key_index(key);
         if (best_i == 0x7FFFFFFF) best_i = 0;
         idx[orig] = best_i;
         dist[orig] = best;
     }
-    if (keys) {
-        __syncthreads();  // the tiles are done with: the claim table reuses their LDS
-        claim_targets(keys, active, best_i, best, orig, reinterpret_cast<int *>(tiles), reinterpret_cast<unsigned long long *>(tiles + kBfTile));
-    }
+    if (keys) claim_targets(keys, active, best_i, best, orig, s_claim_k, s_claim_v);
 }
 
 // ---- matching statistics and Kabsch sums ----------------------------------------------------------------------
@@ -1497,7 +1530,18 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
 {
     float4 *src = w->src.sorted.as<float4>();
     if (nn_mode == 0) {
-        hipLaunchKernelGGL(nn_brute_kernel, dim3(blocks_for(n2)), dim3(kThreads), 0, s, d_verts1, n1, (const float4 *)src, n2, d_idx, d_dist, keys);
+        // slices of the target cloud: ~32 k workgroups of a few hundred to a few thousand points each (measured best at configs[1]
+        // and [2]: 2 k workgroups 2.13 ms, 8 k 1.80, 16-32 k 1.77, 64 k 1.83)
+        static const int want_wgs = getenv("LSN_ICP_BRUTE_WGS") ? std::max(1, atoi(getenv("LSN_ICP_BRUTE_WGS"))) : 32768;
+        const int qblocks = blocks_for(n2);
+        int slices = std::max(1, std::min(65535, (want_wgs + qblocks - 1) / qblocks));
+        const int slice_points = std::max(64, (((n1 + slices - 1) / slices) + 7) & ~7);
+        slices = std::max(1, (n1 + slice_points - 1) / slice_points);
+        unsigned long long *best_key = w->best_key.as<unsigned long long>();
+        hipLaunchKernelGGL(nn_brute_init_kernel, dim3(qblocks), dim3(kThreads), 0, s, best_key, n2);
+        hipLaunchKernelGGL(nn_brute_kernel, dim3(qblocks, slices), dim3(kThreads), 0, s, d_verts1, n1, (const float4 *)src, n2, slice_points, best_key);
+        hipLaunchKernelGGL(nn_brute_finish_kernel, dim3(qblocks), dim3(kThreads), 0, s, (const float4 *)src, n2,
+                           (const unsigned long long *)best_key, d_idx, d_dist, keys);
         LSN_HIP(hipGetLastError());
         return 0;
     }

@@ -25,7 +25,7 @@ for rep in range(int(os.environ.get("ICP_REPS", "3"))):
     Rt = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device="cuda")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ws.run(tgt.data_ptr(), n1, src.data_ptr(), n2, Rt.data_ptr(), Rt.data_ptr() + 36, 10, native.NN_GRID, int(torch.cuda.current_stream().cuda_stream))
+    ws.run(tgt.data_ptr(), n1, src.data_ptr(), n2, Rt.data_ptr(), Rt.data_ptr() + 36, 10, native.NN_BRUTE if os.environ.get("ICP_BRUTE") == "1" else native.NN_GRID, int(torch.cuda.current_stream().cuda_stream))
     e1.record()
     torch.cuda.synchronize()
     print("n1", n1, "n2", n2, "ms/iter", e0.elapsed_time(e1) / 10)
