@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--ticks", type=int, default=64, help="ticks fused per step (one launch sequence)")
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=424)
-    ap.add_argument("--mode", type=int, default=int(os.environ.get("LSN_FUSE_MODE", "0")), help="0 two-pass, 1 look-back")
+    ap.add_argument("--mode", type=int, default=int(os.environ.get("LSN_FUSE_MODE", "0")), help="0 two-pass (default, fastest), 1 look-back per run of tiles, 2 single pass with look-back per tile")
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
@@ -231,7 +231,7 @@ def main():
     else:
         alg_bytes = 2 * P * S_loc * B + 19 * V_local            # fuse_kernel<1>: sum over its sensor-frames of 2P + 19V
         V_total = int(xch.merged_off[:, -1].sum().item()) if multi else V_local
-    if args.mode == 1 and fus.plan.lookback_failed(stream):
+    if args.mode in (1, 2) and fus.plan.lookback_failed(stream):
         raise SystemExit("look-back compaction gave up on a bounded spin: results invalid")
 
     result = None
@@ -259,7 +259,7 @@ def main():
                 "sensors": S, "width": w, "height": h, "ticks_per_step": B,
                 "sensors_per_gpu": S_loc,
                 "survivor_fraction": V_total / float(B * S * P),
-                "compaction": "two-pass" if args.mode == 0 else "look-back",
+                "compaction": {0: "two-pass", 1: "look-back per run of tiles", 2: "single pass, look-back per tile"}[args.mode],
                 "count_pass": ("arithmetic (LSN_NO_THRESHOLDS=1)" if os.environ.get("LSN_NO_THRESHOLDS", "0") not in ("", "0")
                                else "per-pixel depth thresholds"),
                 "threshold_build_ms_once_per_calibration": thr_build_ms,

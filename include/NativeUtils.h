@@ -122,7 +122,8 @@ int lsnFusionSetParams(LsnFusion *plan, const float *intr_params, const float *w
                        const float *bounds6, void *stream);
 
 /* Selects how the raster-order compaction gets its global offsets: 0 = two-pass (count kernel + write kernel),
- * 1 = single pass with decoupled look-back.  Results are identical. */
+ * 1 = single launch, runs of tiles counted then re-evaluated, decoupled look-back per run, 2 = single pass, every tile
+ * evaluated once, decoupled look-back per tile.  Results are identical; 0 is the fastest on MI355X. */
 int lsnFusionSetMode(LsnFusion *plan, int mode);
 
 /* Pipelined calls (mode 0 only): the caller promises that the INPUTS of a call are already resident and stay untouched

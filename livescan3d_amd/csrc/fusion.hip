@@ -228,6 +228,68 @@ __global__ __launch_bounds__(kThreads) void count_thr_kernel(const FuseArgs a)
             s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
 }
 
+// Look-back status word: bits 63..62 flag (0 = empty, 1 = run aggregate, 2 = inclusive prefix), low 32 bits value.
+// One naturally aligned 8-byte word carries flag AND value, written by one agent-scope (sc1, write-through) store and
+// polled with agent-scope loads: nothing else is handed off, so no fence is needed and the result cannot depend on
+// where the producing workgroup ran.
+constexpr unsigned long long kFlagAggregate = 1ull << 62;
+constexpr unsigned long long kFlagPrefix = 2ull << 62;
+constexpr int kSpinLimit = 1 << 20;
+
+// Mode 2 (single pass, one look-back per TILE) tags its words instead of clearing them: bits 63..34 = the launch's epoch,
+// 33..32 = flag, low 32 bits = value; a word of another epoch reads as "empty".
+constexpr int kEpochShift = 34;
+constexpr unsigned long long kTileAggregate = 1ull << 32, kTilePrefix = 2ull << 32;
+
+// Exclusive prefix of this tile inside its tick, by decoupled look-back (wave 0 of the workgroup; 64 predecessors per poll).
+// Relies on workgroups starting in blockIdx order (a tile only ever waits for lower-numbered tiles of its tick, and the
+// lowest unfinished workgroup is always resident); bounded by kSpinLimit so that a launch always drains: returns -1, raises
+// error flag 1 and leaves a poisoned word (flag 3: everybody behind gives up at once) when it gives up.
+__device__ __forceinline__ int tile_lookback(const FuseArgs &a, int tick, int tile, int tile_tot, int lane)
+{
+    unsigned long long *st = a.run_state + (long long)tick * a.tiles_per_tick;
+    const unsigned long long tag = (unsigned long long)a.epoch << kEpochShift;
+    if (lane == 0)
+        __hip_atomic_store(&st[tile], tag | (tile == 0 ? kTilePrefix : kTileAggregate) | (unsigned int)tile_tot, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    int acc = 0;
+    int pos = tile - 1 - lane;  // lane 0 looks at the nearest predecessor
+    bool done = tile == 0;
+    int spins = 0;
+    while (!done) {
+        unsigned long long w = tag | kTilePrefix;  // before the first tile: prefix 0
+        if (pos >= 0) {
+            // most polls take the short way (sc0: past the CU's L1 only; the word is in this XCD's L2 when the producer ran on
+            // this XCD); every fourth goes to memory (agent scope), so a producer on another XCD is seen as well -- a stale L2
+            // line can only read as "empty" (epoch tag)
+            if ((spins & 3) != 3) w = __hip_atomic_load(&st[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else w = __hip_atomic_load(&st[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned int flag = (w >> kEpochShift) == a.epoch ? (unsigned int)(w >> 32) & 3u : 0u;
+        const unsigned long long pref = __ballot(flag == 2);
+        const int first = pref ? __ffsll((long long)pref) - 1 : 63;
+        const unsigned long long relevant = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+        const bool poisoned = (__ballot(flag == 3) & relevant) != 0;
+        if (poisoned || (__ballot(flag == 0) & relevant) != 0) {
+            if (poisoned || ++spins > kSpinLimit) {
+                if (lane == 0) {
+                    atomicExch(a.error_flag, 1);
+                    __hip_atomic_store(&st[tile], tag | (3ull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return -1;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        acc += wave_sum(lane <= first ? (int)(unsigned int)w : 0);
+        if (pref) done = true;
+        else pos -= 64;
+    }
+    if (lane == 0 && tile != 0)
+        __hip_atomic_store(&st[tile], tag | kTilePrefix | (unsigned int)(acc + tile_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return acc;
+}
+
 // ---- mode 0: count kernel, scan kernel, write kernel ------------------------------------------------------------
 
 // MODE 0 = count only (writes tile_counts), 1 = write with offsets from tile_counts (exclusive prefixes by then),
@@ -243,10 +305,23 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     __shared__ uint4 stage[kWrite ? (kWin + kWin / 8) : 1];
     __shared__ int s_wave_tot[4];
     __shared__ int s_wave_next[4];
+    __shared__ int s_base;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int tick = blockIdx.x / a.tiles_per_tick;
-    const int tile = blockIdx.x - tick * a.tiles_per_tick;
+    // mode 4 walks the ticks fastest: the ~2000 resident workgroups then are ~30 consecutive tiles of EVERY tick, i.e. as many
+    // independent look-back chains as ticks (tick-major order keeps 2-3 chains alive and the launch crawls at their pace:
+    // 0.54 ms instead of 0.25); with a tick count that is a multiple of 8 a tick's tiles also share an XCD
+    int tick = blockIdx.x / a.tiles_per_tick;
+    int tile = blockIdx.x - tick * a.tiles_per_tick;
+    if (kWrite && a.chunk > 0) {
+        const int per_chunk = a.chunk * a.n_ticks;
+        const int chunk = blockIdx.x / per_chunk;
+        const int r = blockIdx.x - chunk * per_chunk;
+        const int width = min(a.chunk, a.tiles_per_tick - chunk * a.chunk);   // the last chunk may be narrower
+        tick = r / width;
+        tile = chunk * a.chunk + (r - tick * width);
+    }
+    const int lin = tick * a.tiles_per_tick + tile;
 
     const Tile t = locate(a, tick, tile);
     Inputs in;
@@ -301,9 +376,9 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
     if (lane == 0) s_wave_tot[wave] = wave_total;
     int base = 0, counted = 0;
     if (MODE == 1 || MODE == 3) {
-        base = a.tile_counts[blockIdx.x];  // scan_kernel left the exclusive prefix inside the tick here
+        base = a.tile_counts[lin];  // scan_kernel left the exclusive prefix inside the tick here
         // what the count pass saw in this tile = the next tile's prefix (the tick's total after the last tile) minus this one
-        counted = (tile + 1 < a.tiles_per_tick ? a.tile_counts[blockIdx.x + 1] : a.offsets[tick * (a.n_frames + 1) + a.n_frames]) - base;
+        counted = (tile + 1 < a.tiles_per_tick ? a.tile_counts[lin + 1] : a.offsets[tick * (a.n_frames + 1) + a.n_frames]) - base;
     }
     __syncthreads();
     int wave_off = 0, tile_tot = 0;
@@ -314,11 +389,26 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
         tile_tot += v;
     }
     if (MODE == 0) {
-        if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = tile_tot;
+        if (threadIdx.x == 0) a.tile_counts[lin] = tile_tot;
         return;
     }
-    if (MODE == 3 && threadIdx.x == 0) a.tile_counts_next[blockIdx.x] = s_wave_next[0] + s_wave_next[1] + s_wave_next[2] + s_wave_next[3];
-    if (tile_tot != counted) {
+    if (MODE == 3 && threadIdx.x == 0) a.tile_counts_next[lin] = s_wave_next[0] + s_wave_next[1] + s_wave_next[2] + s_wave_next[3];
+    if (MODE == 4) {
+        // single pass: the vertices wait in registers while wave 0 resolves the tile's offset from its predecessors
+        if (wave == 0) {
+            const int b = tile_lookback(a, tick, tile, tile_tot, lane);
+            if (lane == 0) s_base = b;
+        }
+        __syncthreads();
+        base = s_base;
+        if (base < 0) return;
+        if (threadIdx.x == 0) {   // the per-sensor offsets table scan_kernel writes in mode 0
+            int *off = a.offsets + tick * (a.n_frames + 1);
+            if (t.frame_start) off[t.f] = base;
+            if (tile == a.tiles_per_tick - 1) off[a.n_frames] = base + tile_tot;
+        }
+    }
+    if (MODE != 4 && tile_tot != counted) {
         // The inputs are not the ones the count pass read (a caller refilled a buffer that had been counted ahead by
         // lsnFusionRunStreamed, or overwrote the inputs of a call in flight): the prefixes no longer fit, tiles would
         // overlap and the last one would run past its tick's slab.  Write nothing, raise the flag (lsnFusionCheck).
@@ -353,13 +443,6 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
 
 // ---- mode 1: one launch, runs of tiles with a decoupled look-back per run ---------------------------------------
 
-// Look-back status word: bits 63..62 flag (0 = empty, 1 = run aggregate, 2 = inclusive prefix), low 32 bits value.
-// One naturally aligned 8-byte word carries flag AND value, written by one agent-scope (sc1, write-through) store and
-// polled with agent-scope loads: nothing else is handed off, so no fence is needed and the result cannot depend on
-// where the producing workgroup ran.
-constexpr unsigned long long kFlagAggregate = 1ull << 62;
-constexpr unsigned long long kFlagPrefix = 2ull << 62;
-constexpr int kSpinLimit = 1 << 20;
 
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void run_kernel(const FuseArgs a)
@@ -695,8 +778,8 @@ extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *
 
 extern "C" int lsnFusionSetMode(LsnFusion *p, int mode)
 {
-    if (!p || mode < 0 || mode > 1) {
-        lsn::set_error("lsnFusionSetMode: mode must be 0 (count/scan/write launches) or 1 (single launch, runs + look-back)");
+    if (!p || mode < 0 || mode > 2) {
+        lsn::set_error("lsnFusionSetMode: mode must be 0 (count/scan/write launches), 1 (single launch, runs + look-back) or 2 (single pass, look-back per tile)");
         return -1;
     }
     p->mode = mode;
@@ -754,7 +837,7 @@ extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *lau
     if (avg_ms) *avg_ms = p->launches ? p->acc_ms / (double)p->launches : 0.0;
     if (launches) *launches = p->launches;
     if (name && name_len > 0)
-        snprintf(name, (size_t)name_len, "%s", p->timed_kernel ? p->timed_kernel : (p->mode == 0 ? "fuse_kernel<1>" : "run_kernel"));
+        snprintf(name, (size_t)name_len, "%s", p->timed_kernel ? p->timed_kernel : (p->mode == 0 ? "fuse_kernel<1>" : p->mode == 2 ? "fuse_kernel<4>" : "run_kernel"));
     if (reset) {
         p->acc_ms = 0;
         p->launches = 0;
@@ -765,6 +848,8 @@ extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *lau
 // Kernel arguments of one call (everything but the per-mode scratch selection).
 void lsn::fill_args(LsnFusion *p, FuseArgs &a, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets)
 {
+    a.epoch = 0;
+    a.chunk = 0;
     a.frames = p->frames.as<FrameDesc>();
     a.tiles = p->tile_frame.as<TileDesc>();
     a.params = p->params.as<SensorParams>();
@@ -877,9 +962,9 @@ int lsn::next_event_pair(LsnFusion *p, hipEvent_t &e0, hipEvent_t &e1)
 template <int MODE>
 static void launch(bool vec, int grid, hipStream_t s, const FuseArgs &a, bool lazy_rgb = false)
 {
-    if (MODE == 1 && lazy_rgb) {
-        if (vec) hipLaunchKernelGGL((fuse_kernel<1, true, true>), dim3(grid), dim3(kThreads), 0, s, a);
-        else     hipLaunchKernelGGL((fuse_kernel<1, false, true>), dim3(grid), dim3(kThreads), 0, s, a);
+    if ((MODE == 1 || MODE == 4) && lazy_rgb) {
+        if (vec) hipLaunchKernelGGL((fuse_kernel<MODE, true, true>), dim3(grid), dim3(kThreads), 0, s, a);
+        else     hipLaunchKernelGGL((fuse_kernel<MODE, false, true>), dim3(grid), dim3(kThreads), 0, s, a);
         return;
     }
     if (vec) hipLaunchKernelGGL((fuse_kernel<MODE, true>), dim3(grid), dim3(kThreads), 0, s, a);
@@ -970,9 +1055,26 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         if (hooks && hooks->counted) LSN_HIP(hipEventRecord(hooks->counted, s));
         if (hooks && hooks->colours_ready) LSN_HIP(hipStreamWaitEvent(s, hooks->colours_ready, 0));
         if (e0) LSN_HIP(hipEventRecord(e0, s));
+        static const int exp_chunk = getenv("LSN_EXP_WRITE_CHUNK") ? atoi(getenv("LSN_EXP_WRITE_CHUNK")) : 0;   // experiment: block order of the write pass
+        a.chunk = exp_chunk;
         launch<1>(vec, grid, s, a, p->lazy_rgb);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
         if (hooks && hooks->written) LSN_HIP(hipEventRecord(hooks->written, s));
+    } else if (p->mode == 2) {
+        // single pass: per-tile look-back words tagged with the launch's epoch (30 bits; the words are cleared when it wraps)
+        if (p->epoch == 0 || p->epoch >= (1u << 30) - 1) {
+            LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)grid, s));
+            p->epoch = 0;
+        }
+        a.epoch = ++p->epoch;
+        // block order: chunks of 16 consecutive tiles, every tick's chunk before the next chunk -- the ~2000 resident workgroups
+        // then belong to as many look-back chains as there are ticks (measured, 64 ticks x 848 tiles: tick-major 0.54 ms, ticks
+        // fastest 0.40, chunks of 4 / 16 / 64 tiles 0.335 / 0.328 / 0.41)
+        static const int chunk = getenv("LSN_FUSE_CHUNK") ? atoi(getenv("LSN_FUSE_CHUNK")) : 16;
+        a.chunk = std::max(0, chunk);
+        if (e0) LSN_HIP(hipEventRecord(e0, s));
+        launch<4>(vec, grid, s, a, p->lazy_rgb);
+        if (e1) LSN_HIP(hipEventRecord(e1, s));
     } else {
         LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)grid, s));
         LSN_HIP(hipMemsetAsync(p->misc.as<char>() + 128, 0, 128 * (size_t)p->n_ticks, s));  // tickets; the error flag is sticky

@@ -53,6 +53,8 @@ struct FuseArgs {
     int tiles_per_tick;
     int n_ticks;
     int tiles_per_run;               // mode 1
+    unsigned int epoch;              // mode 2: tag of this launch's look-back words (run_state is never cleared)
+    int chunk;                       // write pass block order: 0 = tick-major; C > 0 = chunks of C consecutive tiles, all ticks of a chunk before the next chunk
     int runs_per_tick;               // mode 1
     long long tick_depth_stride;  // u16 elements
     long long tick_rgb_stride;    // bytes
@@ -421,6 +423,7 @@ struct LsnFusion {
     bool vec_ok = false;
     bool params_set = false;
     int mode = 0;
+    unsigned int epoch = 0;          // mode 2: launches so far (tags the look-back words)
     int tiles_per_run_override = 0;  // $LSN_TILES_PER_RUN (tuning / tests)
     bool want_pixmap = false;        // the run in progress also fills the pixel -> vertex map (set and cleared under mu by run_locked)
     float bounds[6] = {0, 0, 0, 0, 0, 0};

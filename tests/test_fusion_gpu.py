@@ -106,7 +106,7 @@ def test_edge_cases_empty_full_and_nan(gpu, orc):
     _assert_same(verts, want, "fx = 0")
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_device_resident_batch_matches_oracle(gpu, orc, mode):
     """T ticks x N sensors in one launch sequence on HBM-resident inputs; both compaction modes."""
     import torch
@@ -127,7 +127,7 @@ def test_device_resident_batch_matches_oracle(gpu, orc, mode):
         assert list(np.diff(off)) == list(counts)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_full_size_properties(gpu, mode):
     """BASELINE config sizes (8 x 512x424 and 16 x 1024x1024) through size-independent properties:
     offsets are monotone and end at the count, every vertex is inside the crop box, the count equals an independent
