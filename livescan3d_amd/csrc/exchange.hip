@@ -53,8 +53,31 @@ struct PackArgs {
                               // all ticks back to back, ONE contiguous run per shard: what the RCCL all-gather sends as it is
 };
 
+// Aligned copy of n bytes that sit in LDS at lds[lead ..), lead = (address of dst) mod 16, to dst: the 16-byte chunks that lie
+// wholly inside the range go out as one store each, the (< 16-byte) pieces at either end element by element (ELEM bytes each) --
+// the neighbouring tiles own the rest of those chunks.
+template <int ELEM, typename T>
+__device__ __forceinline__ void store_run(T *dst, const T *lds, int lead, int n)
+{
+    static_assert(sizeof(T) == ELEM, "element size");
+    const int end = lead + n;                        // in bytes, relative to the aligned start of the first chunk
+    const int c0 = lead ? 1 : 0, c1 = end >> 4;       // chunks [c0, c1) are whole
+    uint4 *g16 = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(dst) - lead);
+    const uint4 *l16 = reinterpret_cast<const uint4 *>(lds);
+    for (int j = c0 + (int)threadIdx.x; j < c1; j += kThreads) g16[j] = l16[j];
+    const int head = lead ? min(n, 16 - lead) : 0;   // bytes before the first whole chunk
+    const int tail0 = max(head, 16 * c1 - lead);     // first byte after the last whole chunk
+    const int t = (int)threadIdx.x * ELEM;
+    if (t < head) dst[threadIdx.x] = lds[lead / ELEM + threadIdx.x];
+    if (tail0 + t < n) dst[tail0 / ELEM + threadIdx.x] = lds[(lead + tail0) / ELEM + threadIdx.x];
+}
+
+// The survivors of a tile are staged in LDS in rank order and leave as 16-byte stores (the first version had every lane store
+// its own short run: 32 one- and two-byte stores per lane, 0.32 ms per 64 ticks x 8 sensors against 0.14 at the copy rate).
 __global__ __launch_bounds__(kThreads) void pack_kernel(const FuseArgs a, const PackArgs pk)
 {
+    __shared__ alignas(16) unsigned short s_d[kTile + 8];
+    __shared__ alignas(16) unsigned char s_c[3 * kTile + 16];
     __shared__ int s_wave_tot[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -73,31 +96,43 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(const FuseArgs a, const 
     rank_from_masks(keep, below, wave_total);
     if (lane == 0) s_wave_tot[wave] = wave_total;
     const int base = a.tile_counts[blockIdx.x];               // exclusive prefix inside the tick (scan_kernel)
+    const long long r0 = (pk.tick_base ? (long long)pk.tick_base[tick] : tick * a.tick_vert_stride) + base;   // the tile's first stream entry
     __syncthreads();
-    int wave_off = 0;
+    int wave_off = 0, tile_tot = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (i < wave) wave_off += s_wave_tot[i];
+    for (int i = 0; i < 4; i++) {
+        const int v = s_wave_tot[i];
+        if (i < wave) wave_off += v;
+        tile_tot += v;
+    }
     const int p0 = t.px0 + threadIdx.x * kPxPerLane;
-    if (p0 >= t.npix) return;
-    unsigned int m8 = 0;
+    unsigned short *gd = pk.depth_c + r0;
+    unsigned char *gc = pk.rgb_c + 3 * r0;
+    const int lead_d = (int)(reinterpret_cast<uintptr_t>(gd) & 15), lead_c = (int)(reinterpret_cast<uintptr_t>(gc) & 15);   // bytes
+    if (p0 < t.npix) {
+        unsigned int m8 = 0;
 #pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) m8 |= (keep[k] ? 1u : 0u) << k;
-    pk.mask[(tick * a.tick_depth_stride + t.pix_base + p0) >> 3] = (unsigned char)m8;
-    long long r = (pk.tick_base ? (long long)pk.tick_base[tick] : tick * a.tick_vert_stride) + base + wave_off + below;
+        for (int k = 0; k < kPxPerLane; k++) m8 |= (keep[k] ? 1u : 0u) << k;
+        pk.mask[(tick * a.tick_depth_stride + t.pix_base + p0) >> 3] = (unsigned char)m8;
+        int e = wave_off + below;
 #pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) {
-        if (keep[k]) {
-            const int b = 3 * k;
-            const unsigned int lo = in.cw[b >> 2], hi = in.cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
-            const unsigned int rgb = __funnelshift_r(lo, hi, (b & 3) * 8);
-            pk.depth_c[r] = (unsigned short)((k & 1) ? in.dw[k >> 1] >> 16 : in.dw[k >> 1] & 0xFFFFu);
-            pk.rgb_c[3 * r] = (unsigned char)rgb;
-            pk.rgb_c[3 * r + 1] = (unsigned char)(rgb >> 8);
-            pk.rgb_c[3 * r + 2] = (unsigned char)(rgb >> 16);
-            r++;
+        for (int k = 0; k < kPxPerLane; k++) {
+            if (keep[k]) {
+                const int b = 3 * k;
+                const unsigned int lo = in.cw[b >> 2], hi = in.cw[(b >> 2) + 1 < 6 ? (b >> 2) + 1 : 5];
+                const unsigned int rgb = __funnelshift_r(lo, hi, (b & 3) * 8);
+                s_d[lead_d / 2 + e] = (unsigned short)((k & 1) ? in.dw[k >> 1] >> 16 : in.dw[k >> 1] & 0xFFFFu);
+                unsigned char *c = s_c + lead_c + 3 * e;
+                c[0] = (unsigned char)rgb;
+                c[1] = (unsigned char)(rgb >> 8);
+                c[2] = (unsigned char)(rgb >> 16);
+                e++;
+            }
         }
     }
+    __syncthreads();
+    store_run<2>(gd, s_d, lead_d, 2 * tile_tot);
+    store_run<1>(gc, s_c, lead_c, 3 * tile_tot);
 }
 
 struct ReconArgs {
@@ -143,31 +178,57 @@ __global__ __launch_bounds__(kThreads) void tick_base_kernel(const int *shard_of
 }
 
 // `a` describes the WHOLE rig (all sensors, their parameters, a.out = the merged cloud).
-__global__ __launch_bounds__(kThreads) void recon_kernel(const FuseArgs a, const ReconArgs r)
+// Two phases per tile.  Pixel-major: the survivor mask gives every lane the ranks of its 8 pixels, and the kept pixels leave their
+// (column, row) in LDS at their rank.  Survivor-major: thread i takes survivors i, i + 256, ... -- consecutive threads read
+// consecutive entries of the shard's compact depth / colour streams and write consecutive 16-byte vertices, so neither the
+// gathers nor the stores need staging (the first version kept the pixel-major layout of the write kernel throughout: every lane
+// fetched its own short run of the streams, 32 scattered 1- and 2-byte loads per lane, and staged the vertices through LDS:
+// 0.37 ms per 64 ticks x 8 sensors against the 0.2 ms its 1.28 GB take at the copy rate).
+struct ReconGeom {   // wave-uniform
+    Tile t;
+    int tick, shard, local_tile;
+    long long st, mask_pix0;
+};
+
+__device__ __forceinline__ ReconGeom recon_geom(const FuseArgs &a, const ReconArgs &r, int b)
 {
-    __shared__ uint4 stage[kWin + kWin / 8];
+    ReconGeom g;
+    g.tick = b / a.tiles_per_tick + r.tick0;
+    const int tile = b - (g.tick - r.tick0) * a.tiles_per_tick;
+    g.t = locate(a, g.tick, tile);
+    g.shard = g.t.f / r.maps_per_shard;
+    const FrameDesc f0 = a.frames[g.shard * r.maps_per_shard];   // first sensor of the owning shard
+    g.st = (long long)g.shard * a.n_ticks + g.tick;              // (shard, tick) slot in the gathered arrays
+    g.local_tile = tile - f0.tile_start;
+    g.mask_pix0 = g.st * r.cap_loc + (g.t.pix_base - f0.depth_off) + g.t.px0;
+    return g;
+}
+
+// Measured and dropped: a persistent form (a workgroup walks tiles b, b + grid, ... and fetches the next tile's mask byte and
+// prefixes ahead) -- 0.50-0.66 ms: loads and stores share one in-order counter on this GPU, so the next tile's gathers wait
+// for the previous tile's 16-byte stores to be acknowledged.
+__global__ __launch_bounds__(kThreads, 8) void recon_kernel(const FuseArgs a, const ReconArgs r)
+{
+    __shared__ unsigned int s_xy[kTile];   // (column | row << 16) of the tile's survivors, by rank
     __shared__ int s_wave_tot[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int tick = blockIdx.x / a.tiles_per_tick + r.tick0;
-    const int tile = blockIdx.x - (tick - r.tick0) * a.tiles_per_tick;
-    const Tile t = locate(a, tick, tile);
-    const int shard = t.f / r.maps_per_shard;
-    const FrameDesc f0 = a.frames[shard * r.maps_per_shard];   // first sensor of the owning shard
-    const long long st = (long long)shard * a.n_ticks + tick;  // (shard, tick) slot in the gathered arrays
-    const int local_tile = tile - f0.tile_start;
+    const ReconGeom g = recon_geom(a, r, blockIdx.x);
+    const Tile &t = g.t;
     const int p0 = t.px0 + threadIdx.x * kPxPerLane;
-    const bool in_frame = p0 < t.npix;
-    const unsigned int m8 = in_frame ? r.mask[(st * r.cap_loc + (t.pix_base - f0.depth_off) + p0) >> 3] : 0u;
+    const unsigned int m8 = p0 < t.npix ? r.mask[(g.mask_pix0 + threadIdx.x * kPxPerLane) >> 3] : 0u;
+    const int tile_base = r.tile_prefix[g.st * r.tiles_loc + g.local_tile];
+    int shard_base = 0;
+    for (int q = 0; q < g.shard; q++) shard_base += r.shard_off[((long long)q * a.n_ticks + g.tick) * (r.maps_per_shard + 1) + r.maps_per_shard];
+    const SensorParams P = a.params[t.f];
     bool keep[kPxPerLane];
 #pragma unroll
     for (int k = 0; k < kPxPerLane; k++) keep[k] = (m8 >> k) & 1u;
     int below, wave_total;
     rank_from_masks(keep, below, wave_total);
     if (lane == 0) s_wave_tot[wave] = wave_total;
-    const int tile_base = r.tile_prefix[st * r.tiles_loc + local_tile];
-    int shard_base = 0;
-    for (int q = 0; q < shard; q++) shard_base += r.shard_off[((long long)q * a.n_ticks + tick) * (r.maps_per_shard + 1) + r.maps_per_shard];
+    int x, y;
+    lane_origin(t, x, y);
     __syncthreads();
     int wave_off = 0, tile_tot = 0;
 #pragma unroll
@@ -176,43 +237,54 @@ __global__ __launch_bounds__(kThreads) void recon_kernel(const FuseArgs a, const
         if (i < wave) wave_off += v;
         tile_tot += v;
     }
-    // the lane's survivors are consecutive entries of the shard's compact streams
-    const long long run = r.tick_base ? (long long)shard * r.slab + (r.tick_base[st] - r.tick_base[(long long)shard * a.n_ticks + r.tick0]) : st * r.slab;
-    const unsigned short *dc = r.depth_c + run;
-    const unsigned char *cc = r.rgb_c + 3 * run;
-    long long ci = tile_base + wave_off + below;
-    unsigned int d[kPxPerLane], c[kPxPerLane];
+    {
+        int e = wave_off + below;   // w % 8 == 0: the lane's 8 pixels share row y, columns x .. x + 7
 #pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) {
-        d[k] = 0;
-        c[k] = 0;
-        if (keep[k]) {
-            d[k] = dc[ci];
-            c[k] = cc[3 * ci] | (cc[3 * ci + 1] << 8) | (cc[3 * ci + 2] << 16);
-            ci++;
-        }
-    }
-    const SensorParams P = a.params[t.f];
-    float xf[kPxPerLane], yf[kPxPerLane];
-    tile_factors<true>(t, xf, yf);
-    uint4 vert[kPxPerLane];
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; k += 2) {
-        f2 ox, oy, oz;
-        unproject2(f2{(float)d[k], (float)d[k + 1]}, f2{xf[k], xf[k + 1]}, f2{yf[k], yf[k + 1]}, P, ox, oy, oz);
-        vert[k] = make_uint4(c[k] | 0xFF000000u, __float_as_uint(ox.x), __float_as_uint(oy.x), __float_as_uint(oz.x));
-        vert[k + 1] = make_uint4(c[k + 1] | 0xFF000000u, __float_as_uint(ox.y), __float_as_uint(oy.y), __float_as_uint(oz.y));
+        for (int k = 0; k < kPxPerLane; k++)
+            if (keep[k]) s_xy[e++] = (unsigned int)(x + k) | ((unsigned int)y << 16);
     }
     if (t.frame_start && threadIdx.x == 0) {
-        int *mo = r.merged_off + (long long)tick * (a.n_frames + 1);
-        mo[t.f] = shard_base + tile_base;                     // the frame's first tile: its prefix is the sensor's offset in the shard
+        int *mo = r.merged_off + (long long)g.tick * (a.n_frames + 1);
+        mo[t.f] = shard_base + tile_base;             // the frame's first tile: its prefix is the sensor's offset in the shard
         if (t.f == a.n_frames - 1) {
             int total = 0;
-            for (int q = 0; q < r.n_shards; q++) total += r.shard_off[((long long)q * a.n_ticks + tick) * (r.maps_per_shard + 1) + r.maps_per_shard];
+            for (int q = 0; q < r.n_shards; q++)
+                total += r.shard_off[((long long)q * a.n_ticks + g.tick) * (r.maps_per_shard + 1) + r.maps_per_shard];
             mo[a.n_frames] = total;
         }
     }
-    stage_and_store(stage, keep, vert, wave_off + below, tile_tot, a.out + tick * a.tick_vert_stride + shard_base + tile_base);
+    __syncthreads();
+    // the tile's survivors are consecutive entries of the shard's compact streams
+    const long long run = r.tick_base ? (long long)g.shard * r.slab + (r.tick_base[g.st] - r.tick_base[(long long)g.shard * a.n_ticks + r.tick0])
+                                      : g.st * r.slab;
+    const unsigned short *dc = r.depth_c + run + tile_base;
+    const unsigned char *cc = r.rgb_c + 3 * (run + tile_base);
+    uint4 *dst = a.out + g.tick * a.tick_vert_stride + shard_base + tile_base;
+    // all of a thread's (<= 8) survivors are fetched before the first one is evaluated: one memory round trip
+    unsigned int d[kPxPerLane], c[kPxPerLane];
+    float xf[kPxPerLane], yf[kPxPerLane];
+#pragma unroll
+    for (int i = 0; i < kPxPerLane; i++) {
+        const int e = threadIdx.x + i * kThreads;
+        d[i] = 0;
+        c[i] = 0;
+        unsigned int xy = 0;
+        if (e < tile_tot) {
+            xy = s_xy[e];
+            d[i] = dc[e];
+            c[i] = cc[3 * e] | (cc[3 * e + 1] << 8) | (cc[3 * e + 2] << 16);
+        }
+        xf[i] = t.xt[xy & 0xFFFFu];
+        yf[i] = t.yt[xy >> 16];
+    }
+#pragma unroll
+    for (int i = 0; i < kPxPerLane; i += 2) {
+        f2 ox, oy, oz;
+        unproject2(f2{(float)d[i], (float)d[i + 1]}, f2{xf[i], xf[i + 1]}, f2{yf[i], yf[i + 1]}, P, ox, oy, oz);
+        const int e0 = threadIdx.x + i * kThreads, e1 = e0 + kThreads;
+        if (e0 < tile_tot) store_vertex(dst + e0, make_uint4(c[i] | 0xFF000000u, __float_as_uint(ox.x), __float_as_uint(oy.x), __float_as_uint(oz.x)));
+        if (e1 < tile_tot) store_vertex(dst + e1, make_uint4(c[i + 1] | 0xFF000000u, __float_as_uint(ox.y), __float_as_uint(oy.y), __float_as_uint(oz.y)));
+    }
 }
 
 }  // namespace

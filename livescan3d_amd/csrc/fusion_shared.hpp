@@ -268,21 +268,39 @@ __device__ __forceinline__ unsigned int rgba_of(const Inputs &in, int k)
 
 // Keep predicates (wave-wide lane masks in SGPR pairs) and, when WRITE, the assembled vertices of a lane's 8 pixels.
 // Branch-free: a zero depth (invalid pixel, :144, or a lane past the frame end) is computed and then dropped.
+// (column, row) of the lane's first pixel: the tile starts at (x0, y0) and the lane is v = x0 + 8*tid < w + 2048 columns
+// further; v / w by a float multiply and an exact +-1 correction (v < 2^23, so the estimate is off by at most one).
+__device__ __forceinline__ void lane_origin(const Tile &t, int &x, int &y)
+{
+    const int p0 = t.px0 + threadIdx.x * kPxPerLane;
+    const int v = t.x0 + (int)threadIdx.x * kPxPerLane;
+    int q = (int)((float)v * t.inv_w);
+    x = v - q * t.w;
+    if (x < 0) { q--; x += t.w; }
+    if (x >= t.w) { q++; x -= t.w; }
+    y = t.y0 + q;
+    if (p0 >= t.npix) { x = 0; y = 0; }
+}
+
+// streaming 16-byte store of one vertex (the merged cloud is written once and not read again by the launch sequence)
+__device__ __forceinline__ void store_vertex(uint4 *dst, const uint4 v)
+{
+    if (kNontemporalStores) {
+        __builtin_nontemporal_store(v.x, &dst->x);
+        __builtin_nontemporal_store(v.y, &dst->y);
+        __builtin_nontemporal_store(v.z, &dst->z);
+        __builtin_nontemporal_store(v.w, &dst->w);
+    } else {
+        *dst = v;
+    }
+}
+
 // The column / row factors of a lane's 8 pixels (they depend on the tile geometry only, not on the tick or the batch).
 template <bool VEC>
 __device__ __forceinline__ void tile_factors(const Tile &t, float (&xf)[kPxPerLane], float (&yf)[kPxPerLane])
 {
-    const int p0 = t.px0 + threadIdx.x * kPxPerLane;
-    const bool in_frame = p0 < t.npix;
-    // (x, y) of the lane's first pixel: the tile starts at (x0, y0) and the lane is v = x0 + 8*tid < w + 2048 columns
-    // further; v / w by a float multiply and an exact +-1 correction (v < 2^23, so the estimate is off by at most one).
-    const int v = t.x0 + (int)threadIdx.x * kPxPerLane;
-    int q = (int)((float)v * t.inv_w);
-    int x = v - q * t.w;
-    if (x < 0) { q--; x += t.w; }
-    if (x >= t.w) { q++; x -= t.w; }
-    int y = t.y0 + q;
-    if (!in_frame) { x = 0; y = 0; }
+    int x, y;
+    lane_origin(t, x, y);
     float yfac = t.yt[y];
     if (VEC) {
         // w % 8 == 0: the lane's 8 pixels share a row and their columns are 8 consecutive, 32-B aligned table entries
