@@ -56,6 +56,8 @@ def test_nn_matches_oracle_bitexact(gpu, orc, mode):
     for n2 in (63, 64, 65, 128, 129):                                    # query counts around the 64-query group size
         cases.append((rng.uniform(-1, 1, size=(777, 3)).astype(np.float32), rng.uniform(-1.1, 1.1, size=(n2, 3)).astype(np.float32)))
     cases.append((np.full((300, 3), 0.25, np.float32), rng.uniform(-1, 1, size=(200, 3)).astype(np.float32)))   # every target the same point
+    for n1 in (2, 7, 8, 9, 15, 16, 17, 63, 65, 1031):                    # target counts around the brute-force kernel's 8-point steps and slices
+        cases.append((rng.uniform(-1, 1, size=(n1, 3)).astype(np.float32), rng.uniform(-1.1, 1.1, size=(150, 3)).astype(np.float32)))
     for k, (t, q) in enumerate(cases):
         want_i, want_d = orc.nn(t, q, mode="brute", n_threads=8)
         got_i, got_d = _gpu_nn(t, q, mode)
