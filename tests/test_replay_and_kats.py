@@ -87,6 +87,33 @@ def test_cpp_shard_host_one_rank(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_shard_host_two_ranks_on_one_gpu(gpu, tmp_path):
+    """Two C++ ranks as two processes, one sensor each, rendezvous through the id file: the library is pointed at the shared-memory
+    test double of RCCL (tests/fake_rccl; real RCCL refuses two ranks on one device), and BOTH ranks must end up with the golden
+    fixture's merged cloud."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "shard"], stdout=subprocess.DEVNULL)
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(fake), "tests/fake_rccl/libfake_rccl.so is not built (__graft_entry__.build())"
+    env = dict(os.environ, LSN_RCCL_LIBRARY=fake)
+    b = [str(float(x)) for x in synth.CROP_BOUNDS]
+    procs = [subprocess.Popen([os.path.join(ROOT, "examples", "shard"), os.path.join(GOLD, "replay_scene_2x96x80.bin"), "--rank", str(r), "--world", "2",
+                               "--device", "0", "--id-file", str(tmp_path / "id.bin"), "--bounds", *b,
+                               "--expect", os.path.join(GOLD, "replay_scene_2x96x80_mesh.bin")],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((pr.returncode, out))
+    for rc, out in outs:
+        assert rc == 0 and "Test PASSED" in out, out
+
+
+@pytest.mark.gpu
 def test_cpp_example_host_replays_the_golden_fixture(gpu):
     """The C++ host (no Python, no torch in the process) drives the exports and compares bit for bit like the
     reference's regression main() (src/NativeUtils/main.cpp:211-245)."""
