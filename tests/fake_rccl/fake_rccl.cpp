@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -51,15 +52,21 @@ namespace {
 thread_local int g_depth = 0;
 thread_local std::vector<std::pair<ncclComm *, Op>> g_queue;
 
-void barrier(ncclComm *c)
+// false: a peer did not arrive within two minutes (it died): the caller reports an error instead of spinning for ever
+bool barrier(ncclComm *c)
 {
     const int gen = c->hdr->generation.load(std::memory_order_acquire);
     if (c->hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->world) {
         c->hdr->arrived.store(0, std::memory_order_relaxed);
         c->hdr->generation.store(gen + 1, std::memory_order_release);
-    } else {
-        while (c->hdr->generation.load(std::memory_order_acquire) == gen) sched_yield();
+        return true;
     }
+    const time_t t0 = time(nullptr);
+    for (unsigned int spins = 0; c->hdr->generation.load(std::memory_order_acquire) == gen; spins++) {
+        sched_yield();
+        if ((spins & 0xFFFF) == 0xFFFF && time(nullptr) - t0 > 120) return false;
+    }
+    return true;
 }
 
 ncclResult_t run(ncclComm *c, const Op &op)
@@ -69,11 +76,11 @@ ncclResult_t run(ncclComm *c, const Op &op)
         const size_t n = op.bytes - off < kSlot ? op.bytes - off : kSlot;
         if (n && hipMemcpy(c->data + (size_t)c->rank * kSlot, (const char *)op.send + off, n, hipMemcpyDeviceToHost) != hipSuccess)
             return ncclUnhandledCudaError;
-        barrier(c);
+        if (!barrier(c)) return ncclSystemError;
         for (int q = 0; q < c->world && n; q++)
             if (hipMemcpy((char *)op.recv + (size_t)q * op.bytes + off, c->data + (size_t)q * kSlot, n, hipMemcpyHostToDevice) != hipSuccess)
                 return ncclUnhandledCudaError;
-        barrier(c);
+        if (!barrier(c)) return ncclSystemError;
         if (op.bytes == 0) break;
     }
     return ncclSuccess;
@@ -118,7 +125,10 @@ extern "C" ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqu
     c->hdr = static_cast<Header *>(p);
     c->data = static_cast<unsigned char *>(p) + 4096;
     c->hdr->attached.fetch_add(1);
-    barrier(c);                                                   // like the real call: returns once every rank has arrived
+    if (!barrier(c)) {                                            // like the real call: returns once every rank has arrived
+        ncclCommDestroy(c);
+        return ncclSystemError;
+    }
     *comm = c;
     return ncclSuccess;
 }
@@ -166,7 +176,7 @@ extern "C" const char *ncclGetErrorString(ncclResult_t r)
     switch (r) {
     case ncclSuccess: return "no error";
     case ncclUnhandledCudaError: return "fake rccl: HIP call failed";
-    case ncclSystemError: return "fake rccl: shared-memory segment unavailable";
+    case ncclSystemError: return "fake rccl: shared-memory segment unavailable, or a peer rank did not arrive";
     case ncclInvalidArgument: return "fake rccl: invalid argument";
     case ncclInvalidUsage: return "fake rccl: invalid usage";
     default: return "fake rccl: error";
