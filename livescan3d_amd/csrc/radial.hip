@@ -253,10 +253,14 @@ struct RingFeed {
     RingChunk p0, p1;
 };
 
+// only_if (nullable): close only the frames whose flag is set -- the fall-back of the two-pass closing below -- and copy the closed
+// frame to out_d / out_c.
 __global__ __launch_bounds__(768) void radial_close_kernel(const FrameDesc *frames, int n_frames, unsigned short *map_copy,
-                                                            unsigned char *colors_copy, long long tick_pix_stride)
+                                                            unsigned char *colors_copy, long long tick_pix_stride, const int *only_if,
+                                                            unsigned short *out_d, unsigned char *out_c)
 {
     extern __shared__ unsigned int ring_mem[];  // colours: (blockDim.x + 2) x kRing u32, then depths: the same count of u16
+    if (only_if && only_if[blockIdx.x] == 0) return;   // uniform over the workgroup
     const int rows = blockDim.x;
     unsigned int *cring = ring_mem;
     unsigned short *dring = reinterpret_cast<unsigned short *>(ring_mem + (rows + 2) * kRing);
@@ -379,6 +383,404 @@ __global__ __launch_bounds__(768) void radial_close_kernel(const FrameDesc *fram
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
     }
+    if (only_if) {
+        __syncthreads();   // every fill has reached the global maps
+        unsigned short *od = out_d + tick * tick_pix_stride + fd.depth_off;
+        unsigned char *oc = out_c + 3 * (tick * tick_pix_stride + fd.depth_off);
+        for (int i = threadIdx.x; i < fd.npix; i += blockDim.x) {
+            od[i] = map[i];
+            oc[3 * i] = col[3 * i];
+            oc[3 * i + 1] = col[3 * i + 1];
+            oc[3 * i + 2] = col[3 * i + 2];
+        }
+    }
+}
+
+
+// ---- hole closing in two passes (the default; LSN_RADIAL_CLOSE=wavefront selects the kernel above) ------------------------
+//
+// Only a hole BEHIND A FILLED PREDECESSOR (up-left, up, up-right, left) depends on the raster order of the reference's in-place
+// loop: everything else sees the un-closed map on all eight sides.  Measured on the CPU restatement (512x424): hash-noise
+// frames fill no hole at all, scene frames 5 376 of 107 807, the longest chain of fills feeding fills is 262.  So:
+//   1. close_first_kernel, streaming: every pixel is copied to the output; every hole is evaluated against the un-closed map
+//      (exact unless one of its predecessors gets filled) and every fill lists its hole successors (right, down-left, down,
+//      down-right) in the frame's work list;
+//   2. close_fix_kernel, one workgroup per frame: re-evaluates the listed holes with their predecessors read from the OUTPUT
+//      (current values) and their successors from the un-closed map; a pixel whose value changes lists its own hole successors
+//      for the next round.  The dependency graph is acyclic (raster order), every change re-triggers its dependants, so the
+//      rounds end -- after at most the longest chain -- in the unique state the sequential loop reaches (:223-256), whatever
+//      the order inside a round.
+// A frame whose lists overflow is closed by the wavefront kernel instead (flag per frame, no host round trip).
+__device__ __forceinline__ void accept_chain(const int (&nb)[8], int &n, int &sum, unsigned int &accepted)
+{
+    n = 0;
+    sum = 0;
+    accepted = 0;
+    int prev_val = -1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const bool ok = (nb[i] > 0) & ((prev_val == -1) | (abs(nb[i] - prev_val) < 30));  // :241
+        prev_val = ok ? nb[i] : prev_val;
+        n += ok ? 1 : 0;
+        sum += ok ? nb[i] : 0;
+        accepted |= (ok ? 1u : 0u) << i;
+    }
+}
+
+// v / n for n = 5..8 and v < 2^20: a float reciprocal and one correction step divide exactly
+__device__ __forceinline__ unsigned int div_small(int v, int n)
+{
+    const float rn = 1.0f / (float)n;
+    int q = (int)((float)v * rn);
+    const int r = v - q * n;
+    q += r >= n ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return (unsigned int)q;
+}
+
+// the average colour of the accepted neighbours (:244-246, :252-255) as 0x00BBGGRR; nc[i] = neighbour i's packed colour
+__device__ __forceinline__ unsigned int average_colour(const unsigned int (&nc)[8], unsigned int accepted, int n)
+{
+    int sR = 0, sG = 0, sB = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const unsigned int c = (accepted >> i) & 1u ? nc[i] : 0u;
+        sR += c & 0xFF; sG += (c >> 8) & 0xFF; sB += (c >> 16) & 0xFF;
+    }
+    return div_small(sR, n) | (div_small(sG, n) << 8) | (div_small(sB, n) << 16);
+}
+
+__device__ __forceinline__ unsigned int load_rgb24(const unsigned char *c) { return c[0] | (c[1] << 8) | (c[2] << 16); }
+
+struct CloseArgs {
+    const FrameDesc *frames;
+    const TileDesc *tiles;
+    const unsigned short *orig_d;   // the warped, un-closed maps
+    const unsigned char *orig_c;
+    unsigned short *out_d;          // the caller's maps: the result
+    unsigned char *out_c;
+    unsigned int *work;             // [n_ticks * n_frames][work_cap] pixel indices inside the frame
+    int *work_cnt;                  // [n_ticks * n_frames] x kCntStride: entries listed (may exceed work_cap: overflow)
+    int *flags;                     // [n_ticks * n_frames] 1 = close this frame with the wavefront kernel
+    int tiles_per_tick, n_frames, work_cap;
+    long long tick_pix_stride;
+};
+
+// orders a wave's LDS writes before its own later LDS reads (other lanes' data), no barrier: one wave, program order
+__device__ __forceinline__ void wave_lds_fence_r()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kDx[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, kDy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};   // the neighbour order of :225
+
+// Appends the wave's entries to the frame's list: one atomicAdd per wave.  `mine` = this lane's count; returns its first slot.
+__device__ __forceinline__ int wave_reserve(int *counter, int mine)
+{
+    const int lane = threadIdx.x & 63;
+    const int incl = wave_inclusive_scan(mine, lane);
+    const int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (total > 0) {
+        if (lane == 0) base = atomicAdd(counter, total);
+        base = __shfl(base, 0, 64);
+    }
+    return base + incl - mine;
+}
+
+// The same for a whole workgroup (every thread must call it): one atomicAdd per workgroup -- a frame's tiles run side by side
+// and all append to the frame's one counter.
+__device__ __forceinline__ int block_reserve(int *counter, int mine, int *s /* [8] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_inclusive_scan(mine, lane);
+    if (lane == 63) s[wave] = incl;
+    __syncthreads();
+    const int total = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) s[4] = total > 0 ? atomicAdd(counter, total) : 0;
+    __syncthreads();
+    int off = s[4];
+    for (int i = 0; i < wave; i++) off += s[i];
+    return off + incl - mine;
+}
+
+constexpr int kCntStride = 32;   // ints between two frames' counters: one 128-byte line each (atomics on one line serialise in its L2 channel)
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void close_first_kernel(const CloseArgs a)
+{
+    __shared__ int s_res[16];
+    const int tick = blockIdx.x / a.tiles_per_tick;
+    const int tile = blockIdx.x - tick * a.tiles_per_tick;
+    const TileDesc td = a.tiles[tile];
+    const FrameDesc fd = a.frames[td.frame];
+    const int w = fd.w, h = fd.h;
+    const long long fb = tick * a.tick_pix_stride + fd.depth_off;
+    const int tf = tick * a.n_frames + td.frame;
+    unsigned int *work = a.work + (long long)tf * a.work_cap;
+    const int p0 = (tile - fd.tile_start) * kTile + (int)threadIdx.x * kPxPerLane;
+    const bool in_frame = p0 < fd.npix;
+    __shared__ unsigned int s_fill[VEC ? kThreads / 64 : 1][VEC ? 64 * kPxPerLane : 1];   // a wave's fills: pixel | accepted << 24, then their colours
+    unsigned int own_c[6] = {0, 0, 0, 0, 0, 0};   // the lane's 24-byte colour group (VEC)
+    unsigned int push[kPxPerLane];   // per pixel: bit s = successor s (right, down-left, down, down-right) goes on the list
+    unsigned int fill[kPxPerLane];   // per pixel: the accepted-neighbour mask of a fill (0: not filled; a fill accepts >= 5)
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) push[k] = fill[k] = 0;
+    int px[kPxPerLane], py[kPxPerLane];
+    if (VEC) {
+        // w % 8 == 0: the lane's 8 pixels share a row; rows y-1 .. y+1, columns x0-1 .. x0+8 live in registers
+        const int v = td.x0 + (int)threadIdx.x * kPxPerLane;
+        int q = (int)((float)v * fd.inv_w);
+        int x0 = v - q * w;
+        if (x0 < 0) { q--; x0 += w; }
+        if (x0 >= w) { q++; x0 -= w; }
+        const int y = td.y0 + q;
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) { px[k] = x0 + k; py[k] = y; }
+        if (in_frame) {
+            int D[3][kPxPerLane + 2];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int yy = y - 1 + r;
+                const bool row_in = yy >= 0 && yy < h;
+                const unsigned short *row = a.orig_d + fb + (long long)(row_in ? yy : y) * w;
+                uint4 c = *reinterpret_cast<const uint4 *>(row + x0);
+                unsigned int left = x0 > 0 ? row[x0 - 1] : 0u, right = x0 + 8 < w ? row[x0 + 8] : 0u;
+                if (!row_in) { c = make_uint4(0, 0, 0, 0); left = right = 0; }
+                const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
+                D[r][0] = (int)left;
+#pragma unroll
+                for (int k = 0; k < kPxPerLane; k++) D[r][1 + k] = (int)((cw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+                D[r][kPxPerLane + 1] = (int)right;
+            }
+            const long long pos0 = fb + (long long)y * w + x0;
+            const uint2 *cp = reinterpret_cast<const uint2 *>(a.orig_c + 3 * pos0);
+            const uint2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+            unsigned int cw[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
+            unsigned int od[kPxPerLane];
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) od[k] = (unsigned int)D[1][k + 1];
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) {
+                const int x = x0 + k;
+                if (D[1][k + 1] == 0 && y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {                 // :229-234
+                    const int nb[8] = {D[0][k], D[0][k + 1], D[0][k + 2], D[1][k], D[1][k + 2], D[2][k], D[2][k + 1], D[2][k + 2]};
+                    int n, sum;
+                    unsigned int accepted;
+                    accept_chain(nb, n, sum, accepted);
+                    if (n > 4) {                                                                       // :250-256
+                        od[k] = div_small(sum, n);
+                        fill[k] = accepted;   // the colour average follows below, for all the wave's fills at once
+                        // its hole successors now depend on the order: onto the list (interior pixels only, :223-224)
+                        const bool below = y + 1 < h - 1;
+                        push[k] = ((D[1][k + 2] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((D[2][k] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
+                                  ((D[2][k + 1] == 0 && below) ? 4u : 0u) | ((D[2][k + 2] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.out_d + pos0) = make_uint4(od[0] | (od[1] << 16), od[2] | (od[3] << 16), od[4] | (od[5] << 16), od[6] | (od[7] << 16));
+            own_c[0] = cw[0]; own_c[1] = cw[1]; own_c[2] = cw[2]; own_c[3] = cw[3]; own_c[4] = cw[4]; own_c[5] = cw[5];
+        }
+        // The fills' colours.  A wave's fills (a handful, spread over its lanes and over the 8 pixels of a lane) are handed out one
+        // per lane through LDS, so all their neighbour colours are fetched in ONE round trip (evaluated where they arise, the
+        // wave would wait for a load eight times over); the averages come back the same way and are patched into the owners'
+        // 24-byte colour groups before those are stored.
+        {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            unsigned int *mine_l = s_fill[wave];
+            int n_fill = 0;
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) n_fill += fill[k] ? 1 : 0;
+            const int incl = wave_inclusive_scan(n_fill, lane);
+            const int total = __shfl(incl, 63, 64);
+            int slot = incl - n_fill;
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++)
+                if (fill[k]) mine_l[slot++] = (unsigned int)(py[k] * w + px[k]) | (fill[k] << 24);
+            wave_lds_fence_r();
+            for (int i = lane; i < total; i += 64) {
+                const unsigned int e = mine_l[i];
+                const int p = (int)(e & 0xFFFFFFu);
+                const unsigned int accepted = e >> 24;
+                unsigned int nc[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) nc[j] = (accepted >> j) & 1u ? load_rgb24(a.orig_c + 3 * (fb + p + kDy[j] * w + kDx[j])) : 0u;
+                mine_l[i] = average_colour(nc, accepted, __popc(accepted));
+            }
+            wave_lds_fence_r();
+            slot = incl - n_fill;
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) {
+                if (fill[k]) {
+                    const unsigned int rgb = mine_l[slot++];
+                    // the pixel's three bytes start at byte 3k of the lane's 24-byte group
+                    const int b = 3 * k, wi = b >> 2, sh = (b & 3) * 8;
+                    const unsigned long long m = 0xFFFFFFull << sh, v = (unsigned long long)rgb << sh;
+                    own_c[wi] = (own_c[wi] & ~(unsigned int)m) | (unsigned int)v;
+                    if (wi + 1 < 6 && (m >> 32)) own_c[wi + 1] = (own_c[wi + 1] & ~(unsigned int)(m >> 32)) | (unsigned int)(v >> 32);
+                }
+            }
+        }
+        if (in_frame) {
+            uint2 *op = reinterpret_cast<uint2 *>(a.out_c + 3 * (fb + (long long)py[0] * w + px[0]));
+            op[0] = make_uint2(own_c[0], own_c[1]);
+            op[1] = make_uint2(own_c[2], own_c[3]);
+            op[2] = make_uint2(own_c[4], own_c[5]);
+        }
+    } else {
+        // any width: pixel by pixel
+#pragma unroll
+        for (int k = 0; k < kPxPerLane; k++) {
+            const int p = p0 + k;
+            px[k] = py[k] = 0;
+            if (p >= fd.npix) continue;
+            const int y = p / w, x = p - y * w;
+            px[k] = x; py[k] = y;
+            const long long pos = fb + p;
+            unsigned int d = a.orig_d[pos], rgb = load_rgb24(a.orig_c + 3 * pos);
+            if (d == 0 && y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
+                int nb[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) nb[i] = a.orig_d[pos + kDy[i] * w + kDx[i]];
+                int n, sum;
+                unsigned int accepted;
+                accept_chain(nb, n, sum, accepted);
+                if (n > 4) {
+                    unsigned int nc[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) nc[i] = (accepted >> i) & 1u ? load_rgb24(a.orig_c + 3 * (pos + kDy[i] * w + kDx[i])) : 0u;
+                    d = div_small(sum, n);
+                    rgb = average_colour(nc, accepted, n);
+                    const bool below = y + 1 < h - 1;
+                    push[k] = ((nb[4] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((nb[5] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
+                              ((nb[6] == 0 && below) ? 4u : 0u) | ((nb[7] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
+                }
+            }
+            a.out_d[pos] = (unsigned short)d;
+            a.out_c[3 * pos] = (unsigned char)rgb;
+            a.out_c[3 * pos + 1] = (unsigned char)(rgb >> 8);
+            a.out_c[3 * pos + 2] = (unsigned char)(rgb >> 16);
+        }
+    }
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) mine += __popc(push[k]);
+    int slot = block_reserve(a.work_cnt + kCntStride * tf, mine, s_res);
+#pragma unroll
+    for (int k = 0; k < kPxPerLane; k++) {
+#pragma unroll
+        for (int sidx = 0; sidx < 4; sidx++) {
+            if ((push[k] >> sidx) & 1u) {
+                const int i = 4 + sidx;   // neighbours 4..7 are the successors
+                if (slot < a.work_cap) work[slot] = (unsigned int)((py[k] + kDy[i]) * w + px[k] + kDx[i]);
+                slot++;
+            }
+        }
+    }
+}
+
+constexpr int kFixList = 4096;   // entries per round list (LDS)
+constexpr int kFixRounds = 1 << 16;
+
+__global__ __launch_bounds__(kThreads) void close_fix_kernel(const CloseArgs a)
+{
+    __shared__ unsigned int lists[2][kFixList];
+    __shared__ int s_n[2];
+    __shared__ int s_overflow;
+    const int tf = blockIdx.x;
+    const int tick = tf / a.n_frames, f = tf - tick * a.n_frames;
+    const FrameDesc fd = a.frames[f];
+    const int w = fd.w, h = fd.h;
+    const long long fb = tick * a.tick_pix_stride + fd.depth_off;
+    const unsigned short *orig_d = a.orig_d + fb;
+    const unsigned char *orig_c = a.orig_c + 3 * fb;
+    // written and re-read by the waves of this workgroup only, a round apart: they share the CU's L1, and the barrier between two
+    // rounds (workgroup-scope release / acquire) orders the accesses -- no cache bypass needed
+    unsigned short *out_d = a.out_d + fb;
+    unsigned char *out_c = a.out_c + 3 * fb;
+    const int n0 = a.work_cnt[kCntStride * tf];
+    if (threadIdx.x == 0) {
+        s_n[0] = s_n[1] = 0;
+        s_overflow = n0 > a.work_cap ? 1 : 0;
+        a.flags[tf] = 0;
+    }
+    __syncthreads();
+    const unsigned int *glist = a.work + (long long)tf * a.work_cap;
+    int cur = 0;   // lists[cur] is read, lists[1 - cur] is filled; round 0 reads the global list instead
+    for (int round = 0; !s_overflow; round++) {
+        const int n_items = round == 0 ? n0 : s_n[cur];
+        if (n_items == 0) break;
+        if (round >= kFixRounds) {   // cannot happen (the chains are finite); never leave a frame half closed
+            if (threadIdx.x == 0) s_overflow = 1;
+            __syncthreads();
+            break;
+        }
+        for (int i0 = 0; i0 < n_items; i0 += kThreads) {
+            const int i = i0 + (int)threadIdx.x;
+            int mine = 0;
+            unsigned int succ = 0;
+            int x = 0, y = 0;
+            if (i < n_items) {
+                const int p = (int)(round == 0 ? glist[i] : lists[cur][i]);
+                y = p / w;
+                x = p - y * w;
+                // predecessors (neighbours 0..3) as they are now, successors (4..7) as the sequential loop would still see them
+                int nb[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) nb[k] = out_d[p + kDy[k] * w + kDx[k]];
+#pragma unroll
+                for (int k = 4; k < 8; k++) nb[k] = orig_d[p + kDy[k] * w + kDx[k]];
+                // every colour the verdict may need is fetched together with the depths (one memory round trip per round, not two)
+                unsigned int nc[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long long q = 3 * (long long)(p + kDy[k] * w + kDx[k]);
+                    nc[k] = (unsigned int)out_c[q] | ((unsigned int)out_c[q + 1] << 8) | ((unsigned int)out_c[q + 2] << 16);
+                }
+#pragma unroll
+                for (int k = 4; k < 8; k++) nc[k] = load_rgb24(orig_c + 3 * (long long)(p + kDy[k] * w + kDx[k]));
+                const unsigned int od = out_d[p];
+                const unsigned int orgb = (unsigned int)out_c[3 * (long long)p] | ((unsigned int)out_c[3 * (long long)p + 1] << 8) |
+                                          ((unsigned int)out_c[3 * (long long)p + 2] << 16);
+                unsigned int nd = 0, nrgb = load_rgb24(orig_c + 3 * (long long)p);   // an unfilled hole keeps what the warp left (:250)
+                int n, sum;
+                unsigned int accepted;
+                accept_chain(nb, n, sum, accepted);
+                if (n > 4) {
+                    nd = div_small(sum, n);
+                    nrgb = average_colour(nc, accepted, n);
+                }
+                if (nd != od || nrgb != orgb) {
+                    out_d[p] = (unsigned short)nd;
+                    out_c[3 * (long long)p] = (unsigned char)nrgb;
+                    out_c[3 * (long long)p + 1] = (unsigned char)(nrgb >> 8);
+                    out_c[3 * (long long)p + 2] = (unsigned char)(nrgb >> 16);
+                    const bool below = y + 1 < h - 1;
+                    succ = ((nb[4] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((nb[5] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
+                           ((nb[6] == 0 && below) ? 4u : 0u) | ((nb[7] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
+                    mine = __popc(succ);
+                }
+            }
+            int slot = wave_reserve(&s_n[1 - cur], mine);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; sidx++) {
+                if ((succ >> sidx) & 1u) {
+                    const int k = 4 + sidx;
+                    if (slot < kFixList) lists[1 - cur][slot] = (unsigned int)((y + kDy[k]) * w + x + kDx[k]);
+                    else s_overflow = 1;
+                    slot++;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();   // this round's writes are in place before the next round reads them
+        cur = 1 - cur;
+        if (threadIdx.x == 0) s_n[1 - cur] = 0;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_overflow) a.flags[tf] = 1;
 }
 
 }  // namespace
@@ -452,9 +854,47 @@ extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, vo
         const int v = atoi(env);
         if (v >= 64 && v <= 768 && v % 64 == 0) rows = v;
     }
-    hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)(p->n_maps * p->n_ticks)), dim3(rows), (sizeof(unsigned int) + sizeof(unsigned short)) * kRing * (rows + 2), s,
-                       p->frames.as<FrameDesc>(), p->n_maps,
-                       p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap);
+    const size_t ring_bytes = (sizeof(unsigned int) + sizeof(unsigned short)) * kRing * (rows + 2);
+    const int n_tf = p->n_maps * p->n_ticks;
+    // Two-pass closing: its work lists live in `winner` (free once the gather is done): counters, flags, then work_cap entries per frame
+    static const bool wavefront_only = getenv("LSN_RADIAL_CLOSE") && !strcmp(getenv("LSN_RADIAL_CLOSE"), "wavefront");
+    static const bool tiny_lists = getenv("LSN_RADIAL_TINY_LISTS") && atoi(getenv("LSN_RADIAL_TINY_LISTS")) != 0;   // tests: force the fall-back
+    long long work_cap = ((long long)npix - (kCntStride + 1ll) * n_tf - 64) / n_tf;
+    if (work_cap > 16384) work_cap = 16384;
+    if (tiny_lists && work_cap > 8) work_cap = 8;
+    long long max_npix = 0;
+    for (int i = 0; i < p->n_maps; i++) max_npix = std::max(max_npix, (long long)p->w[i] * p->h[i]);
+    // (a wave's fill entries carry the pixel index in 24 bits)
+    if (!wavefront_only && work_cap >= 8 && max_npix < (1ll << 24)) {
+        CloseArgs ca;
+        ca.frames = p->frames.as<FrameDesc>();
+        ca.tiles = p->tile_frame.as<TileDesc>();
+        ca.orig_d = p->map_copy.as<unsigned short>();
+        ca.orig_c = p->colors_copy.as<unsigned char>();
+        ca.out_d = static_cast<unsigned short *>(d_depth);
+        ca.out_c = static_cast<unsigned char *>(d_colors);
+        ca.work_cnt = p->winner.as<int>();
+        ca.flags = ca.work_cnt + (size_t)kCntStride * n_tf;
+        ca.work = p->winner.as<unsigned int>() + ((size_t)kCntStride + 1) * n_tf + 64;
+        ca.tiles_per_tick = p->tiles_per_tick;
+        ca.n_frames = p->n_maps;
+        ca.work_cap = (int)work_cap;
+        ca.tick_pix_stride = p->cap;
+        LSN_HIP(hipMemsetAsync(ca.work_cnt, 0, sizeof(int) * kCntStride * (size_t)n_tf, s));
+        const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && (p->cap % 8) == 0;
+        if (vec) hipLaunchKernelGGL(close_first_kernel<true>, dim3(grid), dim3(kThreads), 0, s, ca);
+        else     hipLaunchKernelGGL(close_first_kernel<false>, dim3(grid), dim3(kThreads), 0, s, ca);
+        hipLaunchKernelGGL(close_fix_kernel, dim3((unsigned)n_tf), dim3(kThreads), 0, s, ca);
+        // frames whose lists overflowed (flag set by close_fix_kernel): the ordered pass on the un-closed maps, copied out
+        hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)n_tf), dim3(rows), ring_bytes, s, p->frames.as<FrameDesc>(), p->n_maps,
+                           p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap, (const int *)ca.flags,
+                           static_cast<unsigned short *>(d_depth), static_cast<unsigned char *>(d_colors));
+        LSN_HIP(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)n_tf), dim3(rows), ring_bytes, s, p->frames.as<FrameDesc>(), p->n_maps,
+                       p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap, (const int *)nullptr,
+                       (unsigned short *)nullptr, (unsigned char *)nullptr);
     LSN_HIP(hipGetLastError());
     // :259-260 the corrected maps replace the inputs
     LSN_HIP(hipMemcpyAsync(d_depth, p->map_copy.p, 2 * npix, hipMemcpyDeviceToDevice, s));
