@@ -479,18 +479,32 @@ def main():
     # ---- radial correction, the step before the merge call on every tick (extra field) ---------------------------
     if rank == 0 and not multi and not args.no_mesh:
         with leg(result, "radial_correction"):
-            d2, c2 = depth.clone(), rgb.clone()
             intr_loc = intr_all[7 * s0:7 * (s0 + S_loc)]
-            fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
-            torch.cuda.synchronize()
-            d2.copy_(depth); c2.copy_(rgb)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
-            torch.cuda.synchronize()
-            result["radial_correction"] = {"frames_per_s": B / (time.perf_counter() - t0),
-                                           "note": "depthMapAndColorSetRadialCorrection on the same ticks, HBM resident, one pass"}
-            del d2, c2
+
+            def radial_ms(d_src, c_src):
+                d2, c2 = d_src.clone(), c_src.clone()
+                best = float("inf")
+                for _ in range(4):                      # the first call builds the warp table of the calibration
+                    d2.copy_(d_src); c2.copy_(c_src)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fus.plan.radial_correct(intr_loc, d2.data_ptr(), c2.data_ptr(), stream)
+                    torch.cuda.synchronize()
+                    best = min(best, time.perf_counter() - t0)
+                return 1e3 * best
+
+            ms_noise = radial_ms(depth, rgb)
+            # ray-cast scene frames (8 distinct ticks, repeated): coherent surfaces and invalid regions, where the hole closing
+            # actually fills pixels (on hash noise it never does: no five neighbours within 30 mm of each other)
+            rigs_s = [synth.make_rig("scene", S_loc, w, h, seed=4, tick=k) for k in range(8)]
+            d_s = torch.from_numpy(np.stack([rigs_s[k % 8].depth_maps.view(np.int16) for k in range(B)])).to(dev)
+            c_s = torch.from_numpy(np.stack([rigs_s[k % 8].depth_colors for k in range(B)])).to(dev)
+            ms_scene = radial_ms(d_s, c_s)
+            result["radial_correction"] = {"frames_per_s": B / (1e-3 * ms_noise), "ms_per_step": ms_noise,
+                                           "scene_frames": {"frames_per_s": B / (1e-3 * ms_scene), "ms_per_step": ms_scene},
+                                           "note": "depthMapAndColorSetRadialCorrection on the same ticks, HBM resident, best of 4; "
+                                                   "scene_frames: the same on ray-cast scene frames"}
+            del d_s, c_s
 
     # ---- outbound formats of one tick's mesh, built in HBM (extra field) -----------------------------------------
     if rank == 0 and not multi and not args.no_mesh:
