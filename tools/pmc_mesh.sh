@@ -18,7 +18,7 @@ for d in sorted(glob.glob("$out/*/")):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if not any(s in k for s in ("tri_kernel", "radial_", "fuse_kernel", "count_thr")): continue
+            if not any(s in k for s in ("tri_kernel", "radial_", "close_", "fuse_kernel", "count_thr")): continue
             name = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
