@@ -857,8 +857,10 @@ extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, vo
     const size_t ring_bytes = (sizeof(unsigned int) + sizeof(unsigned short)) * kRing * (rows + 2);
     const int n_tf = p->n_maps * p->n_ticks;
     // Two-pass closing: its work lists live in `winner` (free once the gather is done): counters, flags, then work_cap entries per frame
-    static const bool wavefront_only = getenv("LSN_RADIAL_CLOSE") && !strcmp(getenv("LSN_RADIAL_CLOSE"), "wavefront");
-    static const bool tiny_lists = getenv("LSN_RADIAL_TINY_LISTS") && atoi(getenv("LSN_RADIAL_TINY_LISTS")) != 0;   // tests: force the fall-back
+    // (read on every call, like LSN_RADIAL_FORCE_ATOMIC: the tests switch them inside one process)
+    const char *close_env = getenv("LSN_RADIAL_CLOSE"), *tiny_env = getenv("LSN_RADIAL_TINY_LISTS");
+    const bool wavefront_only = close_env && !strcmp(close_env, "wavefront");
+    const bool tiny_lists = tiny_env && atoi(tiny_env) != 0;   // tests: force the fall-back
     long long work_cap = ((long long)npix - (kCntStride + 1ll) * n_tf - 64) / n_tf;
     if (work_cap > 16384) work_cap = 16384;
     if (tiny_lists && work_cap > 8) work_cap = 8;

@@ -108,6 +108,35 @@ def test_both_warp_paths_agree_with_the_oracle(gpu, orc, monkeypatch):
         assert np.array_equal(np.asarray(got_c).ravel(), np.asarray(want_c).ravel()), forced
 
 
+@pytest.mark.parametrize("env", [{}, {"LSN_RADIAL_TINY_LISTS": "1"}, {"LSN_RADIAL_CLOSE": "wavefront"}],
+                         ids=["two-pass", "two-pass-overflow-fallback", "wavefront"])
+def test_hole_closing_paths_agree_with_the_oracle(gpu, orc, monkeypatch, env):
+    """The two-pass hole closing (streaming first pass + per-frame re-evaluation rounds), its per-frame fall-back when a frame's work
+    list overflows (forced with tiny lists: the ordered wavefront kernel runs for the flagged frames and copies them out) and the
+    wavefront kernel alone: scene frames (thousands of fills, chains of fills feeding fills), a ragged rig (the pixel-by-pixel first
+    pass) and a batch through the device-resident entry point."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for rig in (synth.make_rig("scene", 3, 512, 424, seed=21), synth.make_rig("scene", 2, 250, 120, seed=22), synth.make_rig("noise", 2, 128, 96, seed=23)):
+        want_d, want_c = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+        got_d, got_c = native.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+        assert np.array_equal(np.asarray(got_d).view(np.uint8).ravel(), np.asarray(want_d).view(np.uint8).ravel())
+        assert np.array_equal(np.asarray(got_c).ravel(), np.asarray(want_c).ravel())
+    T, N, w, h = 5, 4, 256, 212
+    rigs = [synth.make_rig("scene", N, w, h, seed=24, tick=k) for k in range(T)]
+    plan = native.FusionPlan(0, T, rigs[0].widths, rigs[0].heights)
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda()
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()
+    plan.radial_correct(rigs[0].intr, depth.data_ptr(), rgb.data_ptr(), int(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got_d, got_c = depth.cpu().numpy().view(np.uint8), rgb.cpu().numpy()
+    for k in range(T):
+        want_d, want_c = orc.radial_correction(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, rigs[0].intr)
+        assert np.array_equal(got_d[k], np.asarray(want_d).view(np.uint8).ravel()), f"tick {k}: depth"
+        assert np.array_equal(got_c[k], np.asarray(want_c).ravel()), f"tick {k}: colours"
+
+
 def test_more_frames_than_compute_units(gpu, orc):
     """With more than 256 sensor-frames in a batch the hole-closing kernel switches to 256-row bands (two bands for h = 424,
     three frames per CU); a 1024-row frame needs two 768-row bands.  Every frame against the oracle."""
