@@ -122,6 +122,24 @@ __global__ __launch_bounds__(kThreads) void radial_cand_sort_kernel(uint4 *cand,
     cand[i] = c;
 }
 
+// Aligned copy of n bytes that sit in LDS at lds[lead ..), lead = (address of dst) mod 16, to dst: whole 16-byte chunks as one store
+// each, the ragged ends element by element (the twin of store_run in exchange.hip).
+template <int ELEM, typename T>
+__device__ __forceinline__ void store_tile_run(T *dst, const T *lds, int lead, int n)
+{
+    static_assert(sizeof(T) == ELEM, "element size");
+    const int end = lead + n;
+    const int c0 = lead ? 1 : 0, c1 = end >> 4;
+    uint4 *g16 = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(dst) - lead);
+    const uint4 *l16 = reinterpret_cast<const uint4 *>(lds);
+    for (int j = c0 + (int)threadIdx.x; j < c1; j += kThreads) g16[j] = l16[j];
+    const int head = lead ? min(n, 16 - lead) : 0;
+    const int tail0 = max(head, 16 * c1 - lead);
+    const int t = (int)threadIdx.x * ELEM;
+    if (t < head) dst[threadIdx.x] = lds[lead / ELEM + threadIdx.x];
+    if (tail0 + t < n) dst[tail0 / ELEM + threadIdx.x] = lds[(lead + tail0) / ELEM + threadIdx.x];
+}
+
 __global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const FrameDesc *__restrict__ frames, const TileDesc *__restrict__ tiles,
                                                                       const unsigned short *__restrict__ depth, const unsigned char *__restrict__ rgb,
                                                                       const uint4 *__restrict__ cand, unsigned short *__restrict__ map_copy,
@@ -133,6 +151,12 @@ __global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const Fram
     const FrameDesc fd = frames[td.frame];
     const long long fb = tick * tick_pix_stride + fd.depth_off;
     const int p0 = (tile - fd.tile_start) * kTile;
+    // the tile's results are staged in LDS and leave as 16-byte stores (four narrow stores per pixel before)
+    __shared__ alignas(16) unsigned short s_d[kTile + 8];
+    __shared__ alignas(16) unsigned char s_c[3 * kTile + 16];
+    unsigned short *gd = map_copy + fb + p0;
+    unsigned char *gc = colors_copy + 3 * (fb + p0);
+    const int lead_d = (int)(reinterpret_cast<uintptr_t>(gd) & 15), lead_c = (int)(reinterpret_cast<uintptr_t>(gc) & 15);
     // A pixel is a chain of three dependent loads (candidates -> their depths -> the winner's colour); the kernel is bound by
     // that latency (PMC: 87 % of the wave-cycles waiting), so a thread keeps FOUR pixels in flight: all candidate loads, then
     // all depth loads, then all colour loads (the restrict qualifiers let the compiler keep them that way).
@@ -175,13 +199,18 @@ __global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const Fram
 #pragma unroll
         for (int k = 0; k < kFly; k++) {
             if (!in[k]) continue;
-            const long long q = fb + p0 + i0 + k * kThreads;
-            map_copy[q] = d[k];
-            colors_copy[3 * q] = r0[k];
-            colors_copy[3 * q + 1] = r1[k];
-            colors_copy[3 * q + 2] = r2[k];
+            const int i = i0 + k * kThreads;
+            s_d[lead_d / 2 + i] = d[k];
+            unsigned char *c3 = s_c + lead_c + 3 * i;
+            c3[0] = r0[k];
+            c3[1] = r1[k];
+            c3[2] = r2[k];
         }
     }
+    __syncthreads();
+    const int n_px = min(kTile, fd.npix - p0);
+    store_tile_run<2>(gd, s_d, lead_d, 2 * n_px);
+    store_tile_run<1>(gc, s_c, lead_c, 3 * n_px);
 }
 
 // One workgroup per sensor-frame, one thread per row (bands of blockDim rows when h is larger).  At step t the thread of
