@@ -710,7 +710,7 @@ __global__ __launch_bounds__(kThreads) void close_first_kernel(const CloseArgs a
     }
 }
 
-constexpr int kFixList = 4096;   // entries per round list (LDS)
+constexpr int kFixList = 8192;   // entries per round list (LDS, two lists: 64 KB -- a few scene frames listed more than 4096 in a round)
 constexpr int kFixRounds = 1 << 16;
 
 __global__ __launch_bounds__(kThreads) void close_fix_kernel(const CloseArgs a)
