@@ -538,7 +538,7 @@ __device__ __forceinline__ int block_reserve(int *counter, int mine, int *s /* [
 constexpr int kCntStride = 32;   // ints between two frames' counters: one 128-byte line each (atomics on one line serialise in its L2 channel)
 
 template <bool VEC>
-__global__ __launch_bounds__(kThreads) void close_first_kernel(const CloseArgs a)
+__global__ __launch_bounds__(kThreads, 8) void close_first_kernel(const CloseArgs a)
 {
     __shared__ int s_res[16];
     const int tick = blockIdx.x / a.tiles_per_tick;
