@@ -145,7 +145,7 @@ __device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerL
 
 // MODE 0 = count triangles per tile, 1 = write them at the scanned offsets.
 template <int MODE, bool VEC>
-__global__ __launch_bounds__(kThreads) void tri_kernel(const TriArgs a)
+__global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const TriArgs a)
 {
     __shared__ int stage[MODE == 1 ? 3 * kTriWin : 1];
     __shared__ int s_wave_tot[4];
