@@ -459,22 +459,33 @@ def main():
             tri = torch.empty((B, 2 * cap, 3), dtype=torch.int32, device=dev)
             toff = torch.zeros((B, S_loc + 1), dtype=torch.int32, device=dev)
 
-            def mesh_step():
-                fus.plan.run_mesh(depth.data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(), tri.data_ptr(),
-                                  toff.data_ptr(), stream)
-            for _ in range(2):
-                mesh_step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(max(3, args.steps // 4)):
-                mesh_step()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            result["mesh"] = {"frames_per_s": B * max(3, args.steps // 4) / dt,
-                              "triangles_per_tick": float(toff[:, -1].float().mean().item()),
+            def mesh_rate(d_in, c_in, plan_obj):
+                def mesh_step():
+                    plan_obj.plan.run_mesh(d_in.data_ptr(), c_in.data_ptr(), plan_obj.vertices.data_ptr(), plan_obj.offsets.data_ptr(), tri.data_ptr(),
+                                           toff.data_ptr(), stream)
+                for _ in range(2):
+                    mesh_step()
+                torch.cuda.synchronize()
+                n_rep = max(3, args.steps // 4)
+                t0 = time.perf_counter()
+                for _ in range(n_rep):
+                    mesh_step()
+                torch.cuda.synchronize()
+                return B * n_rep / (time.perf_counter() - t0), float(toff[:, -1].float().mean().item())
+
+            rate_n, tri_n = mesh_rate(depth, rgb, fus)
+            # the same on ray-cast scene frames (8 distinct ticks, repeated): coherent surfaces, ~1.6 M triangles per tick
+            rigs_m = [synth.make_rig("scene", S_loc, w, h, seed=4, tick=k) for k in range(8)]
+            d_m = torch.from_numpy(np.stack([rigs_m[k % 8].depth_maps.view(np.int16) for k in range(B)])).to(dev)
+            c_m = torch.from_numpy(np.stack([rigs_m[k % 8].depth_colors for k in range(B)])).to(dev)
+            fus_m = DeviceFusion(B, [w] * S_loc, [h] * S_loc, device=dev_index, mode=0)
+            fus_m.set_params(rigs_m[0].intr, rigs_m[0].wt, rigs_m[0].bounds)
+            rate_s, tri_s = mesh_rate(d_m, c_m, fus_m)
+            result["mesh"] = {"frames_per_s": rate_n, "triangles_per_tick": tri_n,
+                              "scene_frames": {"frames_per_s": rate_s, "triangles_per_tick": tri_s},
                               "note": "vertices + triangulation (meshGenerator.cpp) per tick on the same noise inputs; hash-noise depth "
-                                      "exercises every rejection branch but yields few triangles"}
-            del tri, toff
+                                      "exercises every rejection branch but yields few triangles; scene_frames: ray-cast scene frames"}
+            del tri, toff, d_m, c_m, fus_m
 
     # ---- radial correction, the step before the merge call on every tick (extra field) ---------------------------
     if rank == 0 and not multi and not args.no_mesh:

@@ -194,7 +194,20 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
     } else if (VEC) {
         // w % 8 == 0: the 8 pixels share row y0; window rows y0-2 .. y0+1, columns x0-1 .. x0+9
         const bool row_ok = in_frame && y0 >= 2 && y0 < h - 2;   // :87-90 (bands clamp to [2, h-2))
-        if (row_ok) {
+        bool any_vertex = false;   // a pixel without a vertex emits nothing (:113-114): a lane whose 8 pixels have none skips the stencils --
+        if (row_ok) {               // on real frames whole rows outside the crop box do, i.e. whole waves
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int *mrow = map + (long long)(y0 - 1 + r) * w + x0;
+                const int4 m0 = reinterpret_cast<const int4 *>(mrow)[0], m1 = reinterpret_cast<const int4 *>(mrow)[1];
+                M[r][0] = m0.x; M[r][1] = m0.y; M[r][2] = m0.z; M[r][3] = m0.w;
+                M[r][4] = m1.x; M[r][5] = m1.y; M[r][6] = m1.z; M[r][7] = m1.w;
+                M[r][8] = x0 + 8 < w ? mrow[8] : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < kPxPerLane; k++) any_vertex |= M[1][k] != -1;
+        }
+        if (any_vertex) {
             int D[4][kPxPerLane + 3];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -208,14 +221,6 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
                 if (x0 + 8 < w) right = *reinterpret_cast<const unsigned int *>(row + x0 + 8);
                 D[r][9] = right & 0xFFFFu;
                 D[r][10] = right >> 16;
-            }
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int *mrow = map + (long long)(y0 - 1 + r) * w + x0;
-                const int4 m0 = reinterpret_cast<const int4 *>(mrow)[0], m1 = reinterpret_cast<const int4 *>(mrow)[1];
-                M[r][0] = m0.x; M[r][1] = m0.y; M[r][2] = m0.z; M[r][3] = m0.w;
-                M[r][4] = m1.x; M[r][5] = m1.y; M[r][6] = m1.z; M[r][7] = m1.w;
-                M[r][8] = x0 + 8 < w ? mrow[8] : -1;
             }
             code = lane_triangles(D, M, x0, w);
         }
