@@ -147,7 +147,7 @@ __device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerL
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const TriArgs a)
 {
-    __shared__ int stage[MODE == 1 ? 3 * kTriWin : 1];
+    __shared__ alignas(16) int stage[MODE == 1 ? 3 * kTriWin + 4 : 1];
     __shared__ int s_wave_tot[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -269,6 +269,10 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
 
     // ---- stage in rank order, copy out coalesced (triangles_shifts order, meshGenerator.cpp:101-104) ------------------
     int *dst = a.tri + 3 * (tick * a.tick_tri_stride + base);
+    // the window is staged shifted by the destination's misalignment (0..3 ints; the same for every window: a window is a
+    // multiple of 16 bytes), so that it leaves as whole 16-byte chunks -- 4-byte stores before: scene frames write 1.2 GB of
+    // triangles per 64 ticks
+    const int lead = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);
     const int rank0 = wave_off + incl - cnt;
     for (int w0 = 0; w0 < tile_tot; w0 += kTriWin) {
         int r = rank0 - w0;
@@ -291,9 +295,9 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
                             const int i0 = i == 0 ? mR : (i == 1 ? mR : mP);
                             const int i1 = i == 0 ? mU : (i == 1 ? mUR : (i == 2 ? mUR : mR));
                             const int i2 = i == 0 ? mP : (i == 1 ? mU : (i == 2 ? mU : mUR));
-                            stage[3 * r] = i0;
-                            stage[3 * r + 1] = i1;
-                            stage[3 * r + 2] = i2;
+                            stage[lead + 3 * r] = i0;
+                            stage[lead + 3 * r + 1] = i1;
+                            stage[lead + 3 * r + 2] = i2;
                         }
                         r++;
                     }
@@ -305,8 +309,25 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
             }
         }
         __syncthreads();
-        const int n = 3 * min(kTriWin, tile_tot - w0);
-        for (int i = threadIdx.x; i < n; i += kThreads) __builtin_nontemporal_store(stage[i], &dst[3 * w0 + i]);   // written once
+        const int n = 3 * min(kTriWin, tile_tot - w0);   // ints, at stage[lead ..)
+        int *out = dst + 3 * w0;
+        {
+            const int end = lead + n;                      // in ints, relative to the aligned start of the first chunk
+            const int c0 = lead ? 1 : 0, c1 = end >> 2;     // chunks [c0, c1) are whole
+            int4 *g16 = reinterpret_cast<int4 *>(out - lead);
+            const int4 *l16 = reinterpret_cast<const int4 *>(stage);
+            for (int j = c0 + (int)threadIdx.x; j < c1; j += kThreads) {
+                const int4 v = l16[j];                      // written once, never read again by this launch sequence
+                __builtin_nontemporal_store(v.x, &g16[j].x);
+                __builtin_nontemporal_store(v.y, &g16[j].y);
+                __builtin_nontemporal_store(v.z, &g16[j].z);
+                __builtin_nontemporal_store(v.w, &g16[j].w);
+            }
+            const int head = lead ? min(n, 4 - lead) : 0;   // the ragged ends: the neighbouring tiles own the rest of those chunks
+            const int tail0 = max(head, 4 * c1 - lead);
+            if ((int)threadIdx.x < head) out[threadIdx.x] = stage[lead + threadIdx.x];
+            if (tail0 + (int)threadIdx.x < n) out[tail0 + threadIdx.x] = stage[lead + tail0 + threadIdx.x];
+        }
         __syncthreads();
     }
 }
