@@ -165,6 +165,12 @@ int lsnFusionRunMesh(LsnFusion *plan, const void *d_depth_maps, const void *d_de
 /* Radial correction of n_ticks x n_maps frames in place in HBM (same layouts as lsnFusionRun's inputs);
  * intr_params: host, 7 floats per sensor {cx,cy,fx,fy,r2,r4,r6}. */
 int lsnFusionRadialCorrect(LsnFusion *plan, const float *intr_params, void *d_depth_maps, void *d_depth_colors, void *stream);
+/* The same out of place: the corrected frames go to d_depth_out / d_colors_out, the inputs stay as they are (the reference works
+ * on copies and writes them back at the end, depthprocessing.cpp:193-194,259-260).  This is the cheaper form: the warped, not yet
+ * closed maps then never leave the GPU's local memory (in place they pass through a scratch copy in HBM, because a pixel's source
+ * may lie in rows another workgroup is already overwriting).  Both pointers equal to the inputs = lsnFusionRadialCorrect. */
+int lsnFusionRadialCorrectTo(LsnFusion *plan, const float *intr_params, const void *d_depth_maps, const void *d_depth_colors,
+                             void *d_depth_out, void *d_colors_out, void *stream);
 
 /* Name and average duration (ms, HIP events on the plan's stream) of the dominant kernel over the launches
  * since the last call with reset != 0; used by bench.py's roofline block.  Enable with lsnFusionProfile(plan,1). */

@@ -152,7 +152,7 @@ struct Ctx {
     int *h_off = nullptr, *h_toff = nullptr;   // pinned: the offset tables of the call in progress
     int h_off_cap = 0;
     std::map<std::vector<int>, LsnFusion *> plans;  // key: n_maps, widths..., heights...
-    lsn::DevBuf d_depth, d_colors, d_out, d_off, d_tri, d_tri_off, d_v1, d_v2, d_Rt;
+    lsn::DevBuf d_depth, d_colors, d_depth2, d_colors2, d_out, d_off, d_tri, d_tri_off, d_v1, d_v2, d_Rt;
     LsnIcp *icp = nullptr;
     int icp_n1 = 0, icp_n2 = 0;
     // pinned host blocks handed out as Mesh::vertices, recycled by deleteMesh
@@ -562,23 +562,25 @@ extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *d
         dbytes += (size_t)widths[i] * heights[i] * 2;
         cbytes += (size_t)widths[i] * heights[i] * 3;
     }
-    if (c.d_depth.reserve(dbytes + 16) || c.d_colors.reserve(cbytes + 16)) return;
+    if (c.d_depth.reserve(dbytes + 16) || c.d_colors.reserve(cbytes + 16) || c.d_depth2.reserve(dbytes + 16) || c.d_colors2.reserve(cbytes + 16)) return;
     if (hipMemcpyAsync(c.d_depth.p, depth_maps, dbytes, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
         hipMemcpyAsync(c.d_colors.p, depth_colors, cbytes, hipMemcpyHostToDevice, c.stream) != hipSuccess) {
         lsn::set_error("depthMapAndColorSetRadialCorrection: upload failed: %s", hipGetErrorString(hipGetLastError()));
         return;
     }
-    if (lsnFusionRadialCorrect(plan, intr_params, c.d_depth.p, c.d_colors.p, c.stream)) return;
-    // the caller's arrays are only overwritten once everything has worked
-    std::vector<unsigned char> hd(dbytes), hc(cbytes);
-    if (hipMemcpyAsync(hd.data(), c.d_depth.p, dbytes, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
-        hipMemcpyAsync(hc.data(), c.d_colors.p, cbytes, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+    // out of place on the device (the warped, un-closed maps then stay in LDS); the caller's arrays are only overwritten once
+    // the kernels have run
+    if (lsnFusionRadialCorrectTo(plan, intr_params, c.d_depth.p, c.d_colors.p, c.d_depth2.p, c.d_colors2.p, c.stream)) return;
+    if (hipStreamSynchronize(c.stream) != hipSuccess) {
+        lsn::set_error("depthMapAndColorSetRadialCorrection: the correction failed: %s", hipGetErrorString(hipGetLastError()));
+        return;
+    }
+    if (hipMemcpyAsync(depth_maps, c.d_depth2.p, dbytes, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+        hipMemcpyAsync(depth_colors, c.d_colors2.p, cbytes, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
         hipStreamSynchronize(c.stream) != hipSuccess) {
         lsn::set_error("depthMapAndColorSetRadialCorrection: download failed: %s", hipGetErrorString(hipGetLastError()));
         return;
     }
-    memcpy(depth_maps, hd.data(), dbytes);
-    memcpy(depth_colors, hc.data(), cbytes);
 }
 
 extern "C" Mesh *createMesh(void)

@@ -450,6 +450,10 @@ struct LsnFusion {
     lsn::DevBuf pixmap, tri_counts, tri_codes;  // triangulation scratch, allocated on first use
     lsn::DevBuf winner, map_copy, colors_copy, radial;  // radial-correction scratch, allocated on first use
     lsn::DevBuf cand;                                   // [pixels per tick][4] warp candidates of the current intrinsics
+    lsn::DevBuf ctab;                                   // [pixels per tick] their compact form (one dword per destination)
+    lsn::DevBuf bands, holes, work, work_cnt;           // hole closing: band list, hole bitmap, per-frame work lists and their counters
+    int band_rows = 0, bands_per_tick = 0;              // what `bands` was built for
+    bool band_attr_set = false;
     std::vector<float> radial_intr;                     // the intrinsics `cand` was built for
     bool cand_valid = false, cand_overflow = false;
     // pipelined mode: the count + scan of call k+1 run on a side stream while the write kernel of call k is still busy

@@ -140,9 +140,144 @@ __device__ __forceinline__ void store_tile_run(T *dst, const T *lds, int lead, i
     if (tail0 + t < n) dst[tail0 / ELEM + threadIdx.x] = lds[(lead + tail0) / ELEM + threadIdx.x];
 }
 
-__global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const FrameDesc *__restrict__ frames, const TileDesc *__restrict__ tiles,
-                                                                      const unsigned short *__restrict__ depth, const unsigned char *__restrict__ rgb,
-                                                                      const uint4 *__restrict__ cand, unsigned short *__restrict__ map_copy,
+// ---- the compact warp table ------------------------------------------------------------------------------------------------
+//
+// The candidate table above costs 16 bytes per destination and tick (the 8 x 512x424 rig: 27.8 MB, streamed from the Infinity
+// Cache by every tick -- the round-2 PMC pass showed 2 x 255 MB fetched for 139 MB of frames).  A radial map moves a pixel by
+// a few columns / rows, and almost every destination has one or two sources, so the table the ticks read is ONE dword per
+// destination: two candidates as (dx + 128) | (dy + 128) << 8 in 16 bits each, 0 = none, highest source index first.  A
+// destination with three or four sources, or one further than 127 pixels away, holds kWide and is looked up in the full table
+// (a handful of pixels per frame for Kinect-like intrinsics).  6.9 MB for the 8-sensor rig: it stays in the L2s.
+constexpr unsigned int kWide = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kThreads) void radial_cand_pack_kernel(const FrameDesc *frames, const TileDesc *tiles, const uint4 *cand,
+                                                                    unsigned int *ctab)
+{
+    const int tile = blockIdx.x;
+    const TileDesc td = tiles[tile];
+    const FrameDesc fd = frames[td.frame];
+    const int p0 = (tile - fd.tile_start) * kTile;
+    for (int i = threadIdx.x; i < kTile; i += kThreads) {
+        const int p = p0 + i;
+        if (p >= fd.npix) break;
+        const int y = p / fd.w, x = p - y * fd.w;
+        const uint4 c = cand[fd.depth_off + p];
+        auto enc = [&](unsigned int src, unsigned int &code) {
+            code = 0;
+            if (!src) return true;
+            const int s = (int)(src - 1u), sy = s / fd.w, sx = s - sy * fd.w;
+            const int dx = sx - x, dy = sy - y;
+            if (dx < -127 || dx > 127 || dy < -127 || dy > 127) return false;
+            code = (unsigned int)(dx + 128) | ((unsigned int)(dy + 128) << 8);
+            return true;
+        };
+        unsigned int c0, c1;
+        const bool ok0 = enc(c.x, c0), ok1 = enc(c.y, c1);
+        ctab[fd.depth_off + p] = (ok0 && ok1 && c.z == 0) ? (c0 | (c1 << 16)) : kWide;
+    }
+}
+
+typedef unsigned int u32_ua __attribute__((aligned(1)));
+typedef unsigned short u16_ua __attribute__((aligned(1)));
+typedef unsigned long long u64_ua __attribute__((aligned(1)));
+
+struct WarpSrc {
+    const unsigned short *depth;   // the frames as they came in (or, for the closing alone, the warped un-closed maps)
+    const unsigned char *rgb;
+    const unsigned int *ctab;      // [pixels per tick] compact table
+    const uint4 *cand;             // [pixels per tick] full table (kWide entries)
+    long long last_px;             // index of the last pixel of the whole batch (its colour is not read as a dword)
+};
+
+// the three colour bytes of pixel g as 0x00BBGGRR: one unaligned dword load (the byte behind them belongs to the next pixel; the
+// very last pixel of the batch is read one byte early instead, so nothing behind the buffer is touched), no branch
+__device__ __forceinline__ unsigned int load_rgb_at(const unsigned char *rgb, long long g, long long last_px)
+{
+    const int adj = g == last_px ? 1 : 0;
+    const unsigned int v = *reinterpret_cast<const u32_ua *>(rgb + 3 * g - adj);
+    return (v >> (8 * adj)) & 0x00FFFFFFu;
+}
+
+// Warped value of K destination pixels p[k] of one frame (fb = first pixel of the frame in the batch, doff = in its tick): a
+// chain of dependent loads per pixel -- table, the candidates' depths (both at once; with SPEC the first candidate's colour too),
+// the winner's colour -- issued for all K pixels level by level.  Every load is unconditional (a pixel that needs none reads its own
+// position and drops the value): no exec-mask branches, so the K loads of a level really are in flight together.  pv: any valid
+// pixel of the frame (stands in for p[k] where in[k] is false).
+template <int K, bool SPEC = false>
+__device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, long long doff, int w, int pv, const int (&p)[K], const bool (&in)[K],
+                                             unsigned int (&d)[K], unsigned int (&rgb)[K])
+{
+    unsigned int e[K];
+    int pk[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        pk[k] = in[k] ? p[k] : pv;
+        e[k] = S.ctab[doff + pk[k]];
+    }
+    int s0[K], s1[K];
+    unsigned int d0[K], d1[K], c0[K];
+    bool any_wide = false;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (!in[k]) e[k] = 0;
+        const unsigned int a0 = e[k] & 0xFFFFu, a1 = e[k] >> 16;
+        const bool wide = e[k] == kWide;
+        any_wide |= wide;
+        s0[k] = (a0 && !wide) ? pk[k] + (int)(a0 & 0xFFu) - 128 + ((int)(a0 >> 8) - 128) * w : -1;
+        s1[k] = (a1 && !wide) ? pk[k] + (int)(a1 & 0xFFu) - 128 + ((int)(a1 >> 8) - 128) * w : -1;
+        d0[k] = S.depth[fb + (s0[k] >= 0 ? s0[k] : pk[k])];
+        d1[k] = S.depth[fb + (s1[k] >= 0 ? s1[k] : pk[k])];
+        if (SPEC) c0[k] = load_rgb_at(S.rgb, fb + (s0[k] >= 0 ? s0[k] : pk[k]), S.last_px);   // the first candidate's colour rides with the depths
+    }
+    int src[K];
+    bool second = false;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (s0[k] < 0) d0[k] = 0;
+        if (s1[k] < 0) d1[k] = 0;
+        src[k] = d0[k] ? s0[k] : (d1[k] ? s1[k] : -1);      // the highest valid source wins (:200-218: the last one in raster order)
+        d[k] = d0[k] ? d0[k] : d1[k];
+        if (SPEC) {
+            rgb[k] = d0[k] ? c0[k] : 0u;
+            second |= !d0[k] && d1[k];
+        } else {
+            rgb[k] = load_rgb_at(S.rgb, fb + (src[k] >= 0 ? src[k] : pk[k]), S.last_px);
+            if (src[k] < 0) rgb[k] = 0;
+        }
+    }
+    if (SPEC && __any(second)) {                            // a zero-depth first candidate in front of a valid second one
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool need = !d0[k] && d1[k];
+            const unsigned int v = load_rgb_at(S.rgb, fb + (need ? s1[k] : pk[k]), S.last_px);
+            if (need) rgb[k] = v;
+        }
+    }
+    if (__any(any_wide)) {                                  // three or four sources, or a far one: the full table (a few pixels per frame)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (e[k] == kWide) {
+                const uint4 c = S.cand[doff + pk[k]];
+                const unsigned int cs[4] = {c.x, c.y, c.z, c.w};
+                int sw = -1;
+                unsigned int dd = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (sw < 0 && cs[j]) {
+                        const unsigned int v = S.depth[fb + (cs[j] - 1u)];
+                        if (v) { sw = (int)(cs[j] - 1u); dd = v; }
+                    }
+                }
+                d[k] = dd;
+                rgb[k] = sw >= 0 ? load_rgb_at(S.rgb, fb + sw, S.last_px) : 0u;
+            }
+        }
+    }
+}
+
+// The warp alone, to the un-closed scratch maps (the in-place entry point: the closing then reads those).
+__global__ __launch_bounds__(kThreads) void radial_gather_pack_kernel(const FrameDesc *__restrict__ frames, const TileDesc *__restrict__ tiles,
+                                                                      const WarpSrc S, unsigned short *__restrict__ map_copy,
                                                                       unsigned char *__restrict__ colors_copy, int tiles_per_tick, long long tick_pix_stride)
 {
     const int tick = blockIdx.x / tiles_per_tick;
@@ -151,60 +286,32 @@ __global__ __launch_bounds__(kThreads) void radial_gather_cand_kernel(const Fram
     const FrameDesc fd = frames[td.frame];
     const long long fb = tick * tick_pix_stride + fd.depth_off;
     const int p0 = (tile - fd.tile_start) * kTile;
-    // the tile's results are staged in LDS and leave as 16-byte stores (four narrow stores per pixel before)
+    // the tile's results are staged in LDS and leave as 16-byte stores
     __shared__ alignas(16) unsigned short s_d[kTile + 8];
     __shared__ alignas(16) unsigned char s_c[3 * kTile + 16];
     unsigned short *gd = map_copy + fb + p0;
     unsigned char *gc = colors_copy + 3 * (fb + p0);
     const int lead_d = (int)(reinterpret_cast<uintptr_t>(gd) & 15), lead_c = (int)(reinterpret_cast<uintptr_t>(gc) & 15);
-    // A pixel is a chain of three dependent loads (candidates -> their depths -> the winner's colour); the kernel is bound by
-    // that latency (PMC: 87 % of the wave-cycles waiting), so a thread keeps FOUR pixels in flight: all candidate loads, then
-    // all depth loads, then all colour loads (the restrict qualifiers let the compiler keep them that way).
     constexpr int kFly = 4;
     for (int i0 = threadIdx.x; i0 < kTile; i0 += kFly * kThreads) {
-        uint4 c[kFly];
+        int p[kFly];
         bool in[kFly];
 #pragma unroll
         for (int k = 0; k < kFly; k++) {
-            const int p = p0 + i0 + k * kThreads;
-            in[k] = i0 + k * kThreads < kTile && p < fd.npix;
-            c[k] = in[k] ? cand[fd.depth_off + p] : make_uint4(0, 0, 0, 0);
+            p[k] = p0 + i0 + k * kThreads;
+            in[k] = i0 + k * kThreads < kTile && p[k] < fd.npix;
         }
-        unsigned short d0[kFly], d1[kFly], d2[kFly], d3[kFly];
-#pragma unroll
-        for (int k = 0; k < kFly; k++) {
-            // all four candidate depths are fetched at once (independent loads); the first non-zero one wins
-            d0[k] = c[k].x ? depth[fb + (c[k].x - 1u)] : 0;
-            d1[k] = c[k].y ? depth[fb + (c[k].y - 1u)] : 0;
-            d2[k] = c[k].z ? depth[fb + (c[k].z - 1u)] : 0;
-            d3[k] = c[k].w ? depth[fb + (c[k].w - 1u)] : 0;
-        }
-        unsigned int src[kFly];
-        unsigned short d[kFly];
-        unsigned char r0[kFly], r1[kFly], r2[kFly];
-#pragma unroll
-        for (int k = 0; k < kFly; k++) {
-            src[k] = 0;
-            d[k] = 0;
-            if (d0[k]) { src[k] = c[k].x; d[k] = d0[k]; }
-            else if (d1[k]) { src[k] = c[k].y; d[k] = d1[k]; }
-            else if (d2[k]) { src[k] = c[k].z; d[k] = d2[k]; }
-            else if (d3[k]) { src[k] = c[k].w; d[k] = d3[k]; }
-            r0[k] = r1[k] = r2[k] = 0;
-            if (src[k]) {
-                const long long sidx = fb + (long long)(src[k] - 1u);
-                r0[k] = rgb[3 * sidx]; r1[k] = rgb[3 * sidx + 1]; r2[k] = rgb[3 * sidx + 2];
-            }
-        }
+        unsigned int d[kFly], c[kFly];
+        gather_batch<kFly, true>(S, fb, fd.depth_off, fd.w, p0, p, in, d, c);
 #pragma unroll
         for (int k = 0; k < kFly; k++) {
             if (!in[k]) continue;
             const int i = i0 + k * kThreads;
-            s_d[lead_d / 2 + i] = d[k];
+            s_d[lead_d / 2 + i] = (unsigned short)d[k];
             unsigned char *c3 = s_c + lead_c + 3 * i;
-            c3[0] = r0[k];
-            c3[1] = r1[k];
-            c3[2] = r2[k];
+            c3[0] = (unsigned char)c[k];
+            c3[1] = (unsigned char)(c[k] >> 8);
+            c3[2] = (unsigned char)(c[k] >> 16);
         }
     }
     __syncthreads();
@@ -282,14 +389,11 @@ struct RingFeed {
     RingChunk p0, p1;
 };
 
-// only_if (nullable): close only the frames whose flag is set -- the fall-back of the two-pass closing below -- and copy the closed
-// frame to out_d / out_c.
+// (LSN_RADIAL_CLOSE=wavefront: the ordered kernel of round 1, kept as an ablation of the band + rounds closing below)
 __global__ __launch_bounds__(768) void radial_close_kernel(const FrameDesc *frames, int n_frames, unsigned short *map_copy,
-                                                            unsigned char *colors_copy, long long tick_pix_stride, const int *only_if,
-                                                            unsigned short *out_d, unsigned char *out_c)
+                                                            unsigned char *colors_copy, long long tick_pix_stride)
 {
     extern __shared__ unsigned int ring_mem[];  // colours: (blockDim.x + 2) x kRing u32, then depths: the same count of u16
-    if (only_if && only_if[blockIdx.x] == 0) return;   // uniform over the workgroup
     const int rows = blockDim.x;
     unsigned int *cring = ring_mem;
     unsigned short *dring = reinterpret_cast<unsigned short *>(ring_mem + (rows + 2) * kRing);
@@ -412,34 +516,28 @@ __global__ __launch_bounds__(768) void radial_close_kernel(const FrameDesc *fram
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
     }
-    if (only_if) {
-        __syncthreads();   // every fill has reached the global maps
-        unsigned short *od = out_d + tick * tick_pix_stride + fd.depth_off;
-        unsigned char *oc = out_c + 3 * (tick * tick_pix_stride + fd.depth_off);
-        for (int i = threadIdx.x; i < fd.npix; i += blockDim.x) {
-            od[i] = map[i];
-            oc[3 * i] = col[3 * i];
-            oc[3 * i + 1] = col[3 * i + 1];
-            oc[3 * i + 2] = col[3 * i + 2];
-        }
-    }
 }
 
 
-// ---- hole closing in two passes (the default; LSN_RADIAL_CLOSE=wavefront selects the kernel above) ------------------------
+// ---- warp + hole closing, one band of rows per workgroup (the default) -------------------------------------------------------
 //
 // Only a hole BEHIND A FILLED PREDECESSOR (up-left, up, up-right, left) depends on the raster order of the reference's in-place
-// loop: everything else sees the un-closed map on all eight sides.  Measured on the CPU restatement (512x424): hash-noise
-// frames fill no hole at all, scene frames 5 376 of 107 807, the longest chain of fills feeding fills is 262.  So:
-//   1. close_first_kernel, streaming: every pixel is copied to the output; every hole is evaluated against the un-closed map
-//      (exact unless one of its predecessors gets filled) and every fill lists its hole successors (right, down-left, down,
-//      down-right) in the frame's work list;
-//   2. close_fix_kernel, one workgroup per frame: re-evaluates the listed holes with their predecessors read from the OUTPUT
-//      (current values) and their successors from the un-closed map; a pixel whose value changes lists its own hole successors
-//      for the next round.  The dependency graph is acyclic (raster order), every change re-triggers its dependants, so the
-//      rounds end -- after at most the longest chain -- in the unique state the sequential loop reaches (:223-256), whatever
-//      the order inside a round.
-// A frame whose lists overflow is closed by the wavefront kernel instead (flag per frame, no host round trip).
+// loop (:223-256): everything else sees the un-closed map on all eight sides.  On the 512x424 scene frames (CPU restatement):
+// 108 k holes per frame, 5.2 k of them with the five valid neighbours a fill needs at all, 4.8 k filled; the re-evaluation of the
+// holes behind a fill settles in 13-25 rounds of 3.0 k, 2.4 k, 0.9 k, 0.4 k ... pixels.  So:
+//   1. radial_band_kernel, one workgroup per band of rows: the warped band and one halo row either side are built IN LDS -- the
+//      un-closed map never goes to memory (GATHER), or it is read from the scratch maps a separate warp left (in-place entry point,
+//      atomicMax path).  Every interior hole with at least five valid neighbours goes on a list in LDS; the list is evaluated one
+//      candidate per lane against the un-closed band (exact unless one of the hole's predecessors gets filled); the fills are patched
+//      into the band; the band leaves as 16-byte stores together with one bit per pixel "was a hole before the closing", and every
+//      fill's hole successors (right, down-left, down, down-right) go on the frame's work list;
+//   2. close_fix_kernel, one workgroup per frame: re-evaluates the listed holes with their predecessors as they are NOW and their
+//      successors as the un-closed map had them (the bit says "hole": 0, else the value in place, which a non-hole never changes); a
+//      pixel whose value changes lists its own hole successors for the next round.  The dependency graph is acyclic (raster order)
+//      and every change re-triggers its dependants, so the rounds end -- after at most the longest chain -- in the unique state the
+//      sequential loop reaches, whatever the order inside a round.  A round list that outgrows LDS switches the frame to full sweeps
+//      over all its holes until nothing changes: the same fixed point, no list.
+// The colour of a hole is zero in the un-closed map (map_copy / colors_copy start zeroed, :193-194, and only valid pixels are warped).
 __device__ __forceinline__ void accept_chain(const int (&nb)[8], int &n, int &sum, unsigned int &accepted)
 {
     n = 0;
@@ -479,33 +577,9 @@ __device__ __forceinline__ unsigned int average_colour(const unsigned int (&nc)[
     return div_small(sR, n) | (div_small(sG, n) << 8) | (div_small(sB, n) << 16);
 }
 
-__device__ __forceinline__ unsigned int load_rgb24(const unsigned char *c) { return c[0] | (c[1] << 8) | (c[2] << 16); }
-
-struct CloseArgs {
-    const FrameDesc *frames;
-    const TileDesc *tiles;
-    const unsigned short *orig_d;   // the warped, un-closed maps
-    const unsigned char *orig_c;
-    unsigned short *out_d;          // the caller's maps: the result
-    unsigned char *out_c;
-    unsigned int *work;             // [n_ticks * n_frames][work_cap] pixel indices inside the frame
-    int *work_cnt;                  // [n_ticks * n_frames] x kCntStride: entries listed (may exceed work_cap: overflow)
-    int *flags;                     // [n_ticks * n_frames] 1 = close this frame with the wavefront kernel
-    int tiles_per_tick, n_frames, work_cap;
-    long long tick_pix_stride;
-};
-
-// orders a wave's LDS writes before its own later LDS reads (other lanes' data), no barrier: one wave, program order
-__device__ __forceinline__ void wave_lds_fence_r()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 constexpr int kDx[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, kDy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};   // the neighbour order of :225
 
-// Appends the wave's entries to the frame's list: one atomicAdd per wave.  `mine` = this lane's count; returns its first slot.
+// Appends the wave's entries to a list: one atomicAdd per wave.  `mine` = this lane's count; returns its first slot.
 __device__ __forceinline__ int wave_reserve(int *counter, int mine)
 {
     const int lane = threadIdx.x & 63;
@@ -519,315 +593,426 @@ __device__ __forceinline__ int wave_reserve(int *counter, int mine)
     return base + incl - mine;
 }
 
-// The same for a whole workgroup (every thread must call it): one atomicAdd per workgroup -- a frame's tiles run side by side
-// and all append to the frame's one counter.
-__device__ __forceinline__ int block_reserve(int *counter, int mine, int *s /* [8] */)
+constexpr int kCntStride = 32;   // ints between two frames' counters: one 128-byte line each (atomics on one line serialise in its L2 channel)
+constexpr int kBandThreads = 512;
+
+struct BandDesc { int frame, y0; };
+
+// first bit of frame f in a tick's hole bitmap: 64-bit aligned, frames never share a word
+__device__ __forceinline__ long long hole_base_bit(const FrameDesc &fd, int f) { return ((fd.depth_off + 63) & ~63ll) + 64ll * f; }
+
+struct BandArgs {
+    const FrameDesc *frames;
+    const BandDesc *bands;           // the bands of one tick
+    WarpSrc src;
+    unsigned short *out_d;           // the closed maps
+    unsigned char *out_c;
+    unsigned char *holes;            // [n_ticks][holes_tick_bytes] one bit per pixel: a hole of the un-closed map
+    unsigned int *work;              // [n_ticks][2 * pixels per tick]: frame f's list starts at 2 * depth_off, 2 * npix entries
+    int *work_cnt;                   // [n_ticks * n_frames] x kCntStride
+    int bands_per_tick, n_frames, rows;
+    long long tick_pix_stride, holes_tick_bytes;
+};
+
+// LDS of one band workgroup: (rows + 2) x w depths and colours (each behind up to 15 bytes of lead so that the rows that leave
+// sit at their destination's address modulo 16), the candidate list (rows x w entries: local pixel | fill depth << 16), a counter
+__host__ __device__ inline int band_lds_bytes(int rows, int w)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int incl = wave_inclusive_scan(mine, lane);
-    if (lane == 63) s[wave] = incl;
-    __syncthreads();
-    const int total = s[0] + s[1] + s[2] + s[3];
-    if (threadIdx.x == 0) s[4] = total > 0 ? atomicAdd(counter, total) : 0;
-    __syncthreads();
-    int off = s[4];
-    for (int i = 0; i < wave; i++) off += s[i];
-    return off + incl - mine;
+    const int band_px = (rows + 2) * w;
+    return 16 + ((2 * band_px + 15) & ~15) + 16 + ((3 * band_px + 15) & ~15) + 4 * rows * w + 16;
 }
 
-constexpr int kCntStride = 32;   // ints between two frames' counters: one 128-byte line each (atomics on one line serialise in its L2 channel)
-
-template <bool VEC>
-__global__ __launch_bounds__(kThreads, 8) void close_first_kernel(const CloseArgs a)
+// copies n bytes from LDS to global memory; (lds offset from the 16-byte aligned LDS base) = (global address) modulo 16
+__device__ __forceinline__ void store_band_run(unsigned char *dst, const unsigned char *lds, int n)
 {
-    __shared__ int s_res[16];
-    const int tick = blockIdx.x / a.tiles_per_tick;
-    const int tile = blockIdx.x - tick * a.tiles_per_tick;
-    const TileDesc td = a.tiles[tile];
-    const FrameDesc fd = a.frames[td.frame];
-    const int w = fd.w, h = fd.h;
+    const int lead = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
+    const int head = lead ? min(n, 16 - lead) : 0;
+    const int chunks = (n - head) >> 4;
+    const uint4 *l16 = reinterpret_cast<const uint4 *>(lds + head);
+    uint4 *g16 = reinterpret_cast<uint4 *>(dst + head);
+    for (int j = threadIdx.x; j < chunks; j += kBandThreads) g16[j] = l16[j];
+    const int tail0 = head + 16 * chunks;
+    if ((int)threadIdx.x < head) dst[threadIdx.x] = lds[threadIdx.x];
+    if (tail0 + (int)threadIdx.x < n) dst[tail0 + threadIdx.x] = lds[tail0 + threadIdx.x];
+}
+
+template <bool GATHER, bool VEC>
+__global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int tick = blockIdx.x / a.bands_per_tick;
+    const int band = blockIdx.x - tick * a.bands_per_tick;
+    const BandDesc bd = a.bands[band];
+    const FrameDesc fd = a.frames[bd.frame];
+    const int w = fd.w, h = fd.h, y0 = bd.y0;
+    const int nrows = min(a.rows, h - y0);
     const long long fb = tick * a.tick_pix_stride + fd.depth_off;
-    const int tf = tick * a.n_frames + td.frame;
-    unsigned int *work = a.work + (long long)tf * a.work_cap;
-    const int p0 = (tile - fd.tile_start) * kTile + (int)threadIdx.x * kPxPerLane;
-    const bool in_frame = p0 < fd.npix;
-    __shared__ unsigned int s_fill[VEC ? kThreads / 64 : 1][VEC ? 64 * kPxPerLane : 1];   // a wave's fills: pixel | accepted << 24, then their colours
-    unsigned int own_c[6] = {0, 0, 0, 0, 0, 0};   // the lane's 24-byte colour group (VEC)
-    unsigned int push[kPxPerLane];   // per pixel: bit s = successor s (right, down-left, down, down-right) goes on the list
-    unsigned int fill[kPxPerLane];   // per pixel: the accepted-neighbour mask of a fill (0: not filled; a fill accepts >= 5)
+    const int tf = tick * a.n_frames + bd.frame;
+    const int band_px = (a.rows + 2) * w;
+    unsigned short *gd = a.out_d + fb + (long long)y0 * w;
+    unsigned char *gc = a.out_c + 3 * (fb + (long long)y0 * w);
+    // local pixel 0 is pixel (y0 - 1) * w of the frame; the rows that leave start at local pixel w
+    const int lead_d = (int)((reinterpret_cast<uintptr_t>(gd) - 2 * (uintptr_t)w) & 15);
+    const int lead_c = (int)((reinterpret_cast<uintptr_t>(gc) - 3 * (uintptr_t)w) & 15);
+    const int off_c = 16 + ((2 * band_px + 15) & ~15);
+    const int off_l = off_c + 16 + ((3 * band_px + 15) & ~15);
+    unsigned short *s_d = reinterpret_cast<unsigned short *>(smem + lead_d);
+    unsigned char *s_c = smem + off_c + lead_c;
+    unsigned int *s_list = reinterpret_cast<unsigned int *>(smem + off_l);
+    int *s_n = reinterpret_cast<int *>(smem + off_l + 4 * a.rows * w);
+    if (tid == 0) *s_n = 0;
+    const int pl0 = (y0 - 1) * w;                       // frame pixel of local pixel 0 (negative for the first band)
+    const int lo = pl0 < 0 ? -pl0 : 0;                  // local pixels [lo, hi) exist in the frame
+    const int hi = min((nrows + 2) * w, fd.npix - pl0);
+
+    // ---- 1. the un-closed band into LDS ----
+    if (GATHER) {
+        constexpr int kFly = 6;
+        for (int i0 = lo + tid; i0 < hi; i0 += kFly * kBandThreads) {
+            int p[kFly];
+            bool in[kFly];
 #pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) push[k] = fill[k] = 0;
-    int px[kPxPerLane], py[kPxPerLane];
-    if (VEC) {
-        // w % 8 == 0: the lane's 8 pixels share a row; rows y-1 .. y+1, columns x0-1 .. x0+8 live in registers
-        const int v = td.x0 + (int)threadIdx.x * kPxPerLane;
-        int q = (int)((float)v * fd.inv_w);
-        int x0 = v - q * w;
-        if (x0 < 0) { q--; x0 += w; }
-        if (x0 >= w) { q++; x0 -= w; }
-        const int y = td.y0 + q;
-#pragma unroll
-        for (int k = 0; k < kPxPerLane; k++) { px[k] = x0 + k; py[k] = y; }
-        if (in_frame) {
-            int D[3][kPxPerLane + 2];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const int yy = y - 1 + r;
-                const bool row_in = yy >= 0 && yy < h;
-                const unsigned short *row = a.orig_d + fb + (long long)(row_in ? yy : y) * w;
-                uint4 c = *reinterpret_cast<const uint4 *>(row + x0);
-                unsigned int left = x0 > 0 ? row[x0 - 1] : 0u, right = x0 + 8 < w ? row[x0 + 8] : 0u;
-                if (!row_in) { c = make_uint4(0, 0, 0, 0); left = right = 0; }
-                const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
-                D[r][0] = (int)left;
-#pragma unroll
-                for (int k = 0; k < kPxPerLane; k++) D[r][1 + k] = (int)((cw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-                D[r][kPxPerLane + 1] = (int)right;
+            for (int k = 0; k < kFly; k++) {
+                p[k] = pl0 + i0 + k * kBandThreads;
+                in[k] = i0 + k * kBandThreads < hi;
             }
-            const long long pos0 = fb + (long long)y * w + x0;
-            const uint2 *cp = reinterpret_cast<const uint2 *>(a.orig_c + 3 * pos0);
+            unsigned int d[kFly], c[kFly];
+            gather_batch<kFly>(a.src, fb, fd.depth_off, w, pl0 + lo, p, in, d, c);
+#pragma unroll
+            for (int k = 0; k < kFly; k++) {
+                if (!in[k]) continue;
+                const int i = i0 + k * kBandThreads;
+                s_d[i] = (unsigned short)d[k];
+                unsigned char *c3 = s_c + 3 * i;
+                c3[0] = (unsigned char)c[k];
+                c3[1] = (unsigned char)(c[k] >> 8);
+                c3[2] = (unsigned char)(c[k] >> 16);
+            }
+        }
+    } else if (VEC) {
+        const unsigned short *sd = a.src.depth + fb + pl0;
+        const unsigned char *sc = a.src.rgb + 3 * (fb + pl0);
+        for (int i = lo + 8 * tid; i < hi; i += 8 * kBandThreads) {    // w % 8 == 0: lo, hi and every frame start are multiples of 8
+            *reinterpret_cast<uint4 *>(s_d + i) = *reinterpret_cast<const uint4 *>(sd + i);
+            const uint2 *cp = reinterpret_cast<const uint2 *>(sc + 3 * i);
+            uint2 *lp = reinterpret_cast<uint2 *>(s_c + 3 * i);
             const uint2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
-            unsigned int cw[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
-            unsigned int od[kPxPerLane];
-#pragma unroll
-            for (int k = 0; k < kPxPerLane; k++) od[k] = (unsigned int)D[1][k + 1];
-#pragma unroll
-            for (int k = 0; k < kPxPerLane; k++) {
-                const int x = x0 + k;
-                if (D[1][k + 1] == 0 && y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {                 // :229-234
-                    const int nb[8] = {D[0][k], D[0][k + 1], D[0][k + 2], D[1][k], D[1][k + 2], D[2][k], D[2][k + 1], D[2][k + 2]};
-                    int n, sum;
-                    unsigned int accepted;
-                    accept_chain(nb, n, sum, accepted);
-                    if (n > 4) {                                                                       // :250-256
-                        od[k] = div_small(sum, n);
-                        fill[k] = accepted;   // the colour average follows below, for all the wave's fills at once
-                        // its hole successors now depend on the order: onto the list (interior pixels only, :223-224)
-                        const bool below = y + 1 < h - 1;
-                        push[k] = ((D[1][k + 2] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((D[2][k] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
-                                  ((D[2][k + 1] == 0 && below) ? 4u : 0u) | ((D[2][k + 2] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
-                    }
-                }
-            }
-            *reinterpret_cast<uint4 *>(a.out_d + pos0) = make_uint4(od[0] | (od[1] << 16), od[2] | (od[3] << 16), od[4] | (od[5] << 16), od[6] | (od[7] << 16));
-            own_c[0] = cw[0]; own_c[1] = cw[1]; own_c[2] = cw[2]; own_c[3] = cw[3]; own_c[4] = cw[4]; own_c[5] = cw[5];
-        }
-        // The fills' colours.  A wave's fills (a handful, spread over its lanes and over the 8 pixels of a lane) are handed out one
-        // per lane through LDS, so all their neighbour colours are fetched in ONE round trip (evaluated where they arise, the
-        // wave would wait for a load eight times over); the averages come back the same way and are patched into the owners'
-        // 24-byte colour groups before those are stored.
-        {
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            unsigned int *mine_l = s_fill[wave];
-            int n_fill = 0;
-#pragma unroll
-            for (int k = 0; k < kPxPerLane; k++) n_fill += fill[k] ? 1 : 0;
-            const int incl = wave_inclusive_scan(n_fill, lane);
-            const int total = __shfl(incl, 63, 64);
-            int slot = incl - n_fill;
-#pragma unroll
-            for (int k = 0; k < kPxPerLane; k++)
-                if (fill[k]) mine_l[slot++] = (unsigned int)(py[k] * w + px[k]) | (fill[k] << 24);
-            wave_lds_fence_r();
-            for (int i = lane; i < total; i += 64) {
-                const unsigned int e = mine_l[i];
-                const int p = (int)(e & 0xFFFFFFu);
-                const unsigned int accepted = e >> 24;
-                unsigned int nc[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) nc[j] = (accepted >> j) & 1u ? load_rgb24(a.orig_c + 3 * (fb + p + kDy[j] * w + kDx[j])) : 0u;
-                mine_l[i] = average_colour(nc, accepted, __popc(accepted));
-            }
-            wave_lds_fence_r();
-            slot = incl - n_fill;
-#pragma unroll
-            for (int k = 0; k < kPxPerLane; k++) {
-                if (fill[k]) {
-                    const unsigned int rgb = mine_l[slot++];
-                    // the pixel's three bytes start at byte 3k of the lane's 24-byte group
-                    const int b = 3 * k, wi = b >> 2, sh = (b & 3) * 8;
-                    const unsigned long long m = 0xFFFFFFull << sh, v = (unsigned long long)rgb << sh;
-                    own_c[wi] = (own_c[wi] & ~(unsigned int)m) | (unsigned int)v;
-                    if (wi + 1 < 6 && (m >> 32)) own_c[wi + 1] = (own_c[wi + 1] & ~(unsigned int)(m >> 32)) | (unsigned int)(v >> 32);
-                }
-            }
-        }
-        if (in_frame) {
-            uint2 *op = reinterpret_cast<uint2 *>(a.out_c + 3 * (fb + (long long)py[0] * w + px[0]));
-            op[0] = make_uint2(own_c[0], own_c[1]);
-            op[1] = make_uint2(own_c[2], own_c[3]);
-            op[2] = make_uint2(own_c[4], own_c[5]);
+            lp[0] = c0; lp[1] = c1; lp[2] = c2;
         }
     } else {
-        // any width: pixel by pixel
-#pragma unroll
-        for (int k = 0; k < kPxPerLane; k++) {
-            const int p = p0 + k;
-            px[k] = py[k] = 0;
-            if (p >= fd.npix) continue;
-            const int y = p / w, x = p - y * w;
-            px[k] = x; py[k] = y;
-            const long long pos = fb + p;
-            unsigned int d = a.orig_d[pos], rgb = load_rgb24(a.orig_c + 3 * pos);
-            if (d == 0 && y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
-                int nb[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) nb[i] = a.orig_d[pos + kDy[i] * w + kDx[i]];
-                int n, sum;
-                unsigned int accepted;
-                accept_chain(nb, n, sum, accepted);
-                if (n > 4) {
-                    unsigned int nc[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) nc[i] = (accepted >> i) & 1u ? load_rgb24(a.orig_c + 3 * (pos + kDy[i] * w + kDx[i])) : 0u;
-                    d = div_small(sum, n);
-                    rgb = average_colour(nc, accepted, n);
-                    const bool below = y + 1 < h - 1;
-                    push[k] = ((nb[4] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((nb[5] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
-                              ((nb[6] == 0 && below) ? 4u : 0u) | ((nb[7] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
-                }
-            }
-            a.out_d[pos] = (unsigned short)d;
-            a.out_c[3 * pos] = (unsigned char)rgb;
-            a.out_c[3 * pos + 1] = (unsigned char)(rgb >> 8);
-            a.out_c[3 * pos + 2] = (unsigned char)(rgb >> 16);
+        const unsigned short *sd = a.src.depth + fb + pl0;
+        const unsigned char *sc = a.src.rgb + 3 * (fb + pl0);
+        for (int i = lo + tid; i < hi; i += kBandThreads) {
+            s_d[i] = sd[i];
+            s_c[3 * i] = sc[3 * i];
+            s_c[3 * i + 1] = sc[3 * i + 1];
+            s_c[3 * i + 2] = sc[3 * i + 2];
         }
     }
-    int mine = 0;
+    __syncthreads();
+
+    // ---- 2. the holes: one bit per pixel for the second pass; the candidates (>= 5 valid neighbours, interior) onto the list ----
+    const long long hole_bit0 = hole_base_bit(fd, bd.frame);
+    unsigned char *holes = a.holes + tick * a.holes_tick_bytes;
+    if (VEC) {
+        const int gw = w >> 3, ngroups = nrows * gw;
+        for (int g0 = 0; g0 < ngroups; g0 += kBandThreads) {
+            const int g = g0 + tid;
+            unsigned int cb = 0;
+            int li = 0;
+            if (g < ngroups) {
+                const int r = g / gw, x0 = (g - r * gw) << 3, y = y0 + r;
+                li = (r + 1) * w + x0;
+                unsigned int m[3];
 #pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) mine += __popc(push[k]);
-    int slot = block_reserve(a.work_cnt + kCntStride * tf, mine, s_res);
+                for (int rr = 0; rr < 3; rr++) {
+                    const unsigned short *row = s_d + li + (rr - 1) * w;
+                    const uint4 c = *reinterpret_cast<const uint4 *>(row);
+                    const unsigned int left = x0 > 0 ? row[-1] : 0u, right = x0 + 8 < w ? row[8] : 0u;
+                    const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
+                    unsigned int bits = left ? 1u : 0u;
 #pragma unroll
-    for (int k = 0; k < kPxPerLane; k++) {
+                    for (int k = 0; k < 4; k++) {
+                        bits |= (cw[k] & 0xFFFFu) ? (2u << (2 * k)) : 0u;
+                        bits |= (cw[k] >> 16) ? (4u << (2 * k)) : 0u;
+                    }
+                    bits |= right ? (1u << 9) : 0u;
+                    m[rr] = bits;                                  // bit c: column x0 - 1 + c holds a valid depth
+                }
+                const unsigned int hb = ~(m[1] >> 1) & 0xFFu;      // bit k: pixel x0 + k is a hole
+                holes[(hole_bit0 + (long long)y * w + x0) >> 3] = (unsigned char)hb;
+                if (y >= 1 && y < h - 1) {                         // :223-224 interior pixels only
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int nv = __popc((m[0] >> k) & 7u) + __popc((m[1] >> k) & 5u) + __popc((m[2] >> k) & 7u);
+                        cb |= (nv >= 5 && x0 + k >= 1 && x0 + k < w - 1) ? (1u << k) : 0u;
+                    }
+                    cb &= hb;
+                }
+            }
+            int slot = wave_reserve(s_n, __popc(cb));
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if ((cb >> k) & 1u) s_list[slot++] = (unsigned int)(li + k);
+        }
+    } else {
+        // any width: pixel by pixel (the bitmap was cleared by the host)
+        unsigned int *hw = reinterpret_cast<unsigned int *>(holes);
+        const int n_px = nrows * w;
+        for (int i0 = 0; i0 < n_px; i0 += kBandThreads) {
+            const int i = i0 + tid;
+            bool cand = false;
+            const int li = w + i;
+            if (i < n_px && s_d[li] == 0) {
+                const int r = i / w, x = i - r * w, y = y0 + r;
+                const long long bit = hole_bit0 + (long long)y * w + x;
+                atomicOr(&hw[bit >> 5], 1u << (bit & 31));
+                if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
+                    int nv = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) nv += s_d[li + kDy[j] * w + kDx[j]] != 0 ? 1 : 0;
+                    cand = nv >= 5;
+                }
+            }
+            const int slot = wave_reserve(s_n, cand ? 1 : 0);
+            if (cand) s_list[slot] = (unsigned int)li;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. the candidates, one per lane, against the un-closed band ----
+    const int n_cand = *s_n;
+    unsigned int *work = a.work + 2 * fb;
+    for (int i0 = 0; i0 < n_cand; i0 += kBandThreads) {
+        const int i = i0 + tid;
+        unsigned int succ = 0;
+        int x = 0, y = 0;
+        if (i < n_cand) {
+            const int q = (int)s_list[i];
+            int nb[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) nb[j] = s_d[q + kDy[j] * w + kDx[j]];
+            int n, sum;
+            unsigned int accepted;
+            accept_chain(nb, n, sum, accepted);
+            if (n > 4) {                                                                       // :250-256
+                unsigned int nc[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const unsigned char *c3 = s_c + 3 * (q + kDy[j] * w + kDx[j]);
+                    nc[j] = (accepted >> j) & 1u ? ((unsigned int)c3[0] | ((unsigned int)c3[1] << 8) | ((unsigned int)c3[2] << 16)) : 0u;
+                }
+                const unsigned int rgb = average_colour(nc, accepted, n);
+                // a hole's colour is never read by another evaluation (only accepted = valid neighbours' colours are): patch it now
+                s_c[3 * q] = (unsigned char)rgb;
+                s_c[3 * q + 1] = (unsigned char)(rgb >> 8);
+                s_c[3 * q + 2] = (unsigned char)(rgb >> 16);
+                s_list[i] = (unsigned int)q | (div_small(sum, n) << 16);                       // the depth goes in after the barrier
+                int yl = (int)((float)q * fd.inv_w);
+                x = q - yl * w;
+                if (x < 0) { yl--; x += w; }
+                if (x >= w) { yl++; x -= w; }
+                y = y0 - 1 + yl;
+                // its hole successors now depend on the order: onto the frame's list (interior pixels only, :223-224)
+                const bool below = y + 1 < h - 1;
+                succ = ((nb[4] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((nb[5] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
+                       ((nb[6] == 0 && below) ? 4u : 0u) | ((nb[7] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
+            }
+        }
+        int slot = wave_reserve(a.work_cnt + kCntStride * tf, __popc(succ));
 #pragma unroll
         for (int sidx = 0; sidx < 4; sidx++) {
-            if ((push[k] >> sidx) & 1u) {
-                const int i = 4 + sidx;   // neighbours 4..7 are the successors
-                if (slot < a.work_cap) work[slot] = (unsigned int)((py[k] + kDy[i]) * w + px[k] + kDx[i]);
+            if ((succ >> sidx) & 1u) {
+                const int j = 4 + sidx;   // neighbours 4..7 are the successors
+                if (slot < 2 * fd.npix) work[slot] = (unsigned int)((y + kDy[j]) * w + x + kDx[j]);   // (a frame lists < 24/13 npix entries)
                 slot++;
             }
         }
     }
+    __syncthreads();
+    for (int i = tid; i < n_cand; i += kBandThreads) {
+        const unsigned int e = s_list[i];
+        if (e >> 16) s_d[e & 0xFFFFu] = (unsigned short)(e >> 16);
+    }
+    __syncthreads();
+
+    // ---- 4. the band leaves ----
+    store_band_run(reinterpret_cast<unsigned char *>(gd), reinterpret_cast<const unsigned char *>(s_d + w), 2 * nrows * w);
+    store_band_run(gc, s_c + 3 * w, 3 * nrows * w);
 }
 
-constexpr int kFixList = 8192;   // entries per round list (LDS, two lists: 64 KB -- a few scene frames listed more than 4096 in a round)
-constexpr int kFixRounds = 1 << 16;
+constexpr int kFixThreads = 256;   // measured on 512 scene frames: 1024 threads 377 us, 512: 274, 256: 245 -- the rounds are short, idle waves only add barrier time
+constexpr int kFixList = 8192;   // entries per round list (LDS, two lists: 64 KB)
 
-__global__ __launch_bounds__(kThreads) void close_fix_kernel(const CloseArgs a)
+struct FixArgs {
+    const FrameDesc *frames;
+    unsigned short *out_d;
+    unsigned char *out_c;
+    const unsigned char *holes;
+    const unsigned int *work;
+    int *work_cnt;
+    int n_frames, list_cap;          // list_cap: entries a round list may hold (kFixList; the tests shrink it to force the sweeps)
+    long long tick_pix_stride, holes_tick_bytes;
+};
+
+// Re-evaluates hole p of a frame (out_d / out_c / holes point at the frame, bit0 = its first bit in `holes`): predecessors as they
+// are now, successors as the un-closed map had them.  Returns true and writes the pixel when its value changed; succ = its hole
+// successors (bit s = neighbour 4 + s), which then have to be looked at again.
+__device__ __forceinline__ bool fix_pixel(unsigned short *out_d, unsigned char *out_c, const unsigned char *holes, long long bit0, int p, int w, int h,
+                                          float inv_w, unsigned int &succ, int &x, int &y)
+{
+    y = (int)((float)p * inv_w);
+    x = p - y * w;
+    if (x < 0) { y--; x += w; }
+    if (x >= w) { y++; x -= w; }
+    // three rows of three pixels: depths as dword + word, colours as 8 + 1 bytes (nothing is read outside the nine pixels)
+    unsigned int dv[3][3], cv[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int q = p + (r - 1) * w - 1;
+        const unsigned int d01 = *reinterpret_cast<const u32_ua *>(out_d + q);
+        dv[r][0] = d01 & 0xFFFFu;
+        dv[r][1] = d01 >> 16;
+        dv[r][2] = out_d[q + 2];
+        const unsigned long long c8 = *reinterpret_cast<const u64_ua *>(out_c + 3 * (long long)q);
+        cv[r][0] = (unsigned int)c8 & 0xFFFFFFu;
+        cv[r][1] = (unsigned int)(c8 >> 24) & 0xFFFFFFu;
+        cv[r][2] = (unsigned int)(c8 >> 48) | ((unsigned int)out_c[3 * (long long)q + 8] << 16);
+    }
+    // the hole bits of the four successors: p + 1, and p + w - 1 .. p + w + 1
+    const long long b1 = bit0 + p + 1, b2 = bit0 + p + w - 1;
+    const unsigned int h1 = (holes[b1 >> 3] >> (b1 & 7)) & 1u;
+    const unsigned int h2 = ((unsigned int)*reinterpret_cast<const u16_ua *>(holes + (b2 >> 3)) >> (b2 & 7)) & 7u;
+    const int nb[8] = {(int)dv[0][0], (int)dv[0][1], (int)dv[0][2], (int)dv[1][0], h1 ? 0 : (int)dv[1][2],
+                       (h2 & 1u) ? 0 : (int)dv[2][0], (h2 & 2u) ? 0 : (int)dv[2][1], (h2 & 4u) ? 0 : (int)dv[2][2]};
+    const unsigned int nc[8] = {cv[0][0], cv[0][1], cv[0][2], cv[1][0], cv[1][2], cv[2][0], cv[2][1], cv[2][2]};
+    const unsigned int od = dv[1][1], orgb = cv[1][1];
+    unsigned int nd = 0, nrgb = 0;   // an unfilled hole keeps what the warp left (:250): nothing
+    int n, sum;
+    unsigned int accepted;
+    accept_chain(nb, n, sum, accepted);
+    if (n > 4) {
+        nd = div_small(sum, n);
+        nrgb = average_colour(nc, accepted, n);
+    }
+    succ = 0;
+    if (nd == od && nrgb == orgb) return false;
+    out_d[p] = (unsigned short)nd;
+    out_c[3 * (long long)p] = (unsigned char)nrgb;
+    out_c[3 * (long long)p + 1] = (unsigned char)(nrgb >> 8);
+    out_c[3 * (long long)p + 2] = (unsigned char)(nrgb >> 16);
+    const bool below = y + 1 < h - 1;
+    succ = ((h1 && x + 1 < w - 1) ? 1u : 0u) | (((h2 & 1u) && x - 1 >= 1 && below) ? 2u : 0u) | (((h2 & 2u) && below) ? 4u : 0u) |
+           (((h2 & 4u) && x + 1 < w - 1 && below) ? 8u : 0u);
+    return true;
+}
+
+__global__ __launch_bounds__(kFixThreads) void close_fix_kernel(const FixArgs a)
 {
     __shared__ unsigned int lists[2][kFixList];
     __shared__ int s_n[2];
-    __shared__ int s_overflow;
+    __shared__ int s_flag;
     const int tf = blockIdx.x;
     const int tick = tf / a.n_frames, f = tf - tick * a.n_frames;
     const FrameDesc fd = a.frames[f];
     const int w = fd.w, h = fd.h;
     const long long fb = tick * a.tick_pix_stride + fd.depth_off;
-    const unsigned short *orig_d = a.orig_d + fb;
-    const unsigned char *orig_c = a.orig_c + 3 * fb;
     // written and re-read by the waves of this workgroup only, a round apart: they share the CU's L1, and the barrier between two
     // rounds (workgroup-scope release / acquire) orders the accesses -- no cache bypass needed
     unsigned short *out_d = a.out_d + fb;
     unsigned char *out_c = a.out_c + 3 * fb;
-    const int n0 = a.work_cnt[kCntStride * tf];
+    const unsigned char *holes = a.holes + tick * a.holes_tick_bytes;
+    const long long bit0 = hole_base_bit(fd, f);
+    const int n_listed = a.work_cnt[kCntStride * tf];
+    const int n0 = n_listed > 2 * fd.npix ? 0 : n_listed;   // (a frame whose list overflowed is swept instead)
+    __syncthreads();                                   // everybody has read the counter ...
     if (threadIdx.x == 0) {
+        a.work_cnt[kCntStride * tf] = 0;               // ... which is left cleared for the next call
         s_n[0] = s_n[1] = 0;
-        s_overflow = n0 > a.work_cap ? 1 : 0;
-        a.flags[tf] = 0;
+        s_flag = 0;
     }
     __syncthreads();
-    const unsigned int *glist = a.work + (long long)tf * a.work_cap;
+    const unsigned int *glist = a.work + 2 * fb;
     int cur = 0;   // lists[cur] is read, lists[1 - cur] is filled; round 0 reads the global list instead
-    for (int round = 0; !s_overflow; round++) {
+    bool sweep = n_listed > 2 * fd.npix;
+    for (int round = 0;; round++) {
         const int n_items = round == 0 ? n0 : s_n[cur];
         if (n_items == 0) break;
-        if (round >= kFixRounds) {   // cannot happen (the chains are finite); never leave a frame half closed
-            if (threadIdx.x == 0) s_overflow = 1;
-            __syncthreads();
-            break;
-        }
-        for (int i0 = 0; i0 < n_items; i0 += kThreads) {
+        for (int i0 = 0; i0 < n_items; i0 += kFixThreads) {
             const int i = i0 + (int)threadIdx.x;
-            int mine = 0;
+            if (i0 + (int)(threadIdx.x & ~63u) >= n_items) continue;   // nothing left for this wave (wave-uniform)
             unsigned int succ = 0;
             int x = 0, y = 0;
-            if (i < n_items) {
-                const int p = (int)(round == 0 ? glist[i] : lists[cur][i]);
-                y = p / w;
-                x = p - y * w;
-                // predecessors (neighbours 0..3) as they are now, successors (4..7) as the sequential loop would still see them
-                int nb[8];
-#pragma unroll
-                for (int k = 0; k < 4; k++) nb[k] = out_d[p + kDy[k] * w + kDx[k]];
-#pragma unroll
-                for (int k = 4; k < 8; k++) nb[k] = orig_d[p + kDy[k] * w + kDx[k]];
-                // every colour the verdict may need is fetched together with the depths (one memory round trip per round, not two)
-                unsigned int nc[8];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const long long q = 3 * (long long)(p + kDy[k] * w + kDx[k]);
-                    nc[k] = (unsigned int)out_c[q] | ((unsigned int)out_c[q + 1] << 8) | ((unsigned int)out_c[q + 2] << 16);
-                }
-#pragma unroll
-                for (int k = 4; k < 8; k++) nc[k] = load_rgb24(orig_c + 3 * (long long)(p + kDy[k] * w + kDx[k]));
-                const unsigned int od = out_d[p];
-                const unsigned int orgb = (unsigned int)out_c[3 * (long long)p] | ((unsigned int)out_c[3 * (long long)p + 1] << 8) |
-                                          ((unsigned int)out_c[3 * (long long)p + 2] << 16);
-                unsigned int nd = 0, nrgb = load_rgb24(orig_c + 3 * (long long)p);   // an unfilled hole keeps what the warp left (:250)
-                int n, sum;
-                unsigned int accepted;
-                accept_chain(nb, n, sum, accepted);
-                if (n > 4) {
-                    nd = div_small(sum, n);
-                    nrgb = average_colour(nc, accepted, n);
-                }
-                if (nd != od || nrgb != orgb) {
-                    out_d[p] = (unsigned short)nd;
-                    out_c[3 * (long long)p] = (unsigned char)nrgb;
-                    out_c[3 * (long long)p + 1] = (unsigned char)(nrgb >> 8);
-                    out_c[3 * (long long)p + 2] = (unsigned char)(nrgb >> 16);
-                    const bool below = y + 1 < h - 1;
-                    succ = ((nb[4] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((nb[5] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
-                           ((nb[6] == 0 && below) ? 4u : 0u) | ((nb[7] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
-                    mine = __popc(succ);
-                }
-            }
-            int slot = wave_reserve(&s_n[1 - cur], mine);
+            if (i < n_items) fix_pixel(out_d, out_c, holes, bit0, (int)(round == 0 ? glist[i] : lists[cur][i]), w, h, fd.inv_w, succ, x, y);
+            int slot = wave_reserve(&s_n[1 - cur], __popc(succ));
 #pragma unroll
             for (int sidx = 0; sidx < 4; sidx++) {
                 if ((succ >> sidx) & 1u) {
                     const int k = 4 + sidx;
-                    if (slot < kFixList) lists[1 - cur][slot] = (unsigned int)((y + kDy[k]) * w + x + kDx[k]);
-                    else s_overflow = 1;
+                    if (slot < a.list_cap) lists[1 - cur][slot] = (unsigned int)((y + kDy[k]) * w + x + kDx[k]);
+                    else s_flag = 1;
                     slot++;
                 }
             }
         }
         __threadfence_block();
         __syncthreads();   // this round's writes are in place before the next round reads them
+        if (s_flag) { sweep = true; break; }
         cur = 1 - cur;
         if (threadIdx.x == 0) s_n[1 - cur] = 0;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && s_overflow) a.flags[tf] = 1;
+    // A list outgrew LDS: sweep over every interior hole of the frame until a whole sweep changes nothing.  Same fixed point (a pixel
+    // is final once its predecessors are and it has been looked at again), no list; slow, and only adversarial frames get here.
+    while (sweep) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_flag = 0;
+        __syncthreads();
+        bool changed = false;
+        for (int p = w + 1 + (int)threadIdx.x; p < fd.npix - w - 1; p += kFixThreads) {
+            const long long b = bit0 + p;
+            if (!((holes[b >> 3] >> (b & 7)) & 1u)) continue;
+            int x, y;
+            {
+                y = (int)((float)p * fd.inv_w);
+                x = p - y * w;
+                if (x < 0) { y--; x += w; }
+                if (x >= w) { y++; x -= w; }
+            }
+            if (x < 1 || x >= w - 1) continue;
+            unsigned int succ;
+            changed |= fix_pixel(out_d, out_c, holes, bit0, p, w, h, fd.inv_w, succ, x, y);
+        }
+        if (changed) s_flag = 1;
+        __threadfence_block();
+        __syncthreads();
+        sweep = s_flag != 0;
+    }
+}
+
+// The bands of one tick for `rows` rows per band; returns their number.
+static int make_bands(const LsnFusion *p, int rows, std::vector<BandDesc> &bands)
+{
+    bands.clear();
+    for (int f = 0; f < p->n_maps; f++)
+        for (int y0 = 0; y0 < p->h[f]; y0 += rows) bands.push_back(BandDesc{f, y0});
+    return (int)bands.size();
 }
 
 }  // namespace
 
-extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, void *d_depth, void *d_colors, void *stream)
+static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_depth_in, const void *d_colors_in, void *d_depth, void *d_colors,
+                          hipStream_t s)
 {
-    lsn::clear_error();
-    if (!p || !intr_params || !d_depth || !d_colors) {
-        lsn::set_error("lsnFusionRadialCorrect: null argument");
+    LSN_HIP(hipSetDevice(p->device));
+    const bool in_place = d_depth_in == d_depth && d_colors_in == d_colors;
+    if (!in_place && (d_depth_in == d_depth || d_colors_in == d_colors)) {
+        lsn::set_error("lsnFusionRadialCorrectTo: depth and colours must both be in place or both out of place");
         return -1;
     }
-    std::lock_guard<std::mutex> g(p->mu);
-    LSN_HIP(hipSetDevice(p->device));
-    hipStream_t s = lsn::as_stream(stream);
     const size_t npix = (size_t)p->cap * p->n_ticks;
-    if (p->winner.reserve(4 * npix) || p->map_copy.reserve(2 * npix) || p->colors_copy.reserve(3 * npix) ||
-        p->radial.reserve(sizeof(RadialParams) * p->n_maps))
-        return -1;
+    if (p->radial.reserve(sizeof(RadialParams) * p->n_maps)) return -1;
     std::vector<RadialParams> rp(p->n_maps);
     for (int i = 0; i < p->n_maps; i++) {
         const float *ip = intr_params + 7 * i;  // IntrinsicCameraParameters(float*), include/NativeUtils/depthprocessing.h:96-97
@@ -839,16 +1024,19 @@ extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, vo
     if (!same_intr) {
         LSN_HIP(hipMemcpyAsync(p->radial.p, rp.data(), sizeof(RadialParams) * p->n_maps, hipMemcpyHostToDevice, s));
         LSN_HIP(hipStreamSynchronize(s));  // rp is a local
-        // the warp candidates of this calibration (one tick's worth of pixels; `winner` serves as the per-destination counter)
-        if (p->cand.reserve(16 * (size_t)p->cap)) return -1;
-        LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * (size_t)p->cap, s));
+        // the warp candidates of this calibration (one tick's worth of pixels), then their compact form
+        if (p->cand.reserve(16 * (size_t)p->cap) || p->ctab.reserve(4 * (size_t)p->cap + 16)) return -1;
+        unsigned int *count = p->ctab.as<unsigned int>();   // the per-destination counters of the fill pass live where the compact table will
+        LSN_HIP(hipMemsetAsync(count, 0, 4 * (size_t)p->cap, s));
         LSN_HIP(hipMemsetAsync(p->cand.p, 0, 16 * (size_t)p->cap, s));
         LSN_HIP(hipMemsetAsync(p->misc.as<char>() + 64, 0, sizeof(int), s));
         int *overflow = reinterpret_cast<int *>(p->misc.as<char>() + 64);
         hipLaunchKernelGGL(radial_cand_fill_kernel, dim3(p->tiles_per_tick), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(),
-                           p->tile_frame.as<TileDesc>(), p->radial.as<RadialParams>(), p->winner.as<unsigned int>(), p->cand.as<unsigned int>(), overflow);
+                           p->tile_frame.as<TileDesc>(), p->radial.as<RadialParams>(), count, p->cand.as<unsigned int>(), overflow);
         hipLaunchKernelGGL(radial_cand_sort_kernel, dim3((unsigned)((p->cap + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, p->cand.as<uint4>(),
                            p->cap);
+        hipLaunchKernelGGL(radial_cand_pack_kernel, dim3(p->tiles_per_tick), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(),
+                           p->tile_frame.as<TileDesc>(), (const uint4 *)p->cand.as<uint4>(), p->ctab.as<unsigned int>());
         int ov = 0;
         LSN_HIP(hipMemcpyAsync(&ov, overflow, sizeof(int), hipMemcpyDeviceToHost, s));
         LSN_HIP(hipStreamSynchronize(s));
@@ -856,80 +1044,159 @@ extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, vo
         p->radial_intr.assign(intr_params, intr_params + 7 * (size_t)p->n_maps);
         p->cand_valid = true;
     }
+    // (read on every call: the tests switch them inside one process)
     const char *force = getenv("LSN_RADIAL_FORCE_ATOMIC");  // tests: take the atomicMax path even when the table did not overflow
-    if (!p->cand_overflow && !(force && atoi(force) != 0)) {
-        hipLaunchKernelGGL(radial_gather_cand_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
-                           static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors), (const uint4 *)p->cand.as<uint4>(),
-                           p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->tiles_per_tick, p->cap);
-    } else {
-        LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * npix, s));
-        hipLaunchKernelGGL(radial_warp_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
-                           p->radial.as<RadialParams>(), static_cast<const unsigned short *>(d_depth), p->winner.as<unsigned int>(),
-                           p->tiles_per_tick, p->cap);
-        hipLaunchKernelGGL(radial_gather_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
-                           static_cast<const unsigned short *>(d_depth), static_cast<const unsigned char *>(d_colors),
-                           (const unsigned int *)p->winner.as<unsigned int>(), p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(),
-                           p->tiles_per_tick, p->cap);
-    }
-    int max_h = 1;
-    for (int v : p->h) max_h = v > max_h ? v : max_h;
-    int rows = max_h - 2 < 64 ? 64 : ((max_h - 2 + 63) / 64) * 64;
-    if (rows > 768) rows = 768;  // (rows + 2) x 32 columns x 6 B of LDS rings must fit in 160 KB
-    // One band per frame is the shortest chain of steps, but (rows + 2) x 192 B of LDS per workgroup then allows a single
-    // frame per CU.  With more frames than CUs, 256-row bands (49.5 KB: three frames per CU) win: 2.75 vs 3.37 ms for
-    // 512 frames of 512x424 on MI355X.
-    if ((long long)p->n_maps * p->n_ticks > 256 && rows > 256) rows = 256;
-    if (const char *env = getenv("LSN_RADIAL_ROWS")) {  // tuning: rows per band (multiple of 64, <= 768)
-        const int v = atoi(env);
-        if (v >= 64 && v <= 768 && v % 64 == 0) rows = v;
-    }
-    const size_t ring_bytes = (sizeof(unsigned int) + sizeof(unsigned short)) * kRing * (rows + 2);
-    const int n_tf = p->n_maps * p->n_ticks;
-    // Two-pass closing: its work lists live in `winner` (free once the gather is done): counters, flags, then work_cap entries per frame
-    // (read on every call, like LSN_RADIAL_FORCE_ATOMIC: the tests switch them inside one process)
     const char *close_env = getenv("LSN_RADIAL_CLOSE"), *tiny_env = getenv("LSN_RADIAL_TINY_LISTS");
-    const bool wavefront_only = close_env && !strcmp(close_env, "wavefront");
-    const bool tiny_lists = tiny_env && atoi(tiny_env) != 0;   // tests: force the fall-back
-    long long work_cap = ((long long)npix - (kCntStride + 1ll) * n_tf - 64) / n_tf;
-    if (work_cap > 16384) work_cap = 16384;
-    if (tiny_lists && work_cap > 8) work_cap = 8;
-    long long max_npix = 0;
-    for (int i = 0; i < p->n_maps; i++) max_npix = std::max(max_npix, (long long)p->w[i] * p->h[i]);
-    // (a wave's fill entries carry the pixel index in 24 bits)
-    if (!wavefront_only && work_cap >= 8 && max_npix < (1ll << 24)) {
-        CloseArgs ca;
-        ca.frames = p->frames.as<FrameDesc>();
-        ca.tiles = p->tile_frame.as<TileDesc>();
-        ca.orig_d = p->map_copy.as<unsigned short>();
-        ca.orig_c = p->colors_copy.as<unsigned char>();
-        ca.out_d = static_cast<unsigned short *>(d_depth);
-        ca.out_c = static_cast<unsigned char *>(d_colors);
-        ca.work_cnt = p->winner.as<int>();
-        ca.flags = ca.work_cnt + (size_t)kCntStride * n_tf;
-        ca.work = p->winner.as<unsigned int>() + ((size_t)kCntStride + 1) * n_tf + 64;
-        ca.tiles_per_tick = p->tiles_per_tick;
-        ca.n_frames = p->n_maps;
-        ca.work_cap = (int)work_cap;
-        ca.tick_pix_stride = p->cap;
-        LSN_HIP(hipMemsetAsync(ca.work_cnt, 0, sizeof(int) * kCntStride * (size_t)n_tf, s));
-        const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && (p->cap % 8) == 0;
-        if (vec) hipLaunchKernelGGL(close_first_kernel<true>, dim3(grid), dim3(kThreads), 0, s, ca);
-        else     hipLaunchKernelGGL(close_first_kernel<false>, dim3(grid), dim3(kThreads), 0, s, ca);
-        hipLaunchKernelGGL(close_fix_kernel, dim3((unsigned)n_tf), dim3(kThreads), 0, s, ca);
-        // frames whose lists overflowed (flag set by close_fix_kernel): the ordered pass on the un-closed maps, copied out
+    const bool atomic_warp = p->cand_overflow || (force && atoi(force) != 0);
+    const bool wavefront = close_env && !strcmp(close_env, "wavefront");
+    const bool tiny_lists = tiny_env && atoi(tiny_env) != 0;   // tests: force the sweeps of the second pass
+    const bool vec_ptrs = ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && ((uintptr_t)d_depth_in & 15) == 0 &&
+                          ((uintptr_t)d_colors_in & 7) == 0 && (p->cap % 8) == 0;
+    const bool vec = p->vec_ok && vec_ptrs;
+    WarpSrc src;
+    src.depth = static_cast<const unsigned short *>(d_depth_in);
+    src.rgb = static_cast<const unsigned char *>(d_colors_in);
+    src.ctab = p->ctab.as<unsigned int>();
+    src.cand = p->cand.as<uint4>();
+    src.last_px = (long long)npix - 1;
+    // The un-closed maps go through memory when the closing cannot warp by itself: in place (a band would overwrite another band's
+    // sources), after the atomicMax warp, and for the wavefront kernel.
+    const bool scratch = in_place || atomic_warp || wavefront;
+    if (scratch) {
+        if (p->map_copy.reserve(2 * npix + 16) || p->colors_copy.reserve(3 * npix + 16)) return -1;
+        if (!atomic_warp) {
+            hipLaunchKernelGGL(radial_gather_pack_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(), src,
+                               p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->tiles_per_tick, p->cap);
+        } else {
+            if (p->winner.reserve(4 * npix)) return -1;
+            LSN_HIP(hipMemsetAsync(p->winner.p, 0, 4 * npix, s));
+            hipLaunchKernelGGL(radial_warp_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                               p->radial.as<RadialParams>(), src.depth, p->winner.as<unsigned int>(), p->tiles_per_tick, p->cap);
+            hipLaunchKernelGGL(radial_gather_kernel, dim3(grid), dim3(kThreads), 0, s, p->frames.as<FrameDesc>(), p->tile_frame.as<TileDesc>(),
+                               src.depth, src.rgb, (const unsigned int *)p->winner.as<unsigned int>(), p->map_copy.as<unsigned short>(),
+                               p->colors_copy.as<unsigned char>(), p->tiles_per_tick, p->cap);
+        }
+        src.depth = p->map_copy.as<unsigned short>();
+        src.rgb = p->colors_copy.as<unsigned char>();
+    }
+    const int n_tf = p->n_maps * p->n_ticks;
+    if (wavefront) {
+        int max_h = 1;
+        for (int v : p->h) max_h = v > max_h ? v : max_h;
+        int rows = max_h - 2 < 64 ? 64 : ((max_h - 2 + 63) / 64) * 64;
+        if (rows > 768) rows = 768;  // (rows + 2) x 32 columns x 6 B of LDS rings must fit in 160 KB
+        // One band per frame is the shortest chain of steps, but (rows + 2) x 192 B of LDS per workgroup then allows a single
+        // frame per CU.  With more frames than CUs, 256-row bands (49.5 KB: three frames per CU) win.
+        if ((long long)n_tf > 256 && rows > 256) rows = 256;
+        if (const char *env = getenv("LSN_RADIAL_ROWS")) {  // tuning: rows per band (multiple of 64, <= 768)
+            const int v = atoi(env);
+            if (v >= 64 && v <= 768 && v % 64 == 0) rows = v;
+        }
+        const size_t ring_bytes = (sizeof(unsigned int) + sizeof(unsigned short)) * kRing * (rows + 2);
         hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)n_tf), dim3(rows), ring_bytes, s, p->frames.as<FrameDesc>(), p->n_maps,
-                           p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap, (const int *)ca.flags,
-                           static_cast<unsigned short *>(d_depth), static_cast<unsigned char *>(d_colors));
+                           p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap);
         LSN_HIP(hipGetLastError());
+        // :259-260 the corrected maps replace the inputs
+        LSN_HIP(hipMemcpyAsync(d_depth, p->map_copy.p, 2 * npix, hipMemcpyDeviceToDevice, s));
+        LSN_HIP(hipMemcpyAsync(d_colors, p->colors_copy.p, 3 * npix, hipMemcpyDeviceToDevice, s));
         return 0;
     }
-    hipLaunchKernelGGL(radial_close_kernel, dim3((unsigned)n_tf), dim3(rows), ring_bytes, s, p->frames.as<FrameDesc>(), p->n_maps,
-                       p->map_copy.as<unsigned short>(), p->colors_copy.as<unsigned char>(), p->cap, (const int *)nullptr,
-                       (unsigned short *)nullptr, (unsigned char *)nullptr);
+    // bands: as many rows as fit the LDS budget of two workgroups per CU for the widest frame
+    int max_w = 1, max_h = 1;
+    for (int i = 0; i < p->n_maps; i++) { max_w = std::max(max_w, p->w[i]); max_h = std::max(max_h, p->h[i]); }
+    int rows = 16;
+    while (rows > 1 && band_lds_bytes(rows, max_w) > 79 * 1024) rows--;
+    if (const char *env = getenv("LSN_RADIAL_BAND_ROWS")) {  // tuning
+        const int v = atoi(env);
+        if (v >= 1 && band_lds_bytes(v, max_w) <= 160 * 1024) rows = v;
+    }
+    if (rows > max_h) rows = max_h;
+    if (band_lds_bytes(rows, max_w) > 160 * 1024 || (long long)(rows + 2) * max_w > 65535) {
+        lsn::set_error("lsnFusionRadialCorrect: a frame of width %d does not fit the closing kernel's LDS band", max_w);
+        return -1;
+    }
+    if (p->band_rows != rows) {
+        std::vector<BandDesc> bands;
+        p->bands_per_tick = make_bands(p, rows, bands);
+        if (p->bands.reserve(sizeof(BandDesc) * bands.size())) return -1;
+        LSN_HIP(hipMemcpyAsync(p->bands.p, bands.data(), sizeof(BandDesc) * bands.size(), hipMemcpyHostToDevice, s));
+        LSN_HIP(hipStreamSynchronize(s));  // bands is a local
+        p->band_rows = rows;
+    }
+    const long long holes_tick_bytes = (((p->cap + 64ll * (p->n_maps + 1)) / 8) + 31) & ~15ll;
+    const size_t cnt_bytes = sizeof(int) * kCntStride * (size_t)n_tf;
+    if (p->holes.reserve((size_t)holes_tick_bytes * p->n_ticks + 64) || p->work.reserve(8 * npix + 64)) return -1;
+    if (p->work_cnt.bytes < cnt_bytes) {
+        if (p->work_cnt.reserve(cnt_bytes)) return -1;
+        LSN_HIP(hipMemsetAsync(p->work_cnt.p, 0, cnt_bytes, s));   // the second pass leaves every counter cleared
+    }
+    if (!vec) LSN_HIP(hipMemsetAsync(p->holes.p, 0, (size_t)holes_tick_bytes * p->n_ticks, s));   // the pixel-by-pixel pass only sets bits
+    BandArgs ba;
+    ba.frames = p->frames.as<FrameDesc>();
+    ba.bands = p->bands.as<BandDesc>();
+    ba.src = src;
+    ba.out_d = static_cast<unsigned short *>(d_depth);
+    ba.out_c = static_cast<unsigned char *>(d_colors);
+    ba.holes = p->holes.as<unsigned char>();
+    ba.work = p->work.as<unsigned int>();
+    ba.work_cnt = p->work_cnt.as<int>();
+    ba.bands_per_tick = p->bands_per_tick;
+    ba.n_frames = p->n_maps;
+    ba.rows = rows;
+    ba.tick_pix_stride = p->cap;
+    ba.holes_tick_bytes = holes_tick_bytes;
+    const size_t lds = (size_t)band_lds_bytes(rows, max_w);
+    const dim3 bgrid((unsigned)((long long)p->bands_per_tick * p->n_ticks));
+    if (!p->band_attr_set) {
+        // more than 64 KB of dynamic LDS has to be asked for, once per kernel
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radial_band_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radial_band_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radial_band_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radial_band_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        p->band_attr_set = true;
+    }
+    if (!scratch) {
+        if (vec) hipLaunchKernelGGL((radial_band_kernel<true, true>), bgrid, dim3(kBandThreads), lds, s, ba);
+        else     hipLaunchKernelGGL((radial_band_kernel<true, false>), bgrid, dim3(kBandThreads), lds, s, ba);
+    } else {
+        if (vec) hipLaunchKernelGGL((radial_band_kernel<false, true>), bgrid, dim3(kBandThreads), lds, s, ba);
+        else     hipLaunchKernelGGL((radial_band_kernel<false, false>), bgrid, dim3(kBandThreads), lds, s, ba);
+    }
+    FixArgs fa;
+    fa.frames = ba.frames;
+    fa.out_d = ba.out_d;
+    fa.out_c = ba.out_c;
+    fa.holes = ba.holes;
+    fa.work = ba.work;
+    fa.work_cnt = ba.work_cnt;
+    fa.n_frames = p->n_maps;
+    fa.list_cap = tiny_lists ? 8 : kFixList;
+    fa.tick_pix_stride = p->cap;
+    fa.holes_tick_bytes = holes_tick_bytes;
+    hipLaunchKernelGGL(close_fix_kernel, dim3((unsigned)n_tf), dim3(kFixThreads), 0, s, fa);
     LSN_HIP(hipGetLastError());
-    // :259-260 the corrected maps replace the inputs
-    LSN_HIP(hipMemcpyAsync(d_depth, p->map_copy.p, 2 * npix, hipMemcpyDeviceToDevice, s));
-    LSN_HIP(hipMemcpyAsync(d_colors, p->colors_copy.p, 3 * npix, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
+extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, void *d_depth, void *d_colors, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !intr_params || !d_depth || !d_colors) {
+        lsn::set_error("lsnFusionRadialCorrect: null argument");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    return radial_correct(p, intr_params, d_depth, d_colors, d_depth, d_colors, lsn::as_stream(stream));
+}
+
+extern "C" int lsnFusionRadialCorrectTo(LsnFusion *p, const float *intr_params, const void *d_depth_in, const void *d_colors_in, void *d_depth_out,
+                                        void *d_colors_out, void *stream)
+{
+    lsn::clear_error();
+    if (!p || !intr_params || !d_depth_in || !d_colors_in || !d_depth_out || !d_colors_out) {
+        lsn::set_error("lsnFusionRadialCorrectTo: null argument");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    return radial_correct(p, intr_params, d_depth_in, d_colors_in, d_depth_out, d_colors_out, lsn::as_stream(stream));
+}

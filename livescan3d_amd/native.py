@@ -23,7 +23,7 @@ EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
-    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
+    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
     "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
     "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
@@ -83,6 +83,8 @@ def lib():
     L.depthMapAndColorSetRadialCorrection.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     L.lsnFusionRadialCorrect.restype = C.c_int
     L.lsnFusionRadialCorrect.argtypes = [vp, vp, vp, vp, vp]
+    L.lsnFusionRadialCorrectTo.restype = C.c_int
+    L.lsnFusionRadialCorrectTo.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.createMesh.restype = C.POINTER(Mesh)
     L.createMesh.argtypes = []
     L.deleteMesh.restype = None
@@ -389,6 +391,13 @@ class FusionPlan:
         intr = _as(intr, np.float32).ravel()
         assert intr.size == 7 * self.n_maps
         _check(lib().lsnFusionRadialCorrect(self._h, _ptr(intr), d_depth, d_colors, stream), "lsnFusionRadialCorrect")
+
+    def radial_correct_to(self, intr, d_depth, d_colors, d_depth_out, d_colors_out, stream=0):
+        """Out-of-place radial correction (the cheaper form: the un-closed maps never leave the GPU's LDS)."""
+        intr = _as(intr, np.float32).ravel()
+        assert intr.size == 7 * self.n_maps
+        _check(lib().lsnFusionRadialCorrectTo(self._h, _ptr(intr), d_depth, d_colors, d_depth_out, d_colors_out, stream),
+               "lsnFusionRadialCorrectTo")
 
     def run_mesh(self, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream=0):
         """Vertices + triangles (the reference's complete merge call); d_triangles: n_ticks x 2*capacity x 3 int32."""

@@ -108,13 +108,14 @@ def test_both_warp_paths_agree_with_the_oracle(gpu, orc, monkeypatch):
         assert np.array_equal(np.asarray(got_c).ravel(), np.asarray(want_c).ravel()), forced
 
 
-@pytest.mark.parametrize("env", [{}, {"LSN_RADIAL_TINY_LISTS": "1"}, {"LSN_RADIAL_CLOSE": "wavefront"}],
-                         ids=["two-pass", "two-pass-overflow-fallback", "wavefront"])
+@pytest.mark.parametrize("env", [{}, {"LSN_RADIAL_TINY_LISTS": "1"}, {"LSN_RADIAL_CLOSE": "wavefront"}, {"LSN_RADIAL_BAND_ROWS": "5"},
+                                 {"LSN_RADIAL_FORCE_ATOMIC": "1", "LSN_RADIAL_TINY_LISTS": "1"}],
+                         ids=["two-pass", "two-pass-sweeps", "wavefront", "five-row-bands", "atomic-warp-sweeps"])
 def test_hole_closing_paths_agree_with_the_oracle(gpu, orc, monkeypatch, env):
-    """The two-pass hole closing (streaming first pass + per-frame re-evaluation rounds), its per-frame fall-back when a frame's work
-    list overflows (forced with tiny lists: the ordered wavefront kernel runs for the flagged frames and copies them out) and the
-    wavefront kernel alone: scene frames (thousands of fills, chains of fills feeding fills), a ragged rig (the pixel-by-pixel first
-    pass) and a batch through the device-resident entry point."""
+    """The two-pass hole closing (bands of rows warped and closed in LDS + per-frame re-evaluation rounds), the full sweeps a frame
+    falls back to when a round list outgrows LDS (forced with tiny lists), odd band heights, the atomicMax warp in front of it, and
+    the wavefront kernel alone: scene frames (thousands of fills, chains of fills feeding fills), a ragged rig (the pixel-by-pixel
+    path) and a batch through the device-resident entry points, in place and out of place."""
     import torch
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -131,15 +132,24 @@ def test_hole_closing_paths_agree_with_the_oracle(gpu, orc, monkeypatch, env):
     plan.radial_correct(rigs[0].intr, depth.data_ptr(), rgb.data_ptr(), int(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     got_d, got_c = depth.cpu().numpy().view(np.uint8), rgb.cpu().numpy()
+    depth2 = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda()
+    rgb2 = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()
+    out_d, out_c = torch.zeros_like(depth2), torch.zeros_like(rgb2)
+    plan.radial_correct_to(rigs[0].intr, depth2.data_ptr(), rgb2.data_ptr(), out_d.data_ptr(), out_c.data_ptr(), int(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(depth2.cpu().numpy(), np.stack([r.depth_maps.view(np.int16) for r in rigs])), "out of place: the input was touched"
+    got2_d, got2_c = out_d.cpu().numpy().view(np.uint8), out_c.cpu().numpy()
     for k in range(T):
         want_d, want_c = orc.radial_correction(rigs[k].depth_maps, rigs[k].depth_colors, rigs[k].widths, rigs[k].heights, rigs[0].intr)
         assert np.array_equal(got_d[k], np.asarray(want_d).view(np.uint8).ravel()), f"tick {k}: depth"
         assert np.array_equal(got_c[k], np.asarray(want_c).ravel()), f"tick {k}: colours"
+        assert np.array_equal(got2_d[k], np.asarray(want_d).view(np.uint8).ravel()), f"tick {k}: depth (out of place)"
+        assert np.array_equal(got2_c[k], np.asarray(want_c).ravel()), f"tick {k}: colours (out of place)"
 
 
 def test_more_frames_than_compute_units(gpu, orc):
-    """With more than 256 sensor-frames in a batch the hole-closing kernel switches to 256-row bands (two bands for h = 424,
-    three frames per CU); a 1024-row frame needs two 768-row bands.  Every frame against the oracle."""
+    """A batch with more sensor-frames than the GPU has compute units (the second pass runs one workgroup per frame), and a
+    1024-wide frame (eight-row bands).  Every frame against the oracle."""
     import torch
     T, N, w, h = 33, 8, 512, 424                                 # 264 frames
     rigs = [synth.make_rig("noise" if k % 3 else "scene", N, w, h, seed=14, tick=k) for k in range(T)]
