@@ -73,6 +73,16 @@ void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps, unsigned c
 void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
                                          int *heights, float *intr_params);
 
+/* Extension for hosts that want one call per tick: LiveScanServer's tick is depthMapAndColorSetRadialCorrection followed by
+ * generateMeshFromDepthMaps on the same arrays (LiveScanServer/KinectServer.cs:518-525, then :354-374), which sends the same
+ * 8.7 MB of frames over PCIe twice.  This export does both with ONE upload: radial correction on the device, then the merge
+ * call (flags false, false; vertices + triangles) on the corrected frames.  write_back_corrected != 0 also writes the corrected
+ * maps back into depth_maps / depth_colors, as the separate export does (KinectServer keeps them, e.g. for recording);
+ * 0 leaves the caller's arrays untouched.  Result = the two reference exports called one after the other, bit for bit. */
+void lsnCorrectAndGenerateMesh(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+                               float *intr_params, float *wtransform_params, Mesh *out_mesh, float minX, float minY, float minZ,
+                               float maxX, float maxY, float maxZ, int write_back_corrected);
+
 /* Replaces createMesh / deleteMesh, src/NativeUtils/depthprocessing.cpp:1818-1835.  deleteMesh releases the two
  * arrays only (not the struct) and, unlike the reference, also nulls them so a second call is harmless. */
 Mesh *createMesh(void);

@@ -350,9 +350,12 @@ LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, in
 // Fuses `count` sensors of one tick from host buffers into out_mesh.  first/count select the sensors
 // (generateVerticesFromDepthMap uses one); total_d / total_c are the bytes of the caller's whole arrays as far as the call
 // knows them (what gets registered).  c.mu held.
+// radial (optional): the call starts with the radial correction of the frames (depthMapAndColorSetRadialCorrection) on the device;
+// radial_back_d / radial_back_c (optional): the corrected maps are also copied to these host arrays, like the separate export does.
 int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char *depth_colors, size_t total_d, size_t total_c,
                     const int *widths, const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first,
-                    int count, bool with_triangles)
+                    int count, bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr,
+                    unsigned char *radial_back_c = nullptr)
 {
     LsnFusion *plan = get_plan(c, widths, heights, first, count);
     if (!plan) return -1;
@@ -396,8 +399,24 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
     if (!small) LSN_HIP(hipEventRecord(c.ev_col, up));
     if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, c.stream)) return -1;
     if (!small) LSN_HIP(hipStreamWaitEvent(c.stream, c.ev_depth, 0));
+    const void *run_d = c.d_depth.p, *run_c = c.d_colors.p;
+    if (radial) {
+        // the correction reads depth and colours of the raw frames and leaves the corrected ones in a second pair of buffers, which
+        // the passes below then read; the corrected maps go home on the download stream while the fusion kernels run
+        if (c.d_depth2.reserve(dbytes + 16) || c.d_colors2.reserve(cbytes + 16)) return -1;
+        if (!small) LSN_HIP(hipStreamWaitEvent(c.stream, c.ev_col, 0));
+        if (lsnFusionRadialCorrectTo(plan, intr + 7 * first, c.d_depth.p, c.d_colors.p, c.d_depth2.p, c.d_colors2.p, c.stream)) return -1;
+        run_d = c.d_depth2.p;
+        run_c = c.d_colors2.p;
+        if (radial_back_d && radial_back_c) {
+            LSN_HIP(hipEventRecord(c.ev_down, c.stream));
+            if (!small) LSN_HIP(hipStreamWaitEvent(down, c.ev_down, 0));
+            LSN_HIP(hipMemcpyAsync(radial_back_d + dskip, c.d_depth2.p, dbytes, hipMemcpyDeviceToHost, down));
+            LSN_HIP(hipMemcpyAsync(radial_back_c + cskip, c.d_colors2.p, cbytes, hipMemcpyDeviceToHost, down));
+        }
+    }
     lsn::RunHooks hooks;
-    hooks.colours_ready = small ? nullptr : c.ev_col;
+    hooks.colours_ready = (small || radial) ? nullptr : c.ev_col;
     hooks.h_offsets = c.h_off;
     hooks.counted = c.ev_counted;
     hooks.written = c.ev_written;
@@ -407,10 +426,10 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
         if (c.d_tri.reserve((size_t)tcap * 12) || c.d_tri_off.reserve(sizeof(int) * (count + 1))) return -1;
         hooks.h_tri_offsets = c.h_toff;
         hooks.tri_counted = c.ev_tri_counted;
-        if (lsn::run_mesh(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.d_tri.p, c.d_tri_off.as<int>(), c.stream, &hooks))
+        if (lsn::run_mesh(plan, run_d, run_c, c.d_out.p, c.d_off.as<int>(), c.d_tri.p, c.d_tri_off.as<int>(), c.stream, &hooks))
             return -1;
     } else {
-        if (lsn::run_hooked(plan, c.d_depth.p, c.d_colors.p, c.d_out.p, c.d_off.as<int>(), c.stream, &hooks)) return -1;
+        if (lsn::run_hooked(plan, run_d, run_c, c.d_out.p, c.d_off.as<int>(), c.stream, &hooks)) return -1;
     }
     // the vertex count arrives while the write pass (and the triangulation) are still running
     LSN_HIP(hipEventSynchronize(c.ev_counted));
@@ -476,7 +495,7 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
 
 int fuse_host(Ctx &c, int n_maps_known, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
               const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count,
-              bool with_triangles)
+              bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr, unsigned char *radial_back_c = nullptr)
 {
     size_t total_d = 0, total_c = 0;
     for (int i = 0; i < n_maps_known; i++) {
@@ -484,7 +503,7 @@ int fuse_host(Ctx &c, int n_maps_known, const unsigned char *depth_maps, const u
         total_c += (size_t)widths[i] * heights[i] * 3;
     }
     const int rc = fuse_host_inner(c, depth_maps, depth_colors, total_d, total_c, widths, heights, intr, wt, out, bounds6, first, count,
-                                   with_triangles);
+                                   with_triangles, radial, radial_back_d, radial_back_c);
     if (rc) drain(c);   // nothing of a failed call stays in flight
     return rc;
 }
@@ -542,6 +561,25 @@ extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps,
                     (int)bcolor_transfer, (int)bgenerate_triangles);
         }
     }
+}
+
+extern "C" void lsnCorrectAndGenerateMesh(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+                                          float *intr_params, float *wtransform_params, Mesh *out_mesh, float minX, float minY, float minZ,
+                                          float maxX, float maxY, float maxZ, int write_back_corrected)
+{
+    lsn::clear_error();
+    if (!out_mesh) return;
+    Ctx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (n_maps <= 0 || !depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params) {
+        if (n_maps != 0) lsn::set_error("lsnCorrectAndGenerateMesh: bad arguments");
+        empty_mesh(c, out_mesh);
+        return;
+    }
+    const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
+    if (ensure_ready(c) || fuse_host(c, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps,
+                                     true, true, write_back_corrected ? depth_maps : nullptr, write_back_corrected ? depth_colors : nullptr))
+        empty_mesh(c, out_mesh);
 }
 
 extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,

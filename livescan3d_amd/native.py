@@ -21,7 +21,7 @@ VERTEX_DTYPE = np.dtype([("R", "u1"), ("G", "u1"), ("B", "u1"), ("A", "u1"),
 # every symbol include/NativeUtils.h declares
 EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
-    "lsnGetLastError", "lsnDeviceCount",
+    "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
@@ -79,6 +79,8 @@ def lib():
     L.generateMeshFromDepthMaps.restype = None
     L.generateMeshFromDepthMaps.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(Mesh), C.c_bool,
                                             f, f, f, f, f, f, C.c_bool]
+    L.lsnCorrectAndGenerateMesh.restype = None
+    L.lsnCorrectAndGenerateMesh.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(Mesh), f, f, f, f, f, f, C.c_int]
     L.depthMapAndColorSetRadialCorrection.restype = None
     L.depthMapAndColorSetRadialCorrection.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     L.lsnFusionRadialCorrect.restype = C.c_int
@@ -301,6 +303,27 @@ def radial_correction(depth_maps, depth_colors, widths, heights, intr):
     if err:
         raise NativeUtilsError(err)
     return dm, dc
+
+
+def correct_and_generate_mesh(depth_maps, depth_colors, widths, heights, intr, wt, bounds, write_back=True):
+    """One call per tick (extension): radial correction + merge call with a single upload.  Returns (vertices, triangles,
+    corrected depth as uint8, corrected colours); with write_back=False the last two are the untouched inputs."""
+    require_gpu()
+    widths, heights = _as(widths, np.int32), _as(heights, np.int32)
+    n = len(widths)
+    dm = np.ascontiguousarray(depth_maps).view(np.uint8).ravel().copy()
+    dc = _as(depth_colors, np.uint8).ravel().copy()
+    intr, wt, b = _as(intr, np.float32).ravel(), _as(wt, np.float32).ravel(), _as(bounds, np.float32).ravel()
+    assert intr.size == 7 * n and wt.size == 12 * n and b.size == 6
+    mesh = Mesh()
+    lib().lsnCorrectAndGenerateMesh(n, _ptr(dm), _ptr(dc), _ptr(widths), _ptr(heights), _ptr(intr), _ptr(wt), C.byref(mesh),
+                                    *[float(x) for x in b], 1 if write_back else 0)
+    err = last_error()
+    if err and mesh.nVertices == 0:
+        lib().deleteMesh(C.byref(mesh))
+        raise NativeUtilsError(err)
+    v, t = _copy_mesh(mesh)
+    return v, t, dm, dc
 
 
 def generate_vertices_from_depth_map(depth_maps, depth_colors, widths, heights, intr, wt, bounds, index):

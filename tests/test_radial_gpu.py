@@ -164,3 +164,23 @@ def test_more_frames_than_compute_units(gpu, orc):
         assert np.array_equal(got_d[k], want_d), f"tick {k}: depth"
         assert np.array_equal(got_c[k], want_c), f"tick {k}: colour"
     _check(orc, synth.make_rig("noise", 1, 1024, 1024, seed=15), "1024x1024")
+
+
+def test_one_call_per_tick_equals_the_two_exports(gpu, orc):
+    """lsnCorrectAndGenerateMesh (one upload) against depthMapAndColorSetRadialCorrection followed by generateMeshFromDepthMaps
+    (KinectServer.cs:518-525 then :354-374), and both against the oracle's chain: corrected maps, vertices and triangles bit for bit."""
+    for rig in (synth.make_rig("scene", 8, 512, 424, seed=31, bounds=synth.CROP_BOUNDS), synth.make_rig("scene", 2, 250, 120, seed=32),
+                synth.make_rig("noise", 3, 64, 48, seed=33)):
+        d2, c2 = native.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+        v2, t2 = native.generate_mesh_from_depth_maps(d2, c2, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        for write_back in (True, False):
+            v1, t1, d1, c1 = native.correct_and_generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds,
+                                                              write_back=write_back)
+            assert v1.tobytes() == v2.tobytes() and np.array_equal(t1, t2)
+            if write_back:
+                assert np.array_equal(d1, d2) and np.array_equal(c1, c2)
+            else:
+                assert np.array_equal(d1, np.ascontiguousarray(rig.depth_maps).view(np.uint8).ravel()) and np.array_equal(c1, np.asarray(rig.depth_colors).ravel())
+        want_d, want_c = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+        want_v, _, want_t = orc.generate_mesh(want_d, want_c, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        assert np.array_equal(d2, np.asarray(want_d).view(np.uint8).ravel()) and v2.tobytes() == want_v.tobytes() and np.array_equal(t2, want_t)
