@@ -451,7 +451,7 @@ struct LsnFusion {
     lsn::DevBuf winner, map_copy, colors_copy, radial;  // radial-correction scratch, allocated on first use
     lsn::DevBuf cand;                                   // [pixels per tick][4] warp candidates of the current intrinsics
     lsn::DevBuf ctab;                                   // [pixels per tick] their compact form (one dword per destination)
-    lsn::DevBuf bands, holes, work, work_cnt;           // hole closing: band list, hole bitmap, per-frame work lists and their counters
+    lsn::DevBuf bands, holes, work, work2, work_cnt;    // hole closing: band list, hole bitmap, per-frame work lists (two, used in turn) and their counters
     int band_rows = 0, bands_per_tick = 0;              // what `bands` was built for
     bool band_attr_set = false;
     std::vector<float> radial_intr;                     // the intrinsics `cand` was built for

@@ -850,9 +850,10 @@ struct FixArgs {
     unsigned short *out_d;
     unsigned char *out_c;
     const unsigned char *holes;
-    const unsigned int *work;
-    int *work_cnt;
+    const unsigned int *work;        // the list the per-frame kernel starts from: 2 * npix entries per frame at 2 * (first pixel of the frame)
+    int *work_cnt;                   // [3][n_ticks * n_frames] x kCntStride: band kernel -> first grid-wide round -> second -> per-frame kernel
     int n_frames, list_cap;          // list_cap: entries a round list may hold (kFixList; the tests shrink it to force the sweeps)
+    int n_tf, cnt_index;             // cnt_index: which of the three counter arrays the per-frame kernel starts from
     long long tick_pix_stride, holes_tick_bytes;
 };
 
@@ -908,6 +909,52 @@ __device__ __forceinline__ bool fix_pixel(unsigned short *out_d, unsigned char *
     return true;
 }
 
+constexpr int kOverflow = 0x40000000;   // a list counter at or above this: the list overflowed somewhere up the chain, sweep the frame
+
+// One re-evaluation round over ALL frames at once (the first rounds hold thousands of pixels per frame: one workgroup per frame would
+// walk them twelve at a time... 256 at a time, a dozen dependent memory round trips).  Reads frame tf's list (cnt_in entries at
+// list_in + in_stride * first pixel), appends the hole successors of every changed pixel to its list in list_out.  Pixels of one
+// round that are neighbours may see each other half-written; whoever changes a pixel re-lists its successors, so the next round (behind
+// a kernel boundary) evaluates them again with everything in place.
+__global__ __launch_bounds__(kThreads) void close_fix_round_kernel(const FixArgs a, const unsigned int *list_in, const int *cnt_in, int in_stride,
+                                                                   int in_cap_num, int in_cap_den, unsigned int *list_out, int *cnt_out,
+                                                                   int out_stride, int out_cap_num, int out_cap_den, int blocks_per_frame)
+{
+    const int tf = blockIdx.x / blocks_per_frame, b = blockIdx.x - tf * blocks_per_frame;
+    const int tick = tf / a.n_frames, f = tf - tick * a.n_frames;
+    const FrameDesc fd = a.frames[f];
+    const int w = fd.w, h = fd.h;
+    const long long fb = tick * a.tick_pix_stride + fd.depth_off;
+    const int n_in = cnt_in[kCntStride * tf];
+    const int in_cap = (int)((long long)fd.npix * in_cap_num / in_cap_den), out_cap = (int)((long long)fd.npix * out_cap_num / out_cap_den);
+    if (n_in > in_cap) {                                   // overflowed: hand the verdict on, the per-frame kernel sweeps
+        if (b == 0 && threadIdx.x == 0) cnt_out[kCntStride * tf] = kOverflow;
+        return;
+    }
+    unsigned short *out_d = a.out_d + fb;
+    unsigned char *out_c = a.out_c + 3 * fb;
+    const unsigned char *holes = a.holes + tick * a.holes_tick_bytes;
+    const long long bit0 = hole_base_bit(fd, f);
+    const unsigned int *lin = list_in + in_stride * fb;
+    unsigned int *lout = list_out + out_stride * fb;
+    for (int i0 = b * kThreads; i0 < n_in; i0 += blocks_per_frame * kThreads) {
+        const int i = i0 + (int)threadIdx.x;
+        if (i0 + (int)(threadIdx.x & ~63u) >= n_in) continue;   // nothing left for this wave (wave-uniform)
+        unsigned int succ = 0;
+        int x = 0, y = 0;
+        if (i < n_in) fix_pixel(out_d, out_c, holes, bit0, (int)lin[i], w, h, fd.inv_w, succ, x, y);
+        int slot = wave_reserve(cnt_out + kCntStride * tf, __popc(succ));
+#pragma unroll
+        for (int sidx = 0; sidx < 4; sidx++) {
+            if ((succ >> sidx) & 1u) {
+                const int k = 4 + sidx;
+                if (slot < out_cap) lout[slot] = (unsigned int)((y + kDy[k]) * w + x + kDx[k]);
+                slot++;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kFixThreads) void close_fix_kernel(const FixArgs a)
 {
     __shared__ unsigned int lists[2][kFixList];
@@ -924,11 +971,13 @@ __global__ __launch_bounds__(kFixThreads) void close_fix_kernel(const FixArgs a)
     unsigned char *out_c = a.out_c + 3 * fb;
     const unsigned char *holes = a.holes + tick * a.holes_tick_bytes;
     const long long bit0 = hole_base_bit(fd, f);
-    const int n_listed = a.work_cnt[kCntStride * tf];
+    int *cnt = a.work_cnt + kCntStride * tf;
+    const size_t cnt_step = (size_t)kCntStride * a.n_tf;
+    const int n_listed = cnt[a.cnt_index * cnt_step];
     const int n0 = n_listed > 2 * fd.npix ? 0 : n_listed;   // (a frame whose list overflowed is swept instead)
     __syncthreads();                                   // everybody has read the counter ...
     if (threadIdx.x == 0) {
-        a.work_cnt[kCntStride * tf] = 0;               // ... which is left cleared for the next call
+        cnt[0] = cnt[cnt_step] = cnt[2 * cnt_step] = 0;   // ... and all three are left cleared for the next call
         s_n[0] = s_n[1] = 0;
         s_flag = 0;
     }
@@ -1124,8 +1173,8 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
         p->band_rows = rows;
     }
     const long long holes_tick_bytes = (((p->cap + 64ll * (p->n_maps + 1)) / 8) + 31) & ~15ll;
-    const size_t cnt_bytes = sizeof(int) * kCntStride * (size_t)n_tf;
-    if (p->holes.reserve((size_t)holes_tick_bytes * p->n_ticks + 64) || p->work.reserve(8 * npix + 64)) return -1;
+    const size_t cnt_bytes = 3 * sizeof(int) * kCntStride * (size_t)n_tf;
+    if (p->holes.reserve((size_t)holes_tick_bytes * p->n_ticks + 64) || p->work.reserve(8 * npix + 64) || p->work2.reserve(4 * npix + 64)) return -1;
     if (p->work_cnt.bytes < cnt_bytes) {
         if (p->work_cnt.reserve(cnt_bytes)) return -1;
         LSN_HIP(hipMemsetAsync(p->work_cnt.p, 0, cnt_bytes, s));   // the second pass leaves every counter cleared
@@ -1171,8 +1220,23 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
     fa.work_cnt = ba.work_cnt;
     fa.n_frames = p->n_maps;
     fa.list_cap = tiny_lists ? 8 : kFixList;
+    fa.n_tf = n_tf;
     fa.tick_pix_stride = p->cap;
     fa.holes_tick_bytes = holes_tick_bytes;
+    // A few frames (a live tick): the first two rounds -- thousands of pixels per frame -- over all frames at once, the tail one workgroup
+    // per frame (8 frames: 130 -> 102 us).  A large batch is bound by the scattered lines those rounds touch, not by their latency, and
+    // the two extra launches only cost (512 frames: 242 -> 305 us): there the per-frame kernel does it all.
+    fa.cnt_index = 0;
+    if (n_tf <= 128) {
+        fa.cnt_index = 2;
+        int *c0 = ba.work_cnt, *c1 = c0 + (size_t)kCntStride * n_tf, *c2 = c1 + (size_t)kCntStride * n_tf;
+        const int bpf = 12;
+        const dim3 rgrid((unsigned)((long long)n_tf * bpf));
+        hipLaunchKernelGGL(close_fix_round_kernel, rgrid, dim3(kThreads), 0, s, fa, (const unsigned int *)p->work.as<unsigned int>(), (const int *)c0, 2, 2, 1,
+                           p->work2.as<unsigned int>(), c1, 1, 1, tiny_lists ? (1 << 30) : 1, bpf);
+        hipLaunchKernelGGL(close_fix_round_kernel, rgrid, dim3(kThreads), 0, s, fa, (const unsigned int *)p->work2.as<unsigned int>(), (const int *)c1, 1, 1,
+                           tiny_lists ? (1 << 30) : 1, p->work.as<unsigned int>(), c2, 2, 2, 1, bpf);
+    }
     hipLaunchKernelGGL(close_fix_kernel, dim3((unsigned)n_tf), dim3(kFixThreads), 0, s, fa);
     LSN_HIP(hipGetLastError());
     return 0;
