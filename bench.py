@@ -169,9 +169,11 @@ def main():
     use_sx = survivors_ok and not use_shard and args.exchange in ("survivors", "survivors-python")
     if multi:
         from livescan3d_amd.sharding import ShardedFusion, SurvivorExchange
+        shard_preflight = None
         if use_shard:
-            # the library's own RCCL step; if it cannot be set up on ANY rank (e.g. librccl missing), every rank falls back to the
-            # Python-driven protocol together -- the decision is collective, so no rank is left waiting in a communicator
+            # The library's own RCCL step.  ShardedFusion prepares every rank locally, lets the ranks agree that all are ready and only
+            # then enters the blocking communicator set-up, so a rank that cannot prepare (e.g. librccl missing) makes EVERY rank raise
+            # here; the flag below turns "any rank failed" into a collective decision to fall back to the Python-driven protocol.
             err = None
             try:
                 shard = ShardedFusion(rank, world, B, [w] * S, [h] * S, dev)
@@ -185,12 +187,40 @@ def main():
                 if shard is not None:
                     shard.close()
                 shard, use_shard, use_sx = None, False, True
+                shard_preflight = f"unavailable: {err}"
+        if use_shard and world > 1:
+            # Preflight of the first real N > 1 run: one step through lsnShardStep and one through the Python-driven survivor exchange
+            # (the protocol the gloo tests cover) on the same frames; offsets and one tick's cloud must agree on every rank, else all
+            # ranks take the Python-driven path for the timed steps and the line says so.
+            bad = 0
+            try:
+                whole = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
+                whole.set_params(intr_all, wt_all, bounds)
+                sx = SurvivorExchange(world, fus, whole, via_host=share)
+                m_v, m_o = shard.step(depth, rgb, stream)
+                p_v, p_o = sx.exchange(depth, rgb, stream)
+                torch.cuda.synchronize()
+                n0 = int(p_o[0, -1].item())
+                bad = 0 if (bool(torch.equal(m_o, p_o)) and n0 > 0 and bool(torch.equal(m_v[0, :n0], p_v[0, :n0]))) else 1
+            except Exception as ex:  # noqa: BLE001
+                print(f"[bench rank {rank}] shard preflight raised {type(ex).__name__}: {ex}", file=sys.stderr)
+                bad = 1
+            flag = torch.tensor([bad], dtype=torch.int32, device="cpu" if share else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                shard_preflight = "mismatch"
+                shard.close()
+                shard, use_shard, use_sx = None, False, True     # sx / whole are kept for the timed steps
+            else:
+                shard_preflight = "ok"
+                sx = whole = None
         if use_shard:
             pass
         elif use_sx:
-            whole = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
-            whole.set_params(intr_all, wt_all, bounds)
-            sx = SurvivorExchange(world, fus, whole, via_host=share)
+            if sx is None:
+                whole = DeviceFusion(B, [w] * S, [h] * S, device=dev_index, mode=0)
+                whole.set_params(intr_all, wt_all, bounds)
+                sx = SurvivorExchange(world, fus, whole, via_host=share)
         else:
             xch = MergedCloudExchange(world, B, S_loc, fus.capacity, dev, compact=not args.padded_exchange, via_host=share)
     prof_plan = shard.shard.plan(True) if use_shard else (whole.plan if use_sx else fus.plan)
@@ -293,6 +323,7 @@ def main():
                 "parallelism": f"sensor-shard{world}" + (("+allgather(survivors; lsnShard* = C++ host glue + RCCL inside the library)" if use_shard else
                                                           "+allgather(survivors; Python over torch.distributed)" if use_sx else "+allgather(vertices)") if multi else ""),
                 "bounds": [float(x) for x in bounds],
+                **({"shard_preflight": shard_preflight, "rccl_library": native.shard_rccl_path() if (use_shard or shard_preflight) else None} if multi else {}),
                 "parity": "outputs bit-identical to the CPU restatement of the reference (tests/, -m gpu); that restatement is PARITY UNPINNED for "
                           "the depth -> cloud path, the radial correction and the non-NN part of ICP (the reference ships no fixtures and "
                           "depthprocessing.cpp / icp.cpp cannot be built here without stand-ins); nearest neighbour and triangulation are "

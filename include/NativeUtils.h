@@ -232,17 +232,28 @@ int lsnFusionReconstructRun(LsnFusion *all, int n_shards, int maps_per_shard, co
  * instead (lsnFusionRun on the block, one all-gather per tick cut to the step's largest shard, lsnMergeShards' packing pass):
  * the same merged cloud for about three times the bytes on the links.
  *
- * Rendezvous: rank 0 calls lsnShardUniqueId and hands the 128 bytes to the other ranks by whatever channel the host has
- * (a file, a socket, torch.distributed); every rank then calls lsnShardCreate with the same id (collective: blocks until
- * all ranks have arrived).  widths / heights / intr / wt describe ALL n_maps sensors on every rank.
+ * Rendezvous, in two steps so that no rank is left waiting inside a communicator that will never form: (1) every rank calls
+ * lsnShardPrepare -- everything that can fail on one rank alone: argument checks, loading RCCL, device buffers -- and rank 0
+ * calls lsnShardUniqueId; (2) the ranks agree, over whatever channel the host has (a file, a socket, torch.distributed), that ALL
+ * of them are ready, and rank 0's 128 bytes go to everybody; (3) only then every rank calls lsnShardConnect with the same id
+ * (collective: ncclCommInitRank blocks until all ranks have arrived).  lsnShardCreate = Prepare + Connect for hosts that have no
+ * such channel.  widths / heights / intr / wt describe ALL n_maps sensors on every rank.
+ * RCCL is loaded on first use: an instance already mapped in the process (PyTorch-ROCm's bundled one) is preferred, so a process
+ * never holds two; lsnShardRcclPath reports the file.
  * lsnShardStep is collective and asynchronous on `stream` except for one event wait on a small pinned read-back (the element
- * count of a collective is a host-side argument; $LSN_SHARD_PADDED=1 trades it for full-capacity transfers).
+ * count of a collective is a host-side argument; $LSN_SHARD_PADDED=1 trades it for full-capacity transfers).  All collectives
+ * run on the caller's stream in one ncclGroup; $LSN_SHARD_CHUNKS=n (opt-in, not yet verified on a multi-GPU node) sends the
+ * streams in n groups of ticks on a second stream beside the reconstruction.  After a failed step the handle refuses further
+ * steps (the ranks' communicators are no longer in step): destroy it.
  * *d_merged: n_ticks x lsnShardMergedCapacity() VertexC4ubV3f, *d_merged_offsets: n_ticks x (n_maps + 1) ints, both owned
  * by the handle and valid until its next step. */
 typedef struct LsnShard LsnShard;
 int lsnShardUniqueId(unsigned char *id128);
+LsnShard *lsnShardPrepare(int device, int rank, int world, int n_ticks, int n_maps, const int *widths, const int *heights);
+int lsnShardConnect(LsnShard *shard, const unsigned char *id128);
 LsnShard *lsnShardCreate(int device, int rank, int world, const unsigned char *id128, int n_ticks, int n_maps, const int *widths,
                          const int *heights);
+int lsnShardRcclPath(char *buf, int len);
 void lsnShardDestroy(LsnShard *shard);
 long long lsnShardMergedCapacity(const LsnShard *shard);
 int lsnShardSetParams(LsnShard *shard, const float *intr_all, const float *wt_all, const float *bounds6, void *stream);

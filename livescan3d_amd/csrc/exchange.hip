@@ -499,7 +499,16 @@ int lsn::merge_shards(int device, int n_shards, int n_ticks, int maps_per_shard,
 // RCCL is loaded with dlopen on first use: a single-GPU host of this library never maps it.
 // -------------------------------------------------------------------------------------------------------------------------
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+
+// RCCL is only ever dlopen()ed, so the library builds without the rccl development headers: the handful of types and constants the
+// seven entry points need are declared here (the nccl.h ABI: opaque communicator, 128-byte id, ncclSuccess = 0, ncclUint8 = 1,
+// ncclInt32 = 2).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2 } ncclDataType_t;
+}
 
 namespace {
 
@@ -512,6 +521,18 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string path;   // the file the entry points came from
+};
+
+// ncclGroupStart ... ncclGroupEnd with the end guaranteed: a collective that fails inside a group must not leave the thread's group
+// open (every later collective would be queued and never launched -- the next step would hang instead of reporting an error).
+struct NcclGroup {
+    Rccl *r;
+    bool open = false;
+    explicit NcclGroup(Rccl *r_) : r(r_) {}
+    ncclResult_t start() { const ncclResult_t rc = r->GroupStart(); open = rc == ncclSuccess; return rc; }
+    ncclResult_t end() { open = false; return r->GroupEnd(); }
+    ~NcclGroup() { if (open) (void)r->GroupEnd(); }
 };
 
 Rccl *rccl()
@@ -527,9 +548,18 @@ Rccl *rccl()
     if (custom && *custom) {
         lib = dlopen(custom, RTLD_NOW | RTLD_LOCAL);
     } else {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // An RCCL that is already mapped in this process comes first (PyTorch-ROCm maps its own bundled librccl.so when
+        // torch.distributed initialises the "nccl" backend): one process never holds two RCCL instances.  Only a host without one
+        // (LiveScanServer, C/C++ callers) loads the system's.
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (lib) break;
+        }
+        if (!lib) {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (lib) break;
+            }
         }
     }
     if (!lib) {
@@ -550,6 +580,8 @@ Rccl *rccl()
         delete t;
         return nullptr;
     }
+    Dl_info info;
+    if (dladdr((void *)t->AllGather, &info) && info.dli_fname) t->path = info.dli_fname;
     r = t;
     return r;
 }
@@ -584,11 +616,13 @@ struct LsnShard {
     int *h_goff = nullptr;                     // pinned copy of the gathered offset tables
     hipEvent_t ev_off = nullptr;
     // the streams travel in `chunks` groups of ticks on a second stream while the reconstruction of the previous group runs
-    int chunks = 4;                            // $LSN_SHARD_CHUNKS (1 = one shot on the caller's stream)
+    int chunks = 1;                            // $LSN_SHARD_CHUNKS (1 = one shot on the caller's stream, the default)
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_pre = nullptr;
     std::vector<hipEvent_t> ev_chunk;
     long long last_slab = 0, last_bytes_per_rank = 0;
+    bool failed = false;                       // a step returned an error: every later step refuses
+    std::string failure;
     std::mutex mu;
 };
 
@@ -620,12 +654,11 @@ extern "C" void lsnShardDestroy(LsnShard *sh)
     delete sh;
 }
 
-extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsigned char *id128, int n_ticks, int n_maps, const int *widths,
-                                    const int *heights)
+extern "C" LsnShard *lsnShardPrepare(int device, int rank, int world, int n_ticks, int n_maps, const int *widths, const int *heights)
 {
     lsn::clear_error();
-    if (world <= 0 || rank < 0 || rank >= world || !id128 || n_ticks <= 0 || n_maps <= 0 || !widths || !heights || n_maps % world != 0) {
-        lsn::set_error("lsnShardCreate: bad arguments (rank %d of %d, %d sensors must split evenly)", rank, world, n_maps);
+    if (world <= 0 || rank < 0 || rank >= world || n_ticks <= 0 || n_maps <= 0 || !widths || !heights || n_maps % world != 0) {
+        lsn::set_error("lsnShardPrepare: bad arguments (rank %d of %d, %d sensors must split evenly)", rank, world, n_maps);
         return nullptr;
     }
     bool uniform = true;
@@ -639,7 +672,7 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
         for (int i = 0; i < per_rank; i++) capq += (long long)widths[q * per_rank + i] * heights[q * per_rank + i];
         if (q == 0) cap0 = capq;
         if (capq != cap0) {
-            lsn::set_error("lsnShardCreate: the ranks' sensor blocks must hold the same number of pixels (%lld vs %lld)", cap0, capq);
+            lsn::set_error("lsnShardPrepare: the ranks' sensor blocks must hold the same number of pixels (%lld vs %lld)", cap0, capq);
             return nullptr;
         }
     }
@@ -656,7 +689,10 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
     sh->mpr = n_maps / world;
     sh->vertex_mode = !uniform || (getenv("LSN_SHARD_VERTICES") && atoi(getenv("LSN_SHARD_VERTICES")) != 0);
     if (const char *e = getenv("LSN_SHARD_PADDED")) sh->padded = atoi(e) != 0;
-    sh->chunks = world > 1 ? 4 : 1;   // nothing to overlap with one rank: its "transfer" is a local copy (measured: 0.89 ms in one shot, 0.98 in four chunks)
+    // One shot on the caller's stream unless $LSN_SHARD_CHUNKS asks for the pipelined form (collectives on a second stream beside the
+    // reconstruction): that form has only ever run with the shared-memory test double and with one real rank -- it stays opt-in until
+    // a run on a multi-GPU node has verified it.
+    sh->chunks = 1;
     if (const char *e = getenv("LSN_SHARD_CHUNKS")) sh->chunks = atoi(e);
     if (sh->chunks < 1) sh->chunks = 1;
     if (sh->chunks > 16) sh->chunks = 16;
@@ -697,22 +733,65 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
             if (e) sh->ev_chunk.push_back(e);
         }
     }
-    if (!bad) {
-        ncclUniqueId id;
-        memcpy(&id, id128, 128);
-        const ncclResult_t rc = r->CommInitRank(&sh->comm, world, id, rank);
-        if (rc != ncclSuccess) {
-            lsn::set_error("lsnShardCreate: ncclCommInitRank failed: %s", r->GetErrorString(rc));
-            sh->comm = nullptr;
-            bad = true;
-        }
-    }
     if (bad) {
-        if (lsn::last_error().empty()) lsn::set_error("lsnShardCreate: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        if (lsn::last_error().empty()) lsn::set_error("lsnShardPrepare: allocation failed: %s", hipGetErrorString(hipGetLastError()));
         lsnShardDestroy(sh);
         return nullptr;
     }
     return sh;
+}
+
+extern "C" int lsnShardConnect(LsnShard *sh, const unsigned char *id128)
+{
+    lsn::clear_error();
+    if (!sh || !id128) {
+        lsn::set_error("lsnShardConnect: null argument");
+        return -1;
+    }
+    Rccl *r = rccl();
+    if (!r) return -1;
+    std::lock_guard<std::mutex> g(sh->mu);
+    if (sh->comm) {
+        lsn::set_error("lsnShardConnect: already connected");
+        return -1;
+    }
+    LSN_HIP(hipSetDevice(sh->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    const ncclResult_t rc = r->CommInitRank(&sh->comm, sh->world, id, sh->rank);   // blocks until every rank of the world has called it
+    if (rc != ncclSuccess) {
+        lsn::set_error("lsnShardConnect: ncclCommInitRank failed: %s", r->GetErrorString(rc));
+        sh->comm = nullptr;
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsigned char *id128, int n_ticks, int n_maps, const int *widths,
+                                    const int *heights)
+{
+    if (!id128) {
+        lsn::clear_error();
+        lsn::set_error("lsnShardCreate: null id");
+        return nullptr;
+    }
+    LsnShard *sh = lsnShardPrepare(device, rank, world, n_ticks, n_maps, widths, heights);
+    if (!sh) return nullptr;
+    if (lsnShardConnect(sh, id128)) {
+        const std::string why = lsn::last_error();
+        lsnShardDestroy(sh);
+        lsn::set_error("%s", why.c_str());
+        return nullptr;
+    }
+    return sh;
+}
+
+extern "C" int lsnShardRcclPath(char *buf, int len)
+{
+    Rccl *r = rccl();
+    if (!r) return -1;
+    if (buf && len > 0) snprintf(buf, (size_t)len, "%s", r->path.c_str());
+    return (int)r->path.size();
 }
 
 extern "C" LsnFusion *lsnShardPlan(LsnShard *sh, int whole) { return sh ? (whole ? sh->whole : sh->local) : nullptr; }
@@ -730,6 +809,8 @@ extern "C" int lsnShardSetParams(LsnShard *sh, const float *intr_all, const floa
     return lsnFusionSetParams(sh->local, intr_all + 7 * (size_t)sh->rank * sh->mpr, wt_all + 12 * (size_t)sh->rank * sh->mpr, bounds6, stream);
 }
 
+static int shard_step(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets, void *stream);
+
 extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets,
                             void *stream)
 {
@@ -738,9 +819,28 @@ extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void 
         lsn::set_error("lsnShardStep: null argument");
         return -1;
     }
+    std::lock_guard<std::mutex> g(sh->mu);
+    if (!sh->comm) {
+        lsn::set_error("lsnShardStep: the handle is not connected (lsnShardConnect)");
+        return -1;
+    }
+    if (sh->failed) {
+        // a collective of an earlier step failed: the ranks' communicators are no longer in step, nothing further may be queued on them
+        lsn::set_error("lsnShardStep: an earlier step failed (%s); destroy the handle", sh->failure.c_str());
+        return -1;
+    }
+    const int rc = shard_step(sh, d_depth_local, d_colors_local, d_merged, d_merged_offsets, stream);
+    if (rc) {
+        sh->failed = true;
+        sh->failure = lsn::last_error();
+    }
+    return rc;
+}
+
+static int shard_step(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets, void *stream)
+{
     Rccl *r = rccl();
     if (!r) return -1;
-    std::lock_guard<std::mutex> g(sh->mu);
     LSN_HIP(hipSetDevice(sh->device));
     hipStream_t s = lsn::as_stream(stream);
     const size_t T = (size_t)sh->n_ticks, W = (size_t)sh->world, cap = (size_t)sh->cap_loc;
@@ -764,11 +864,14 @@ extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void 
             }
             slab = most;
         }
-        LSN_NCCL(r->GroupStart());
-        for (size_t k = 0; k < T; k++)
-            LSN_NCCL(r->AllGather(sh->v_local.as<uint4>() + k * cap, sh->v_gathered.as<uint4>() + k * W * (size_t)slab, (size_t)slab * 16, ncclUint8,
-                                  sh->comm, s));
-        LSN_NCCL(r->GroupEnd());
+        {
+            NcclGroup grp(r);
+            LSN_NCCL(grp.start());
+            for (size_t k = 0; k < T; k++)
+                LSN_NCCL(r->AllGather(sh->v_local.as<uint4>() + k * cap, sh->v_gathered.as<uint4>() + k * W * (size_t)slab, (size_t)slab * 16, ncclUint8,
+                                      sh->comm, s));
+            LSN_NCCL(grp.end());
+        }
         sh->last_slab = slab;
         sh->last_bytes_per_rank = (long long)(sizeof(int) * off_ints + T * (size_t)slab * 16);
         if (lsn::merge_shards(sh->device, sh->world, sh->n_ticks, sh->mpr, sh->v_gathered.p, slab, sh->g_off.as<int>(), sh->merged.p, sh->whole->cap,
@@ -803,12 +906,15 @@ extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void 
     if (C <= 1) {
         sh->last_slab = slab;
         sh->last_bytes_per_rank = (long long)(sizeof(int) * off_ints + sizeof(int) * T * sh->tiles_loc + T * cap / 8 + (size_t)slab * 5);
-        LSN_NCCL(r->GroupStart());
-        LSN_NCCL(r->AllGather(sh->local->tile_counts.p, sh->g_tp.p, T * sh->tiles_loc, ncclInt32, sh->comm, s));
-        LSN_NCCL(r->AllGather(sh->mask.p, sh->g_mask.p, T * cap / 8, ncclUint8, sh->comm, s));
-        LSN_NCCL(r->AllGather(sh->depth_c.p, sh->g_dc.p, (size_t)slab * 2, ncclUint8, sh->comm, s));
-        LSN_NCCL(r->AllGather(sh->rgb_c.p, sh->g_cc.p, (size_t)slab * 3, ncclUint8, sh->comm, s));
-        LSN_NCCL(r->GroupEnd());
+        {
+            NcclGroup grp(r);
+            LSN_NCCL(grp.start());
+            LSN_NCCL(r->AllGather(sh->local->tile_counts.p, sh->g_tp.p, T * sh->tiles_loc, ncclInt32, sh->comm, s));
+            LSN_NCCL(r->AllGather(sh->mask.p, sh->g_mask.p, T * cap / 8, ncclUint8, sh->comm, s));
+            LSN_NCCL(r->AllGather(sh->depth_c.p, sh->g_dc.p, (size_t)slab * 2, ncclUint8, sh->comm, s));
+            LSN_NCCL(r->AllGather(sh->rgb_c.p, sh->g_cc.p, (size_t)slab * 3, ncclUint8, sh->comm, s));
+            LSN_NCCL(grp.end());
+        }
         if (lsn::reconstruct(sh->whole, sh->world, sh->mpr, sh->g_mask.p, sh->g_dc.p, sh->g_cc.p, slab, sh->g_tp.as<int>(), sh->g_off.as<int>(),
                              sh->merged.p, sh->merged_off.as<int>(), sh->g_tick_base.as<int>(), stream))
             return -1;
@@ -818,10 +924,13 @@ extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void 
         // ticks the same way and derives the same chunk lengths from the same gathered offset tables.
         const int per = (int)((T + C - 1) / C);
         auto count_of = [&](size_t q, size_t k) { return (long long)sh->h_goff[(q * T + k) * (sh->mpr + 1) + sh->mpr]; };
-        LSN_NCCL(r->GroupStart());
-        LSN_NCCL(r->AllGather(sh->local->tile_counts.p, sh->g_tp.p, T * sh->tiles_loc, ncclInt32, sh->comm, s));
-        LSN_NCCL(r->AllGather(sh->mask.p, sh->g_mask.p, T * cap / 8, ncclUint8, sh->comm, s));
-        LSN_NCCL(r->GroupEnd());
+        {
+            NcclGroup grp(r);
+            LSN_NCCL(grp.start());
+            LSN_NCCL(r->AllGather(sh->local->tile_counts.p, sh->g_tp.p, T * sh->tiles_loc, ncclInt32, sh->comm, s));
+            LSN_NCCL(r->AllGather(sh->mask.p, sh->g_mask.p, T * cap / 8, ncclUint8, sh->comm, s));
+            LSN_NCCL(grp.end());
+        }
         LSN_HIP(hipEventRecord(sh->ev_pre, s));                        // pack and the small gathers are done: the streams may be read
         LSN_HIP(hipStreamWaitEvent(sh->comm_stream, sh->ev_pre, 0));
         long long my_start = 0, recv_off = 0, sent = 0;
@@ -837,12 +946,15 @@ extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void 
                 if ((int)q == sh->rank) mine = len;
             }
             const long long slab_c = (most + 7) & ~7ll;
-            LSN_NCCL(r->GroupStart());
-            LSN_NCCL(r->AllGather(sh->depth_c.as<unsigned short>() + my_start, sh->g_dc.as<unsigned short>() + recv_off, (size_t)slab_c * 2, ncclUint8,
-                                  sh->comm, sh->comm_stream));
-            LSN_NCCL(r->AllGather(sh->rgb_c.as<unsigned char>() + 3 * my_start, sh->g_cc.as<unsigned char>() + 3 * recv_off, (size_t)slab_c * 3, ncclUint8,
-                                  sh->comm, sh->comm_stream));
-            LSN_NCCL(r->GroupEnd());
+            {
+                NcclGroup grp(r);
+                LSN_NCCL(grp.start());
+                LSN_NCCL(r->AllGather(sh->depth_c.as<unsigned short>() + my_start, sh->g_dc.as<unsigned short>() + recv_off, (size_t)slab_c * 2, ncclUint8,
+                                      sh->comm, sh->comm_stream));
+                LSN_NCCL(r->AllGather(sh->rgb_c.as<unsigned char>() + 3 * my_start, sh->g_cc.as<unsigned char>() + 3 * recv_off, (size_t)slab_c * 3,
+                                      ncclUint8, sh->comm, sh->comm_stream));
+                LSN_NCCL(grp.end());
+            }
             LSN_HIP(hipEventRecord(sh->ev_chunk[c], sh->comm_stream));
             LSN_HIP(hipStreamWaitEvent(s, sh->ev_chunk[c], 0));
             if (lsn::reconstruct(sh->whole, sh->world, sh->mpr, sh->g_mask.p, sh->g_dc.as<unsigned short>() + recv_off,

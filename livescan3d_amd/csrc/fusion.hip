@@ -1055,8 +1055,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         if (hooks && hooks->counted) LSN_HIP(hipEventRecord(hooks->counted, s));
         if (hooks && hooks->colours_ready) LSN_HIP(hipStreamWaitEvent(s, hooks->colours_ready, 0));
         if (e0) LSN_HIP(hipEventRecord(e0, s));
-        static const int exp_chunk = getenv("LSN_EXP_WRITE_CHUNK") ? atoi(getenv("LSN_EXP_WRITE_CHUNK")) : 0;   // experiment: block order of the write pass
-        a.chunk = exp_chunk;
+        a.chunk = 0;   // tick-major block order (walking the ticks fastest was measured slower: DESIGN.md section 4, mode 2)
         launch<1>(vec, grid, s, a, p->lazy_rgb);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
         if (hooks && hooks->written) LSN_HIP(hipEventRecord(hooks->written, s));

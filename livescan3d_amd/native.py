@@ -26,7 +26,7 @@ EXPORTS = [
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
     "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
-    "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
+    "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardPrepare", "lsnShardConnect", "lsnShardRcclPath", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
@@ -167,6 +167,12 @@ def lib():
     L.lsnShardUniqueId.argtypes = [vp]
     L.lsnShardCreate.restype = vp
     L.lsnShardCreate.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    L.lsnShardPrepare.restype = vp
+    L.lsnShardPrepare.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.lsnShardConnect.restype = C.c_int
+    L.lsnShardConnect.argtypes = [vp, vp]
+    L.lsnShardRcclPath.restype = C.c_int
+    L.lsnShardRcclPath.argtypes = [C.c_char_p, C.c_int]
     L.lsnShardPlan.restype = vp
     L.lsnShardPlan.argtypes = [vp, C.c_int]
     L.lsnShardDestroy.restype = None
@@ -501,6 +507,13 @@ def merge_shards(device, n_shards, n_ticks, maps_per_shard, d_shards, shard_cap,
                                 d_shard_offsets, d_merged, int(merged_cap), d_merged_offsets, stream), "lsnMergeShards")
 
 
+def shard_rccl_path():
+    """The file the library's nccl* entry points came from (an RCCL already mapped in the process is preferred)."""
+    buf = C.create_string_buffer(1024)
+    n = lib().lsnShardRcclPath(buf, len(buf))
+    return buf.value.decode() if n >= 0 else None
+
+
 def shard_unique_id():
     """128 bytes from rank 0's RCCL (lsnShardUniqueId); every rank passes the same ones to Shard()."""
     require_gpu()
@@ -513,14 +526,25 @@ class Shard:
     """lsnShard*: this rank's block of sensors in, the merged cloud of all sensors out (RCCL all-gathers inside the library)."""
 
     def __init__(self, device, rank, world, unique_id, n_ticks, widths, heights):
+        """unique_id: rank 0's 128 bytes -> prepare + connect at once (lsnShardCreate); None -> lsnShardPrepare only, the caller
+        connects (connect()) once every rank has reported that its own preparation worked."""
         require_gpu()
         w, h = _as(widths, np.int32), _as(heights, np.int32)
         self.n_ticks, self.n_maps, self.world, self.rank = int(n_ticks), len(w), int(world), int(rank)
-        idb = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
-        self._h = lib().lsnShardCreate(int(device), self.rank, self.world, idb, self.n_ticks, self.n_maps, _ptr(w), _ptr(h))
+        if unique_id is None:
+            self._h = lib().lsnShardPrepare(int(device), self.rank, self.world, self.n_ticks, self.n_maps, _ptr(w), _ptr(h))
+            what = "lsnShardPrepare"
+        else:
+            idb = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+            self._h = lib().lsnShardCreate(int(device), self.rank, self.world, idb, self.n_ticks, self.n_maps, _ptr(w), _ptr(h))
+            what = "lsnShardCreate"
         if not self._h:
-            raise NativeUtilsError(f"lsnShardCreate failed: {last_error()}")
+            raise NativeUtilsError(f"{what} failed: {last_error()}")
         self.capacity = int(lib().lsnShardMergedCapacity(self._h))
+
+    def connect(self, unique_id):
+        idb = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().lsnShardConnect(self._h, idb), "lsnShardConnect")
 
     def set_params(self, intr_all, wt_all, bounds, stream=0):
         intr, wt, b = _as(intr_all, np.float32).ravel(), _as(wt_all, np.float32).ravel(), _as(bounds, np.float32).ravel()

@@ -36,17 +36,28 @@ class ShardedFusion:
     def __init__(self, rank, world, n_ticks, widths, heights, device, group=None):
         self.rank, self.world, self.n_ticks = rank, world, n_ticks
         self.device = torch.device(device)
-        ids = [None]
-        if rank == 0:
-            try:
-                ids = [native.shard_unique_id()]
-            except native.NativeUtilsError as ex:      # e.g. librccl cannot be loaded: tell the other ranks instead of leaving them waiting
-                ids = [str(ex)]
+        # 1. everything that can fail on this rank alone (argument checks, loading RCCL, device buffers); rank 0 also draws the id
+        err, ident, self.shard = None, None, None
+        try:
+            self.shard = native.Shard(self.device.index, rank, world, None, n_ticks, widths, heights)
+            if rank == 0:
+                ident = native.shard_unique_id()
+        except native.NativeUtilsError as ex:
+            err = f"rank {rank}: {ex}"
+        # 2. the ranks agree that ALL of them are ready before anybody enters the blocking ncclCommInitRank: a rank that failed in
+        #    step 1 would otherwise leave its peers waiting in it forever
+        reports = [(err, ident)]
         if world > 1:
-            dist.broadcast_object_list(ids, src=0, group=group)
-        if not isinstance(ids[0], (bytes, bytearray)):
-            raise native.NativeUtilsError(f"lsnShardUniqueId failed on rank 0: {ids[0]}")
-        self.shard = native.Shard(self.device.index, rank, world, ids[0], n_ticks, widths, heights)
+            reports = [None] * world
+            dist.all_gather_object(reports, (err, ident), group=group)
+        errors = [e for e, _ in reports if e]
+        if errors:
+            if self.shard is not None:
+                self.shard.close()
+                self.shard = None
+            raise native.NativeUtilsError("lsnShardPrepare failed on " + "; ".join(errors))
+        # 3. the collective part
+        self.shard.connect(reports[0][1])
         self.n_maps = self.shard.n_maps
         self.capacity = self.shard.capacity
 
@@ -62,7 +73,8 @@ class ShardedFusion:
             _device_view(mo, (self.n_ticks, self.n_maps + 1), torch.int32, self.device)
 
     def close(self):
-        self.shard.close()
+        if self.shard is not None:
+            self.shard.close()
 
 
 class _Span:

@@ -378,13 +378,15 @@ RAGGED4 = [(61, 37), (250, 120), (250, 120), (61, 37)]               # equal pix
 
 @pytest.mark.parametrize("world,sizes,chunks,padded", [
     (2, UNIFORM4, 1, False), (2, UNIFORM4, 3, False), (4, UNIFORM8, 4, False), (4, UNIFORM4, 1, True), (2, UNIFORM8, 5, False),
+    (4, UNIFORM4, 4, False), (4, UNIFORM4, 1, False),                 # one sensor per rank (the shape of BASELINE configs[3]), compact: chunked and one shot
     (2, RAGGED4, 1, False), (2, RAGGED4, 1, True)])
 def test_shard_step_several_ranks_on_one_gpu(gpu, tmp_path, world, sizes, chunks, padded):
     """lsnShardStep with world > 1.  RCCL refuses two ranks on one device, so the library is pointed ($LSN_RCCL_LIBRARY) at
     tests/fake_rccl -- the seven nccl* entry points over a shared-memory segment -- and `world` processes share this GPU:
     rank offsets, the grouped all-gathers, the chunked second-stream pipeline, the reconstruction of every rank's sensors
     (or the vertex exchange on the ragged rig) all run as they would on `world` GPUs, and every rank must end up with the
-    single-plan merged cloud."""
+    single-plan merged cloud.  World 8 (configs[3] itself) cannot be rehearsed here: a GPU box admits at most 6 processes on its
+    card, so 4 ranks x 1 sensor is the largest one-sensor-per-rank case."""
     if not os.path.exists(FAKE_RCCL):
         pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
     import torch.multiprocessing as mp
@@ -431,4 +433,39 @@ def test_shard_exports_configs4_shape_world1(gpu, tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
     mp.spawn(_shard_worker_big, args=(out,), nprocs=1, join=True)
+    assert open(out).read() == "ok"
+
+
+def _shard_worker_prepare_failure(rank, world, port, out):
+    """Rank 1 asks for an impossible rig (its sensor blocks hold different pixel counts -> lsnShardPrepare fails there only): every
+    rank must get the error instead of rank 0 hanging in ncclCommInitRank."""
+    sys.path.insert(0, ROOT)
+    os.environ["LSN_RCCL_LIBRARY"] = FAKE_RCCL
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from livescan3d_amd import native
+    from livescan3d_amd.sharding import ShardedFusion
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    sizes = [(64, 48), (64, 48)] if rank == 0 else [(64, 48), (32, 48)]
+    msg = "no error"
+    try:
+        ShardedFusion(rank, world, 2, [w for w, _ in sizes], [h for _, h in sizes], torch.device("cuda", 0))
+    except native.NativeUtilsError as ex:
+        msg = str(ex)
+    msgs = [None] * world
+    dist.all_gather_object(msgs, msg)
+    dist.destroy_process_group()
+    if rank == 0:
+        with open(out, "w") as f:
+            f.write("ok" if all("rank 1" in m and "lsnShardPrepare" in m for m in msgs) else f"unexpected {msgs}")
+
+
+def test_a_rank_that_cannot_prepare_does_not_leave_its_peers_waiting(gpu, tmp_path):
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is not built")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_shard_worker_prepare_failure, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "ok"

@@ -1,6 +1,10 @@
 #!/bin/bash
 # Dev helper (GPU box): PMC passes for the kernels of the multi-GPU step (pack_kernel / recon_kernel), driven through
-# tools/shard_driver.py (no RCCL in the process: rocprofv3 --pmc crashes the process when torch.distributed is initialised); usage: tools/pmc_shard.sh <tag>
+# tools/shard_driver.py (the two kernels alone, numpy-generated frames); usage: tools/pmc_shard.sh <tag>
+# (Round 2 noted that a --pmc pass "crashes the process when torch.distributed is initialised": the library then dlopen()ed the system's
+# librccl.so.1 next to the librccl.so torch had already mapped -- two RCCL instances in one profiled process.  Since rccl() prefers the
+# mapped instance, `LSN_BENCH_FORCE_DIST=1 rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --core-only ...` completes: round-3 log kept as
+# profiles/r03_pmc_pass_with_torch_distributed.log.)
 # Counters are collected in separate runs (TCC slot limits; FETCH_SIZE and WRITE_SIZE cannot share a pass).
 tag=$1
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_shard_$tag
