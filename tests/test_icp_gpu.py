@@ -244,3 +244,49 @@ def test_refine_loop_matches_oracle(gpu, orc):
     c1, R1, t1, Rs1, Ts1 = native.refine(clouds[:1], wR[:1], wt[:1])
     assert np.array_equal(c1[0], clouds[0]) and np.array_equal(Rs1[0], np.eye(3, dtype=np.float32)) and not Ts1.any()
     assert np.array_equal(R1[0], wR[0]) and np.array_equal(t1[0], wt[0])
+
+
+_CONFIGS2_ORACLE = {}
+
+
+@pytest.mark.parametrize("mode", [native.NN_GRID, native.NN_BRUTE], ids=["grid", "brute"])
+def test_icp_at_the_callers_shape_configs2(gpu, orc, mode):
+    """BASELINE configs[2] = the shape LiveScanServer's refine loop calls ICP with (MainWindowForm.cs:347-376): the source is one
+    sensor's cloud (n2 ~ 108 k), the target all seven others' (n1 ~ 738 k), maxIter = 10 -- both NN modes against the oracle's run
+    (kd-tree NN) within 1e-4 on every vertex, R and t."""
+    import torch
+    from tests import scene_cases
+    if "run" not in _CONFIGS2_ORACLE:
+        clouds = scene_cases.scene_clouds(orc, 8)
+        tgt, src = np.concatenate(clouds[1:]), clouds[0]
+        _CONFIGS2_ORACLE["run"] = (tgt, src, orc.icp(tgt, src, max_iter=10, n_threads=8))
+    tgt, src, (ref_v, ref_R, ref_t) = _CONFIGS2_ORACLE["run"]
+    assert len(tgt) > 700000 and len(src) > 100000
+    v1 = torch.from_numpy(tgt).cuda()
+    v2 = torch.from_numpy(src.copy()).cuda()
+    Rt = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device="cuda")
+    ws = native.IcpWorkspace(0, len(tgt), len(src))
+    st = int(torch.cuda.current_stream().cuda_stream)
+    ws.run(v1.data_ptr(), len(tgt), v2.data_ptr(), len(src), Rt.data_ptr(), Rt.data_ptr() + 36, 10, mode, st)
+    torch.cuda.synchronize()
+    got_v, got = v2.cpu().numpy(), Rt.cpu().numpy()
+    ws.close()
+    assert np.abs(got_v - ref_v).max() <= TOL
+    assert np.abs(got[:9].reshape(3, 3) - ref_R).max() <= TOL and np.abs(got[9:] - ref_t).max() <= TOL
+    assert np.abs(got_v - src).max() > 1e-3                        # the source did move
+
+
+def test_refine_pass_at_full_size(gpu, orc):
+    """The whole refine pass of LiveScanServer at its real size: 8 sensors x 512x424, nNumRefineIters = 2, nNumICPIterations = 10
+    (160 ICP iterations, every call against the seven other clouds) through lsnRefine against the oracle's mirror of the loop."""
+    from tests import scene_cases
+    clouds = scene_cases.scene_clouds(orc, 8)
+    n = len(clouds)
+    wR = np.stack([synth.rot_y(2 * np.pi * i / n) for i in range(n)]).astype(np.float32)
+    wt = np.tile(np.array([0, 0, -2.0], np.float32), (n, 1))
+    got_c, got_R, got_t, got_Rs, got_Ts = native.refine(clouds, wR, wt, n_refine_iters=2, n_icp_iters=10)
+    ref_c, ref_R, ref_t, ref_Rs, ref_Ts = orc.refine(clouds, wR, wt, n_refine_iters=2, n_icp_iters=10, n_threads=16)
+    for i in range(n):
+        assert np.abs(got_c[i] - ref_c[i]).max() <= TOL, i
+    assert np.abs(got_Rs - ref_Rs).max() <= TOL and np.abs(got_Ts - ref_Ts).max() <= TOL
+    assert np.abs(got_R - ref_R).max() <= TOL and np.abs(got_t - ref_t).max() <= TOL
