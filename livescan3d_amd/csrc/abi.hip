@@ -20,6 +20,7 @@
 //   * the vertices leave on a second stream as soon as they are written, while the triangulation kernels are still running.
 #include "lsn_common.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -141,26 +142,37 @@ extern "C" int lsnStreamSynchronize(int device, void *stream)
 
 namespace {
 
-struct Ctx {
-    std::mutex mu;            // merge / single-sensor / radial / last-mesh calls and the pinned-block pool
-    std::mutex icp_mu;        // ICP: own buffers, own stream
-    std::mutex init_mu;
-    bool ready = false;
-    int device = 0;
-    hipStream_t stream = nullptr, up = nullptr, down = nullptr, icp_stream = nullptr;
+// What one call in flight needs: streams, events, device buffers.  LiveScanServer runs its merge calls (updateWorker: radial correction,
+// generateMeshFromDepthMaps) and its refine calls (refineWorker: generateVerticesFromDepthMap per sensor, then ICP) on two threads
+// (MainWindowForm.cs:238,304); each of the three families has its own lane, so they only meet at the short shared tables below.
+struct Lane {
+    std::mutex mu;
+    hipStream_t stream = nullptr, up = nullptr, down = nullptr;
     hipEvent_t ev_depth = nullptr, ev_col = nullptr, ev_counted = nullptr, ev_written = nullptr, ev_tri_counted = nullptr, ev_down = nullptr;
     int *h_off = nullptr, *h_toff = nullptr;   // pinned: the offset tables of the call in progress
     int h_off_cap = 0;
+    lsn::DevBuf d_depth, d_colors, d_depth2, d_colors2, d_out, d_off, d_tri, d_tri_off;
+    int last_nv = -1, last_nt = 0;   // the mesh of the lane's last call is still in d_out / d_tri (lsnLastMesh* read the merge lane's)
+};
+
+struct Ctx {
+    Lane merge, single;       // lane of the merge / radial / last-mesh calls; lane of the single-sensor calls
+    std::mutex icp_mu;        // ICP: own buffers, own stream
+    std::mutex init_mu;
+    std::mutex tab_mu;        // the shared tables: plans, the pinned-block pool, the registered host ranges
+    std::atomic<Lane *> last_lane{nullptr};   // the lane whose call finished last: lsnLastMesh* read the mesh it left in HBM
+    bool ready = false;
+    int device = 0;
+    hipStream_t icp_stream = nullptr;
     std::map<std::vector<int>, LsnFusion *> plans;  // key: n_maps, widths..., heights...
-    lsn::DevBuf d_depth, d_colors, d_depth2, d_colors2, d_out, d_off, d_tri, d_tri_off, d_v1, d_v2, d_Rt;
+    lsn::DevBuf d_v1, d_v2, d_Rt;
     LsnIcp *icp = nullptr;
     int icp_n1 = 0, icp_n2 = 0;
     // pinned host blocks handed out as Mesh::vertices, recycled by deleteMesh
     std::unordered_map<void *, size_t> live;          // ptr -> capacity (bytes)
     std::multimap<size_t, void *> pool;               // capacity -> ptr
     std::unordered_map<void *, int> live_tri;         // triangles arrays we own
-    // the mesh of the last merge / single-sensor call is still in d_out / d_tri (lsnLastMesh* read it there)
-    int last_nv = -1, last_nt = 0;
+    std::mutex wire_mu;       // the packer and its output buffer (lsnLastMesh*)
     LsnTransfer *xfer = nullptr;
     int xfer_v = 0, xfer_t = 0;
     lsn::DevBuf d_wire;
@@ -202,9 +214,12 @@ int ensure_ready(Ctx &c)
         return -1;
     }
     LSN_HIP(hipSetDevice(c.device));
-    for (hipStream_t *s : {&c.stream, &c.up, &c.down, &c.icp_stream}) LSN_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&c.ev_depth, &c.ev_col, &c.ev_counted, &c.ev_written, &c.ev_tri_counted, &c.ev_down})
-        LSN_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    LSN_HIP(hipStreamCreateWithFlags(&c.icp_stream, hipStreamNonBlocking));
+    for (Lane *l : {&c.merge, &c.single}) {
+        for (hipStream_t *s : {&l->stream, &l->up, &l->down}) LSN_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&l->ev_depth, &l->ev_col, &l->ev_counted, &l->ev_written, &l->ev_tri_counted, &l->ev_down})
+            LSN_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
     if (const char *e = getenv("LSN_HOST_REGISTER")) c.reg_enabled = atoi(e) != 0;
     c.ready = true;
     return 0;
@@ -223,10 +238,11 @@ void reg_drop(Ctx &c, size_t i)
 
 // True when [p, p + bytes) lies inside a range registered with the runtime (copies from it then run as DMA out of the
 // caller's pages).  A range is registered on its second sighting -- one-off buffers are not worth the ~millisecond the
-// registration costs.  may_register = false only looks the range up.  c.mu held.
+// registration costs.  may_register = false only looks the range up.
 bool host_range_pinned(Ctx &c, const void *p, size_t bytes, bool may_register)
 {
     if (!c.reg_enabled || !p || bytes < 65536) return false;
+    std::lock_guard<std::mutex> tg(c.tab_mu);
     const char *b = static_cast<const char *>(p);
     c.use_clock++;
     for (auto &r : c.regs)
@@ -274,17 +290,18 @@ bool host_range_pinned(Ctx &c, const void *p, size_t bytes, bool may_register)
 
 // waits for everything the context has in flight on the merge streams (error paths: no copy may touch the caller's arrays
 // or our buffers once the call has returned)
-void drain(Ctx &c)
+void drain(Lane &l)
 {
-    (void)hipStreamSynchronize(c.up);
-    (void)hipStreamSynchronize(c.stream);
-    (void)hipStreamSynchronize(c.down);
+    (void)hipStreamSynchronize(l.up);
+    (void)hipStreamSynchronize(l.stream);
+    (void)hipStreamSynchronize(l.down);
     (void)hipGetLastError();
 }
 
 void *pinned_get(Ctx &c, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
+    std::lock_guard<std::mutex> tg(c.tab_mu);
     auto it = c.pool.lower_bound(bytes);
     if (it != c.pool.end() && it->first <= bytes * 2 + 4096) {
         void *p = it->second;
@@ -305,6 +322,7 @@ void *pinned_get(Ctx &c, size_t bytes)
 
 void pinned_put(Ctx &c, void *p)
 {
+    std::lock_guard<std::mutex> tg(c.tab_mu);
     auto it = c.live.find(p);
     if (it == c.live.end()) return;  // not ours: leave it alone
     size_t cap = it->second;
@@ -321,12 +339,16 @@ void empty_mesh(Ctx &c, Mesh *m)
     m->nTriangles = 0;
     int *tri = (int *)malloc(sizeof(int));  // "new int[0]": valid, never dereferenced (KinectServer.cs:344-345)
     m->triangles = tri;
-    if (tri) c.live_tri[tri] = 1;
+    if (tri) {
+        std::lock_guard<std::mutex> tg(c.tab_mu);
+        c.live_tri[tri] = 1;
+    }
 }
 
-// The cached single-tick plan for sensors [first, first + count) of a call.  c.mu held.
+// The cached single-tick plan for sensors [first, first + count) of a call.
 LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, int count)
 {
+    std::lock_guard<std::mutex> tg(c.tab_mu);
     // `first` is part of the key: generateVerticesFromDepthMap is called for sensor 0, 1, ... in turn (KinectServer.cs:527-554) and every
     // sensor keeps its own plan, so its calibration stays set (no parameter upload, no table rebuild per call) and its count pass
     // can run from the per-pixel depth thresholds from the second round on
@@ -352,7 +374,7 @@ LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, in
 // knows them (what gets registered).  c.mu held.
 // radial (optional): the call starts with the radial correction of the frames (depthMapAndColorSetRadialCorrection) on the device;
 // radial_back_d / radial_back_c (optional): the corrected maps are also copied to these host arrays, like the separate export does.
-int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char *depth_colors, size_t total_d, size_t total_c,
+int fuse_host_inner(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, size_t total_d, size_t total_c,
                     const int *widths, const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first,
                     int count, bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr,
                     unsigned char *radial_back_c = nullptr)
@@ -369,19 +391,19 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
         dbytes += (size_t)widths[first + i] * heights[first + i] * 2;
         cbytes += (size_t)widths[first + i] * heights[first + i] * 3;
     }
-    c.last_nv = -1;                                   // d_out / d_tri are about to be overwritten (or reallocated)
+    l.last_nv = -1;                                   // d_out / d_tri are about to be overwritten (or reallocated)
     const long long cap = lsnFusionTickCapacity(plan);
-    if (c.d_depth.reserve(dbytes + 16) || c.d_colors.reserve(cbytes + 16) || c.d_out.reserve((size_t)cap * 16) ||
-        c.d_off.reserve(sizeof(int) * (count + 1)))
+    if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_out.reserve((size_t)cap * 16) ||
+        l.d_off.reserve(sizeof(int) * (count + 1)))
         return -1;
-    if (c.h_off_cap < count + 1) {
-        if (c.h_off) (void)hipHostFree(c.h_off);
-        if (c.h_toff) (void)hipHostFree(c.h_toff);
-        c.h_off = c.h_toff = nullptr;
-        c.h_off_cap = 0;
-        LSN_HIP(hipHostMalloc((void **)&c.h_off, sizeof(int) * (size_t)(count + 1 + 64), hipHostMallocDefault));
-        LSN_HIP(hipHostMalloc((void **)&c.h_toff, sizeof(int) * (size_t)(count + 1 + 64), hipHostMallocDefault));
-        c.h_off_cap = count + 1 + 64;
+    if (l.h_off_cap < count + 1) {
+        if (l.h_off) (void)hipHostFree(l.h_off);
+        if (l.h_toff) (void)hipHostFree(l.h_toff);
+        l.h_off = l.h_toff = nullptr;
+        l.h_off_cap = 0;
+        LSN_HIP(hipHostMalloc((void **)&l.h_off, sizeof(int) * (size_t)(count + 1 + 64), hipHostMallocDefault));
+        LSN_HIP(hipHostMalloc((void **)&l.h_toff, sizeof(int) * (size_t)(count + 1 + 64), hipHostMallocDefault));
+        l.h_off_cap = count + 1 + 64;
     }
     // the merge call sees the whole arrays the caller keeps from tick to tick: those get registered; a single-sensor call
     // (which only knows a prefix of them) profits when its slice lies inside
@@ -392,48 +414,48 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
     // overlap could win, so it runs on ONE stream.  A big call goes depth first (the count pass needs nothing else), colours
     // behind it on the upload stream, kernels on the main stream, vertices home on the download stream.
     const bool small = dbytes + cbytes < ((size_t)4 << 20);
-    hipStream_t up = small ? c.stream : c.up, down = small ? c.stream : c.down;
-    LSN_HIP(hipMemcpyAsync(c.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, up));
-    if (!small) LSN_HIP(hipEventRecord(c.ev_depth, up));
-    LSN_HIP(hipMemcpyAsync(c.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, up));
-    if (!small) LSN_HIP(hipEventRecord(c.ev_col, up));
-    if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, c.stream)) return -1;
-    if (!small) LSN_HIP(hipStreamWaitEvent(c.stream, c.ev_depth, 0));
-    const void *run_d = c.d_depth.p, *run_c = c.d_colors.p;
+    hipStream_t up = small ? l.stream : l.up, down = small ? l.stream : l.down;
+    LSN_HIP(hipMemcpyAsync(l.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, up));
+    if (!small) LSN_HIP(hipEventRecord(l.ev_depth, up));
+    LSN_HIP(hipMemcpyAsync(l.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, up));
+    if (!small) LSN_HIP(hipEventRecord(l.ev_col, up));
+    if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, l.stream)) return -1;
+    if (!small) LSN_HIP(hipStreamWaitEvent(l.stream, l.ev_depth, 0));
+    const void *run_d = l.d_depth.p, *run_c = l.d_colors.p;
     if (radial) {
         // the correction reads depth and colours of the raw frames and leaves the corrected ones in a second pair of buffers, which
         // the passes below then read; the corrected maps go home on the download stream while the fusion kernels run
-        if (c.d_depth2.reserve(dbytes + 16) || c.d_colors2.reserve(cbytes + 16)) return -1;
-        if (!small) LSN_HIP(hipStreamWaitEvent(c.stream, c.ev_col, 0));
-        if (lsnFusionRadialCorrectTo(plan, intr + 7 * first, c.d_depth.p, c.d_colors.p, c.d_depth2.p, c.d_colors2.p, c.stream)) return -1;
-        run_d = c.d_depth2.p;
-        run_c = c.d_colors2.p;
+        if (l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16)) return -1;
+        if (!small) LSN_HIP(hipStreamWaitEvent(l.stream, l.ev_col, 0));
+        if (lsnFusionRadialCorrectTo(plan, intr + 7 * first, l.d_depth.p, l.d_colors.p, l.d_depth2.p, l.d_colors2.p, l.stream)) return -1;
+        run_d = l.d_depth2.p;
+        run_c = l.d_colors2.p;
         if (radial_back_d && radial_back_c) {
-            LSN_HIP(hipEventRecord(c.ev_down, c.stream));
-            if (!small) LSN_HIP(hipStreamWaitEvent(down, c.ev_down, 0));
-            LSN_HIP(hipMemcpyAsync(radial_back_d + dskip, c.d_depth2.p, dbytes, hipMemcpyDeviceToHost, down));
-            LSN_HIP(hipMemcpyAsync(radial_back_c + cskip, c.d_colors2.p, cbytes, hipMemcpyDeviceToHost, down));
+            LSN_HIP(hipEventRecord(l.ev_down, l.stream));
+            if (!small) LSN_HIP(hipStreamWaitEvent(down, l.ev_down, 0));
+            LSN_HIP(hipMemcpyAsync(radial_back_d + dskip, l.d_depth2.p, dbytes, hipMemcpyDeviceToHost, down));
+            LSN_HIP(hipMemcpyAsync(radial_back_c + cskip, l.d_colors2.p, cbytes, hipMemcpyDeviceToHost, down));
         }
     }
     lsn::RunHooks hooks;
-    hooks.colours_ready = (small || radial) ? nullptr : c.ev_col;
-    hooks.h_offsets = c.h_off;
-    hooks.counted = c.ev_counted;
-    hooks.written = c.ev_written;
-    c.h_toff[count] = 0;
+    hooks.colours_ready = (small || radial) ? nullptr : l.ev_col;
+    hooks.h_offsets = l.h_off;
+    hooks.counted = l.ev_counted;
+    hooks.written = l.ev_written;
+    l.h_toff[count] = 0;
     if (with_triangles) {
         const long long tcap = lsnFusionTickTriangleCapacity(plan);
-        if (c.d_tri.reserve((size_t)tcap * 12) || c.d_tri_off.reserve(sizeof(int) * (count + 1))) return -1;
-        hooks.h_tri_offsets = c.h_toff;
-        hooks.tri_counted = c.ev_tri_counted;
-        if (lsn::run_mesh(plan, run_d, run_c, c.d_out.p, c.d_off.as<int>(), c.d_tri.p, c.d_tri_off.as<int>(), c.stream, &hooks))
+        if (l.d_tri.reserve((size_t)tcap * 12) || l.d_tri_off.reserve(sizeof(int) * (count + 1))) return -1;
+        hooks.h_tri_offsets = l.h_toff;
+        hooks.tri_counted = l.ev_tri_counted;
+        if (lsn::run_mesh(plan, run_d, run_c, l.d_out.p, l.d_off.as<int>(), l.d_tri.p, l.d_tri_off.as<int>(), l.stream, &hooks))
             return -1;
     } else {
-        if (lsn::run_hooked(plan, run_d, run_c, c.d_out.p, c.d_off.as<int>(), c.stream, &hooks)) return -1;
+        if (lsn::run_hooked(plan, run_d, run_c, l.d_out.p, l.d_off.as<int>(), l.stream, &hooks)) return -1;
     }
     // the vertex count arrives while the write pass (and the triangulation) are still running
-    LSN_HIP(hipEventSynchronize(c.ev_counted));
-    const int nv = c.h_off[count];
+    LSN_HIP(hipEventSynchronize(l.ev_counted));
+    const int nv = l.h_off[count];
     if (nv < 0 || nv > cap) {
         lsn::set_error("NativeUtils: device returned an impossible vertex count %d", nv);
         return -1;
@@ -442,10 +464,10 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
     if (!host) return -1;
     if (nv > 0) {
         // the vertices leave on their own stream as soon as the write pass is done
-        if ((!small && hipStreamWaitEvent(down, c.ev_written, 0) != hipSuccess) ||
-            hipMemcpyAsync(host, c.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, down) != hipSuccess) {
+        if ((!small && hipStreamWaitEvent(down, l.ev_written, 0) != hipSuccess) ||
+            hipMemcpyAsync(host, l.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, down) != hipSuccess) {
             lsn::set_error("NativeUtils: vertex download failed: %s", hipGetErrorString(hipGetLastError()));
-            drain(c);
+            drain(l);
             pinned_put(c, host);
             return -1;
         }
@@ -453,33 +475,33 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
     int nt = 0;
     void *host_tri = nullptr;
     if (with_triangles) {
-        bool bad = hipEventSynchronize(c.ev_tri_counted) != hipSuccess;
-        nt = bad ? 0 : c.h_toff[count];
+        bool bad = hipEventSynchronize(l.ev_tri_counted) != hipSuccess;
+        nt = bad ? 0 : l.h_toff[count];
         if (!bad && (nt < 0 || nt > 2 * cap)) {
             lsn::set_error("NativeUtils: device returned an impossible triangle count %d", nt);
             bad = true;
         }
         if (!bad && nt > 0) {
             host_tri = pinned_get(c, (size_t)nt * 12);
-            bad = !host_tri || hipMemcpyAsync(host_tri, c.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, c.stream) != hipSuccess;
+            bad = !host_tri || hipMemcpyAsync(host_tri, l.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, l.stream) != hipSuccess;
         }
         if (bad) {
             if (lsn::last_error().empty()) lsn::set_error("NativeUtils: triangle download failed: %s", hipGetErrorString(hipGetLastError()));
-            drain(c);
+            drain(l);
             pinned_put(c, host);
             if (host_tri) pinned_put(c, host_tri);
             return -1;
         }
     }
-    if (hipStreamSynchronize(c.stream) != hipSuccess || hipStreamSynchronize(c.down) != hipSuccess) {
+    if (hipStreamSynchronize(l.stream) != hipSuccess || hipStreamSynchronize(l.down) != hipSuccess) {
         lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
-        drain(c);
+        drain(l);
         pinned_put(c, host);
         if (host_tri) pinned_put(c, host_tri);
         return -1;
     }
-    c.last_nv = nv;
-    c.last_nt = nt;
+    l.last_nv = nv;
+    l.last_nt = nt;
     out->nVertices = nv;
     out->vertices = static_cast<VertexC4ubV3f *>(host);
     out->nTriangles = nt;
@@ -488,12 +510,16 @@ int fuse_host_inner(Ctx &c, const unsigned char *depth_maps, const unsigned char
     } else {
         int *tri = (int *)malloc(sizeof(int));  // "new int[0]": valid, never dereferenced (KinectServer.cs:344-345)
         out->triangles = tri;
-        if (tri) c.live_tri[tri] = 1;
+        if (tri) {
+            std::lock_guard<std::mutex> tg(c.tab_mu);
+            c.live_tri[tri] = 1;
+        }
     }
+    c.last_lane.store(&l);
     return 0;
 }
 
-int fuse_host(Ctx &c, int n_maps_known, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
+int fuse_host(Ctx &c, Lane &l, int n_maps_known, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
               const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count,
               bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr, unsigned char *radial_back_c = nullptr)
 {
@@ -502,9 +528,9 @@ int fuse_host(Ctx &c, int n_maps_known, const unsigned char *depth_maps, const u
         total_d += (size_t)widths[i] * heights[i] * 2;
         total_c += (size_t)widths[i] * heights[i] * 3;
     }
-    const int rc = fuse_host_inner(c, depth_maps, depth_colors, total_d, total_c, widths, heights, intr, wt, out, bounds6, first, count,
+    const int rc = fuse_host_inner(c, l, depth_maps, depth_colors, total_d, total_c, widths, heights, intr, wt, out, bounds6, first, count,
                                    with_triangles, radial, radial_back_d, radial_back_c);
-    if (rc) drain(c);   // nothing of a failed call stays in flight
+    if (rc) drain(l);   // nothing of a failed call stays in flight
     return rc;
 }
 
@@ -517,14 +543,15 @@ extern "C" void generateVerticesFromDepthMap(unsigned char *depth_maps, unsigned
     lsn::clear_error();
     if (!out_mesh) return;
     Ctx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
+    Lane &l = c.single;
+    std::lock_guard<std::mutex> g(l.mu);
     if (!depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params || depth_map_index < 0) {
         lsn::set_error("generateVerticesFromDepthMap: bad arguments");
         empty_mesh(c, out_mesh);
         return;
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
-    if (ensure_ready(c) || fuse_host(c, depth_map_index + 1, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params,
+    if (ensure_ready(c) || fuse_host(c, l, depth_map_index + 1, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params,
                                      out_mesh, b, depth_map_index, 1, false))
         empty_mesh(c, out_mesh);
 }
@@ -536,7 +563,8 @@ extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps,
     lsn::clear_error();
     if (!out_mesh) return;
     Ctx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
+    Lane &l = c.merge;
+    std::lock_guard<std::mutex> g(l.mu);
     if (n_maps <= 0 || !depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params) {
         if (n_maps != 0) lsn::set_error("generateMeshFromDepthMaps: bad arguments");
         empty_mesh(c, out_mesh);
@@ -544,7 +572,7 @@ extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps,
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
     if (ensure_ready(c) ||
-        fuse_host(c, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps, true)) {
+        fuse_host(c, l, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps, true)) {
         empty_mesh(c, out_mesh);
         return;
     }
@@ -570,14 +598,15 @@ extern "C" void lsnCorrectAndGenerateMesh(int n_maps, unsigned char *depth_maps,
     lsn::clear_error();
     if (!out_mesh) return;
     Ctx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
+    Lane &l = c.merge;
+    std::lock_guard<std::mutex> g(l.mu);
     if (n_maps <= 0 || !depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params) {
         if (n_maps != 0) lsn::set_error("lsnCorrectAndGenerateMesh: bad arguments");
         empty_mesh(c, out_mesh);
         return;
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
-    if (ensure_ready(c) || fuse_host(c, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps,
+    if (ensure_ready(c) || fuse_host(c, l, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps,
                                      true, true, write_back_corrected ? depth_maps : nullptr, write_back_corrected ? depth_colors : nullptr))
         empty_mesh(c, out_mesh);
 }
@@ -591,7 +620,8 @@ extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *d
         return;
     }
     Ctx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
+    Lane &l = c.merge;
+    std::lock_guard<std::mutex> g(l.mu);
     if (ensure_ready(c)) return;
     LsnFusion *plan = get_plan(c, widths, heights, 0, n_maps);
     if (!plan) return;
@@ -600,22 +630,22 @@ extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *d
         dbytes += (size_t)widths[i] * heights[i] * 2;
         cbytes += (size_t)widths[i] * heights[i] * 3;
     }
-    if (c.d_depth.reserve(dbytes + 16) || c.d_colors.reserve(cbytes + 16) || c.d_depth2.reserve(dbytes + 16) || c.d_colors2.reserve(cbytes + 16)) return;
-    if (hipMemcpyAsync(c.d_depth.p, depth_maps, dbytes, hipMemcpyHostToDevice, c.stream) != hipSuccess ||
-        hipMemcpyAsync(c.d_colors.p, depth_colors, cbytes, hipMemcpyHostToDevice, c.stream) != hipSuccess) {
+    if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16)) return;
+    if (hipMemcpyAsync(l.d_depth.p, depth_maps, dbytes, hipMemcpyHostToDevice, l.stream) != hipSuccess ||
+        hipMemcpyAsync(l.d_colors.p, depth_colors, cbytes, hipMemcpyHostToDevice, l.stream) != hipSuccess) {
         lsn::set_error("depthMapAndColorSetRadialCorrection: upload failed: %s", hipGetErrorString(hipGetLastError()));
         return;
     }
     // out of place on the device (the warped, un-closed maps then stay in LDS); the caller's arrays are only overwritten once
     // the kernels have run
-    if (lsnFusionRadialCorrectTo(plan, intr_params, c.d_depth.p, c.d_colors.p, c.d_depth2.p, c.d_colors2.p, c.stream)) return;
-    if (hipStreamSynchronize(c.stream) != hipSuccess) {
+    if (lsnFusionRadialCorrectTo(plan, intr_params, l.d_depth.p, l.d_colors.p, l.d_depth2.p, l.d_colors2.p, l.stream)) return;
+    if (hipStreamSynchronize(l.stream) != hipSuccess) {
         lsn::set_error("depthMapAndColorSetRadialCorrection: the correction failed: %s", hipGetErrorString(hipGetLastError()));
         return;
     }
-    if (hipMemcpyAsync(depth_maps, c.d_depth2.p, dbytes, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
-        hipMemcpyAsync(depth_colors, c.d_colors2.p, cbytes, hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
-        hipStreamSynchronize(c.stream) != hipSuccess) {
+    if (hipMemcpyAsync(depth_maps, l.d_depth2.p, dbytes, hipMemcpyDeviceToHost, l.stream) != hipSuccess ||
+        hipMemcpyAsync(depth_colors, l.d_colors2.p, cbytes, hipMemcpyDeviceToHost, l.stream) != hipSuccess ||
+        hipStreamSynchronize(l.stream) != hipSuccess) {
         lsn::set_error("depthMapAndColorSetRadialCorrection: download failed: %s", hipGetErrorString(hipGetLastError()));
         return;
     }
@@ -631,15 +661,18 @@ extern "C" void deleteMesh(Mesh *mesh)
 {
     if (!mesh) return;
     Ctx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
     if (mesh->triangles) {
-        auto it = c.live_tri.find(mesh->triangles);
-        if (it != c.live_tri.end()) {
-            c.live_tri.erase(it);
-            free(mesh->triangles);
-        } else {
-            pinned_put(c, mesh->triangles);  // a pinned block of ours, or not ours at all (then left alone)
+        bool plain = false;
+        {
+            std::lock_guard<std::mutex> tg(c.tab_mu);
+            auto it = c.live_tri.find(mesh->triangles);
+            if (it != c.live_tri.end()) {
+                c.live_tri.erase(it);
+                plain = true;
+            }
         }
+        if (plain) free(mesh->triangles);
+        else pinned_put(c, mesh->triangles);  // a pinned block of ours, or not ours at all (then left alone)
     }
     if (mesh->vertices) pinned_put(c, mesh->vertices);
     mesh->triangles = nullptr;
@@ -701,17 +734,18 @@ extern "C" float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2,
 // ---- the outbound formats of the mesh the last merge call left in HBM (include/NativeUtils.h part 3) ----------------------------
 
 namespace {
-// requires c.mu held; kind 0 = TransferSocket.SendFrame stream, 1 = binary PLY file image
-long long last_mesh_bytes(Ctx &c, int kind, unsigned char *out, long long out_cap)
+// requires the lane's lock; kind 0 = TransferSocket.SendFrame stream, 1 = binary PLY file image
+long long last_mesh_bytes(Ctx &c, Lane &l, int kind, unsigned char *out, long long out_cap)
 {
     if (ensure_ready(c)) return -1;
-    if (c.last_nv < 0) {
+    if (l.last_nv < 0) {
         lsn::set_error("lsnLastMesh*: no mesh is resident (call generateMeshFromDepthMaps / generateVerticesFromDepthMap first)");
         return -1;
     }
-    const int nv = c.last_nv, nt = c.last_nt;
+    const int nv = l.last_nv, nt = l.last_nt;
     const long long bound = kind == 0 ? lsnTransferFrameBound(nv, nt) : lsnPlyBinaryBytes(nv, nt);
     if (!out) return bound;
+    std::lock_guard<std::mutex> wg(c.wire_mu);
     if (c.d_wire.reserve((size_t)bound + 16)) return -1;
     long long n = -1;
     if (kind == 0) {
@@ -725,18 +759,18 @@ long long last_mesh_bytes(Ctx &c, int kind, unsigned char *out, long long out_ca
                 return -1;
             }
         }
-        n = lsnTransferPack(c.xfer, c.d_out.p, nv, nt > 0 ? c.d_tri.as<int>() : nullptr, nt, c.d_wire.p, bound, c.stream);
+        n = lsnTransferPack(c.xfer, l.d_out.p, nv, nt > 0 ? l.d_tri.as<int>() : nullptr, nt, c.d_wire.p, bound, l.stream);
     } else {
-        n = lsnPlyPack(c.device, c.d_out.p, nv, nt > 0 ? c.d_tri.as<int>() : nullptr, nt, c.d_wire.p, bound, c.stream);
+        n = lsnPlyPack(c.device, l.d_out.p, nv, nt > 0 ? l.d_tri.as<int>() : nullptr, nt, c.d_wire.p, bound, l.stream);
     }
     if (n < 0) return -1;
     if (n > out_cap) {
-        (void)hipStreamSynchronize(c.stream);
+        (void)hipStreamSynchronize(l.stream);
         lsn::set_error("lsnLastMesh*: the result is %lld bytes, the buffer holds %lld", n, out_cap);
         return -1;
     }
-    LSN_HIP(hipMemcpyAsync(out, c.d_wire.p, (size_t)n, hipMemcpyDeviceToHost, c.stream));
-    LSN_HIP(hipStreamSynchronize(c.stream));
+    LSN_HIP(hipMemcpyAsync(out, c.d_wire.p, (size_t)n, hipMemcpyDeviceToHost, l.stream));
+    LSN_HIP(hipStreamSynchronize(l.stream));
     return n;
 }
 }  // namespace
@@ -745,14 +779,18 @@ extern "C" long long lsnLastMeshTransferFrame(unsigned char *out, long long out_
 {
     lsn::clear_error();
     Ctx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    return last_mesh_bytes(c, 0, out, out_cap);
+    Lane *l = c.last_lane.load();
+    if (!l) l = &c.merge;
+    std::lock_guard<std::mutex> g(l->mu);
+    return last_mesh_bytes(c, *l, 0, out, out_cap);
 }
 
 extern "C" long long lsnLastMeshPly(unsigned char *out, long long out_cap)
 {
     lsn::clear_error();
     Ctx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    return last_mesh_bytes(c, 1, out, out_cap);
+    Lane *l = c.last_lane.load();
+    if (!l) l = &c.merge;
+    std::lock_guard<std::mutex> g(l->mu);
+    return last_mesh_bytes(c, *l, 1, out, out_cap);
 }

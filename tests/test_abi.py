@@ -88,3 +88,48 @@ def test_public_header_is_plain_c_and_cpp():
     subprocess.check_call(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", hdr])
     includes = [l for l in open(hdr).read().splitlines() if l.strip().startswith("#include")]
     assert all(("<stdbool.h>" in l) or ("<stdint.h>" in l) for l in includes), f"the boundary header pulls in more than <stdbool.h>/<stdint.h>: {includes}"
+
+
+@pytest.mark.gpu
+def test_merge_and_single_sensor_calls_from_two_threads(gpu, orc):
+    """LiveScanServer's updateWorker (merge calls) and refineWorker (single-sensor calls) run concurrently (MainWindowForm.cs:238,304):
+    the two families have their own lanes (streams, buffers, lock) inside the library; every result must be the oracle's."""
+    import threading
+    from livescan3d_amd import synth
+    rig = synth.make_rig("scene", 4, 256, 212, seed=41, bounds=synth.CROP_BOUNDS)
+    want_v, counts, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    edges = np.concatenate([[0], np.cumsum(counts)])
+    errors = []
+
+    def merges():
+        try:
+            for _ in range(12):
+                v, t = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+                assert v.tobytes() == want_v.tobytes() and np.array_equal(t, want_t)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(f"merge: {ex!r}")
+
+    def singles():
+        try:
+            for rep in range(12):
+                i = rep % 4
+                v = native.generate_vertices_from_depth_map(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, i)
+                assert v.tobytes() == want_v[edges[i]:edges[i + 1]].tobytes()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(f"single: {ex!r}")
+
+    def radials():
+        try:
+            want_d, want_c = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+            for _ in range(6):
+                d, c = native.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+                assert np.array_equal(d, np.asarray(want_d).view(np.uint8).ravel()) and np.array_equal(c, np.asarray(want_c).ravel())
+        except Exception as ex:  # noqa: BLE001
+            errors.append(f"radial: {ex!r}")
+
+    threads = [threading.Thread(target=f) for f in (merges, singles, radials)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
