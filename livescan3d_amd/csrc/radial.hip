@@ -145,9 +145,10 @@ __device__ __forceinline__ void store_tile_run(T *dst, const T *lds, int lead, i
 // The candidate table above costs 16 bytes per destination and tick (the 8 x 512x424 rig: 27.8 MB, streamed from the Infinity
 // Cache by every tick -- the round-2 PMC pass showed 2 x 255 MB fetched for 139 MB of frames).  A radial map moves a pixel by
 // a few columns / rows, and almost every destination has one or two sources, so the table the ticks read is ONE dword per
-// destination: two candidates as (dx + 128) | (dy + 128) << 8 in 16 bits each, 0 = none, highest source index first.  A
-// destination with three or four sources, or one further than 127 pixels away, holds kWide and is looked up in the full table
-// (a handful of pixels per frame for Kinect-like intrinsics).  6.9 MB for the 8-sensor rig: it stays in the L2s.
+// destination: two candidates as (source pixel - destination pixel) + 32768 in 16 bits each (indices inside the frame; 0 = none),
+// highest source index first -- a candidate then decodes with one add.  A destination with three or four sources, or one more than
+// 32767 pixels away, holds kWide and is looked up in the full table (a handful of pixels per frame for Kinect-like intrinsics).
+// 6.9 MB for the 8-sensor rig: it stays in the L2s.
 constexpr unsigned int kWide = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(kThreads) void radial_cand_pack_kernel(const FrameDesc *frames, const TileDesc *tiles, const uint4 *cand,
@@ -160,15 +161,13 @@ __global__ __launch_bounds__(kThreads) void radial_cand_pack_kernel(const FrameD
     for (int i = threadIdx.x; i < kTile; i += kThreads) {
         const int p = p0 + i;
         if (p >= fd.npix) break;
-        const int y = p / fd.w, x = p - y * fd.w;
         const uint4 c = cand[fd.depth_off + p];
         auto enc = [&](unsigned int src, unsigned int &code) {
             code = 0;
             if (!src) return true;
-            const int s = (int)(src - 1u), sy = s / fd.w, sx = s - sy * fd.w;
-            const int dx = sx - x, dy = sy - y;
-            if (dx < -127 || dx > 127 || dy < -127 || dy > 127) return false;
-            code = (unsigned int)(dx + 128) | ((unsigned int)(dy + 128) << 8);
+            const int rel = (int)(src - 1u) - p;
+            if (rel < -32767 || rel > 32767) return false;
+            code = (unsigned int)(rel + 32768);
             return true;
         };
         unsigned int c0, c1;
@@ -189,14 +188,6 @@ struct WarpSrc {
     long long last_px;             // index of the last pixel of the whole batch (its colour is not read as a dword)
 };
 
-// the three colour bytes of pixel g as 0x00BBGGRR: one unaligned dword load (the byte behind them belongs to the next pixel; the
-// very last pixel of the batch is read one byte early instead, so nothing behind the buffer is touched), no branch
-__device__ __forceinline__ unsigned int load_rgb_at(const unsigned char *rgb, long long g, long long last_px)
-{
-    const int adj = g == last_px ? 1 : 0;
-    const unsigned int v = *reinterpret_cast<const u32_ua *>(rgb + 3 * g - adj);
-    return (v >> (8 * adj)) & 0x00FFFFFFu;
-}
 
 // Warped value of K destination pixels p[k] of one frame (fb = first pixel of the frame in the batch, doff = in its tick): a
 // chain of dependent loads per pixel -- table, the candidates' depths (both at once; with SPEC the first candidate's colour too),
@@ -207,15 +198,25 @@ template <int K, bool SPEC = false>
 __device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, long long doff, int w, int pv, const int (&p)[K], const bool (&in)[K],
                                              unsigned int (&d)[K], unsigned int (&rgb)[K])
 {
-    unsigned int e[K];
-    int pk[K];
+    // wave-uniform bases + 32-bit offsets: the loads address as SGPR pair + VGPR offset, no 64-bit vector arithmetic per pixel
+    const unsigned int *tab = S.ctab + doff;
+    const unsigned short *dep = S.depth + fb;
+    const unsigned char *col = S.rgb + 3 * fb;
+    const bool last_frame = fb + (long long)pv <= S.last_px && S.last_px - fb < (1ll << 30);   // the batch's last pixel may lie in this frame
+    const unsigned int last = last_frame ? (unsigned int)(S.last_px - fb) : 0xFFFFFFFFu;
+    auto colour = [&](unsigned int q) {     // 0x00BBGGRR of the frame's pixel q (see load_rgb_at)
+        const unsigned int adj = q == last ? 1u : 0u;
+        const unsigned int v = *reinterpret_cast<const u32_ua *>(col + (3u * q - adj));
+        return (v >> (8u * adj)) & 0x00FFFFFFu;
+    };
+    unsigned int e[K], pk[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        pk[k] = in[k] ? p[k] : pv;
-        e[k] = S.ctab[doff + pk[k]];
+        pk[k] = (unsigned int)(in[k] ? p[k] : pv);
+        e[k] = tab[pk[k]];
     }
-    int s0[K], s1[K];
-    unsigned int d0[K], d1[K], c0[K];
+    unsigned int s0[K], s1[K], d0[K], d1[K], c0[K];
+    bool v0[K], v1[K];
     bool any_wide = false;
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -223,33 +224,36 @@ __device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, lon
         const unsigned int a0 = e[k] & 0xFFFFu, a1 = e[k] >> 16;
         const bool wide = e[k] == kWide;
         any_wide |= wide;
-        s0[k] = (a0 && !wide) ? pk[k] + (int)(a0 & 0xFFu) - 128 + ((int)(a0 >> 8) - 128) * w : -1;
-        s1[k] = (a1 && !wide) ? pk[k] + (int)(a1 & 0xFFu) - 128 + ((int)(a1 >> 8) - 128) * w : -1;
-        d0[k] = S.depth[fb + (s0[k] >= 0 ? s0[k] : pk[k])];
-        d1[k] = S.depth[fb + (s1[k] >= 0 ? s1[k] : pk[k])];
-        if (SPEC) c0[k] = load_rgb_at(S.rgb, fb + (s0[k] >= 0 ? s0[k] : pk[k]), S.last_px);   // the first candidate's colour rides with the depths
+        v0[k] = a0 != 0 && !wide;
+        v1[k] = a1 != 0 && !wide;
+        s0[k] = v0[k] ? pk[k] + a0 - 32768u : pk[k];      // a candidate that does not exist reads the pixel's own position and is dropped
+        s1[k] = v1[k] ? pk[k] + a1 - 32768u : pk[k];
+        d0[k] = dep[s0[k]];
+        d1[k] = dep[s1[k]];
+        if (SPEC) c0[k] = colour(s0[k]);                   // the first candidate's colour rides with the depths
     }
-    int src[K];
+    unsigned int src[K];
     bool second = false;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        if (s0[k] < 0) d0[k] = 0;
-        if (s1[k] < 0) d1[k] = 0;
-        src[k] = d0[k] ? s0[k] : (d1[k] ? s1[k] : -1);      // the highest valid source wins (:200-218: the last one in raster order)
+        if (!v0[k]) d0[k] = 0;
+        if (!v1[k]) d1[k] = 0;
+        const bool any = (d0[k] | d1[k]) != 0;
+        src[k] = d0[k] ? s0[k] : (d1[k] ? s1[k] : pk[k]);   // the highest valid source wins (:200-218: the last one in raster order)
         d[k] = d0[k] ? d0[k] : d1[k];
         if (SPEC) {
             rgb[k] = d0[k] ? c0[k] : 0u;
             second |= !d0[k] && d1[k];
         } else {
-            rgb[k] = load_rgb_at(S.rgb, fb + (src[k] >= 0 ? src[k] : pk[k]), S.last_px);
-            if (src[k] < 0) rgb[k] = 0;
+            rgb[k] = colour(src[k]);
+            if (!any) rgb[k] = 0;
         }
     }
     if (SPEC && __any(second)) {                            // a zero-depth first candidate in front of a valid second one
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const bool need = !d0[k] && d1[k];
-            const unsigned int v = load_rgb_at(S.rgb, fb + (need ? s1[k] : pk[k]), S.last_px);
+            const unsigned int v = colour(need ? s1[k] : pk[k]);
             if (need) rgb[k] = v;
         }
     }
@@ -264,12 +268,12 @@ __device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, lon
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (sw < 0 && cs[j]) {
-                        const unsigned int v = S.depth[fb + (cs[j] - 1u)];
+                        const unsigned int v = dep[cs[j] - 1u];
                         if (v) { sw = (int)(cs[j] - 1u); dd = v; }
                     }
                 }
                 d[k] = dd;
-                rgb[k] = sw >= 0 ? load_rgb_at(S.rgb, fb + sw, S.last_px) : 0u;
+                rgb[k] = sw >= 0 ? colour((unsigned int)sw) : 0u;
             }
         }
     }
@@ -614,12 +618,21 @@ struct BandArgs {
     long long tick_pix_stride, holes_tick_bytes;
 };
 
+constexpr int kBandList = 8192;   // most candidates one pass over the band's rows lists (16-bit local pixel indices); taller / wider bands go in chunks of rows
+
+// entries of the candidate list of a band
+__host__ __device__ inline int band_list_entries(int rows, int w)
+{
+    const int all = rows * w;
+    return all <= kBandList ? all : (kBandList > w ? kBandList : w);
+}
+
 // LDS of one band workgroup: (rows + 2) x w depths and colours (each behind up to 15 bytes of lead so that the rows that leave
-// sit at their destination's address modulo 16), the candidate list (rows x w entries: local pixel | fill depth << 16), a counter
+// sit at their destination's address modulo 16), the candidate list, a counter
 __host__ __device__ inline int band_lds_bytes(int rows, int w)
 {
     const int band_px = (rows + 2) * w;
-    return 16 + ((2 * band_px + 15) & ~15) + 16 + ((3 * band_px + 15) & ~15) + 4 * rows * w + 16;
+    return 16 + ((2 * band_px + 15) & ~15) + 16 + ((3 * band_px + 15) & ~15) + ((2 * band_list_entries(rows, w) + 15) & ~15) + 16;
 }
 
 // copies n bytes from LDS to global memory; (lds offset from the 16-byte aligned LDS base) = (global address) modulo 16
@@ -659,9 +672,9 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
     const int off_l = off_c + 16 + ((3 * band_px + 15) & ~15);
     unsigned short *s_d = reinterpret_cast<unsigned short *>(smem + lead_d);
     unsigned char *s_c = smem + off_c + lead_c;
-    unsigned int *s_list = reinterpret_cast<unsigned int *>(smem + off_l);
-    int *s_n = reinterpret_cast<int *>(smem + off_l + 4 * a.rows * w);
-    if (tid == 0) *s_n = 0;
+    unsigned short *s_list = reinterpret_cast<unsigned short *>(smem + off_l);
+    const int list_entries = band_list_entries(a.rows, w);
+    int *s_n = reinterpret_cast<int *>(smem + off_l + ((2 * list_entries + 15) & ~15));
     const int pl0 = (y0 - 1) * w;                       // frame pixel of local pixel 0 (negative for the first band)
     const int lo = pl0 < 0 ? -pl0 : 0;                  // local pixels [lo, hi) exist in the frame
     const int hi = min((nrows + 2) * w, fd.npix - pl0);
@@ -712,134 +725,138 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
     }
     __syncthreads();
 
-    // ---- 2. the holes: one bit per pixel for the second pass; the candidates (>= 5 valid neighbours, interior) onto the list ----
-    const long long hole_bit0 = hole_base_bit(fd, bd.frame);
-    unsigned char *holes = a.holes + tick * a.holes_tick_bytes;
-    if (VEC) {
-        const int gw = w >> 3, ngroups = nrows * gw;
-        for (int g0 = 0; g0 < ngroups; g0 += kBandThreads) {
-            const int g = g0 + tid;
-            unsigned int cb = 0;
-            int li = 0;
-            if (g < ngroups) {
-                const int r = g / gw, x0 = (g - r * gw) << 3, y = y0 + r;
-                li = (r + 1) * w + x0;
-                unsigned int m[3];
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++) {
-                    const unsigned short *row = s_d + li + (rr - 1) * w;
-                    const uint4 c = *reinterpret_cast<const uint4 *>(row);
-                    const unsigned int left = x0 > 0 ? row[-1] : 0u, right = x0 + 8 < w ? row[8] : 0u;
-                    const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
-                    unsigned int bits = left ? 1u : 0u;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        bits |= (cw[k] & 0xFFFFu) ? (2u << (2 * k)) : 0u;
-                        bits |= (cw[k] >> 16) ? (4u << (2 * k)) : 0u;
-                    }
-                    bits |= right ? (1u << 9) : 0u;
-                    m[rr] = bits;                                  // bit c: column x0 - 1 + c holds a valid depth
-                }
-                const unsigned int hb = ~(m[1] >> 1) & 0xFFu;      // bit k: pixel x0 + k is a hole
-                holes[(hole_bit0 + (long long)y * w + x0) >> 3] = (unsigned char)hb;
-                if (y >= 1 && y < h - 1) {                         // :223-224 interior pixels only
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int nv = __popc((m[0] >> k) & 7u) + __popc((m[1] >> k) & 5u) + __popc((m[2] >> k) & 7u);
-                        cb |= (nv >= 5 && x0 + k >= 1 && x0 + k < w - 1) ? (1u << k) : 0u;
-                    }
-                    cb &= hb;
-                }
-            }
-            int slot = wave_reserve(s_n, __popc(cb));
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if ((cb >> k) & 1u) s_list[slot++] = (unsigned int)(li + k);
-        }
-    } else {
-        // any width: pixel by pixel (the bitmap was cleared by the host)
-        unsigned int *hw = reinterpret_cast<unsigned int *>(holes);
-        const int n_px = nrows * w;
-        for (int i0 = 0; i0 < n_px; i0 += kBandThreads) {
-            const int i = i0 + tid;
-            bool cand = false;
-            const int li = w + i;
-            if (i < n_px && s_d[li] == 0) {
-                const int r = i / w, x = i - r * w, y = y0 + r;
-                const long long bit = hole_bit0 + (long long)y * w + x;
-                atomicOr(&hw[bit >> 5], 1u << (bit & 31));
-                if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
-                    int nv = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) nv += s_d[li + kDy[j] * w + kDx[j]] != 0 ? 1 : 0;
-                    cand = nv >= 5;
-                }
-            }
-            const int slot = wave_reserve(s_n, cand ? 1 : 0);
-            if (cand) s_list[slot] = (unsigned int)li;
-        }
-    }
-    __syncthreads();
-
-    // ---- 3. the candidates, one per lane, against the un-closed band ----
-    const int n_cand = *s_n;
-    unsigned int *work = a.work + 2 * fb;
-    for (int i0 = 0; i0 < n_cand; i0 += kBandThreads) {
-        const int i = i0 + tid;
-        unsigned int succ = 0;
-        int x = 0, y = 0;
-        if (i < n_cand) {
-            const int q = (int)s_list[i];
-            int nb[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) nb[j] = s_d[q + kDy[j] * w + kDx[j]];
-            int n, sum;
-            unsigned int accepted;
-            accept_chain(nb, n, sum, accepted);
-            if (n > 4) {                                                                       // :250-256
-                unsigned int nc[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const unsigned char *c3 = s_c + 3 * (q + kDy[j] * w + kDx[j]);
-                    nc[j] = (accepted >> j) & 1u ? ((unsigned int)c3[0] | ((unsigned int)c3[1] << 8) | ((unsigned int)c3[2] << 16)) : 0u;
-                }
-                const unsigned int rgb = average_colour(nc, accepted, n);
-                // a hole's colour is never read by another evaluation (only accepted = valid neighbours' colours are): patch it now
-                s_c[3 * q] = (unsigned char)rgb;
-                s_c[3 * q + 1] = (unsigned char)(rgb >> 8);
-                s_c[3 * q + 2] = (unsigned char)(rgb >> 16);
-                s_list[i] = (unsigned int)q | (div_small(sum, n) << 16);                       // the depth goes in after the barrier
-                int yl = (int)((float)q * fd.inv_w);
-                x = q - yl * w;
-                if (x < 0) { yl--; x += w; }
-                if (x >= w) { yl++; x -= w; }
-                y = y0 - 1 + yl;
-                // its hole successors now depend on the order: onto the frame's list (interior pixels only, :223-224)
-                const bool below = y + 1 < h - 1;
-                succ = ((nb[4] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((nb[5] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
-                       ((nb[6] == 0 && below) ? 4u : 0u) | ((nb[7] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
-            }
-        }
-        int slot = wave_reserve(a.work_cnt + kCntStride * tf, __popc(succ));
-#pragma unroll
-        for (int sidx = 0; sidx < 4; sidx++) {
-            if ((succ >> sidx) & 1u) {
-                const int j = 4 + sidx;   // neighbours 4..7 are the successors
-                if (slot < 2 * fd.npix) work[slot] = (unsigned int)((y + kDy[j]) * w + x + kDx[j]);   // (a frame lists < 24/13 npix entries)
-                slot++;
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < n_cand; i += kBandThreads) {
-        const unsigned int e = s_list[i];
-        if (e >> 16) s_d[e & 0xFFFFu] = (unsigned short)(e >> 16);
-    }
-    __syncthreads();
-
-    // ---- 4. the band leaves ----
+    // ---- 2. the band leaves as it is (un-closed); the fills follow below as single stores, behind the barrier that ends this phase ----
     store_band_run(reinterpret_cast<unsigned char *>(gd), reinterpret_cast<const unsigned char *>(s_d + w), 2 * nrows * w);
     store_band_run(gc, s_c + 3 * w, 3 * nrows * w);
+
+    // ---- 3. the holes, a few rows at a time: one bit per pixel for the second pass; the candidates (interior holes with >= 5 valid
+    //         neighbours) go on a short list in LDS and are evaluated one per lane against the un-closed band (which nothing modifies:
+    //         exact unless one of the hole's predecessors gets filled); a fill is stored straight to the output and lists its hole
+    //         successors (right, down-left, down, down-right) on the frame's work list ----
+    const long long hole_bit0 = hole_base_bit(fd, bd.frame);
+    unsigned char *holes = a.holes + tick * a.holes_tick_bytes;
+    unsigned int *work = a.work + 2 * fb;
+    int *work_cnt = a.work_cnt + kCntStride * tf;
+    const int rows_per_chunk = max(1, list_entries / w);   // a chunk's candidates always fit the list
+    for (int r0 = 0; r0 < nrows; r0 += rows_per_chunk) {
+        const int r1 = min(nrows, r0 + rows_per_chunk);
+        __syncthreads();                                 // the previous chunk's list has been consumed (first chunk: the band's stores are done)
+        if (tid == 0) *s_n = 0;
+        __syncthreads();
+        if (VEC) {
+            const int gw = w >> 3, ngroups = (r1 - r0) * gw;
+            for (int g0 = 0; g0 < ngroups; g0 += kBandThreads) {
+                const int g = g0 + tid;
+                unsigned int cb = 0;
+                int li = 0;
+                if (g < ngroups) {
+                    const int r = r0 + g / gw, x0 = (g % gw) << 3, y = y0 + r;
+                    li = (r + 1) * w + x0;
+                    unsigned int m[3];
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++) {
+                        const unsigned short *row = s_d + li + (rr - 1) * w;
+                        const uint4 c = *reinterpret_cast<const uint4 *>(row);
+                        const unsigned int left = x0 > 0 ? row[-1] : 0u, right = x0 + 8 < w ? row[8] : 0u;
+                        const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
+                        unsigned int bits = left ? 1u : 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            bits |= (cw[k] & 0xFFFFu) ? (2u << (2 * k)) : 0u;
+                            bits |= (cw[k] >> 16) ? (4u << (2 * k)) : 0u;
+                        }
+                        bits |= right ? (1u << 9) : 0u;
+                        m[rr] = bits;                                  // bit c: column x0 - 1 + c holds a valid depth
+                    }
+                    const unsigned int hb = ~(m[1] >> 1) & 0xFFu;      // bit k: pixel x0 + k is a hole
+                    holes[(hole_bit0 + (long long)y * w + x0) >> 3] = (unsigned char)hb;
+                    if (y >= 1 && y < h - 1) {                         // :223-224 interior pixels only
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int nv = __popc((m[0] >> k) & 7u) + __popc((m[1] >> k) & 5u) + __popc((m[2] >> k) & 7u);
+                            cb |= (nv >= 5 && x0 + k >= 1 && x0 + k < w - 1) ? (1u << k) : 0u;
+                        }
+                        cb &= hb;
+                    }
+                }
+                int slot = wave_reserve(s_n, __popc(cb));
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if ((cb >> k) & 1u) s_list[slot++] = (unsigned short)(li + k);
+            }
+        } else {
+            // any width: pixel by pixel (the bitmap was cleared by the host)
+            unsigned int *hw = reinterpret_cast<unsigned int *>(holes);
+            const int n_px = (r1 - r0) * w;
+            for (int i0 = 0; i0 < n_px; i0 += kBandThreads) {
+                const int i = r0 * w + i0 + tid;
+                bool cand = false;
+                const int li = w + i;
+                if (i0 + tid < n_px && s_d[li] == 0) {
+                    const int r = i / w, x = i - r * w, y = y0 + r;
+                    const long long bit = hole_bit0 + (long long)y * w + x;
+                    atomicOr(&hw[bit >> 5], 1u << (bit & 31));
+                    if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
+                        int nv = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) nv += s_d[li + kDy[j] * w + kDx[j]] != 0 ? 1 : 0;
+                        cand = nv >= 5;
+                    }
+                }
+                const int slot = wave_reserve(s_n, cand ? 1 : 0);
+                if (cand) s_list[slot] = (unsigned short)li;
+            }
+        }
+        __syncthreads();
+        const int n_cand = *s_n;
+        for (int i0 = 0; i0 < n_cand; i0 += kBandThreads) {
+            const int i = i0 + tid;
+            if (i0 + (tid & ~63) >= n_cand) continue;                 // nothing left for this wave (wave-uniform)
+            unsigned int succ = 0;
+            int x = 0, y = 0;
+            if (i < n_cand) {
+                const int q = (int)s_list[i];
+                int nb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) nb[j] = s_d[q + kDy[j] * w + kDx[j]];
+                int n, sum;
+                unsigned int accepted;
+                accept_chain(nb, n, sum, accepted);
+                if (n > 4) {                                                                       // :250-256
+                    unsigned int nc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const unsigned char *c3 = s_c + 3 * (q + kDy[j] * w + kDx[j]);
+                        nc[j] = (accepted >> j) & 1u ? ((unsigned int)c3[0] | ((unsigned int)c3[1] << 8) | ((unsigned int)c3[2] << 16)) : 0u;
+                    }
+                    const unsigned int rgb = average_colour(nc, accepted, n);
+                    const long long pos = fb + pl0 + q;
+                    a.out_d[pos] = (unsigned short)div_small(sum, n);
+                    a.out_c[3 * pos] = (unsigned char)rgb;
+                    a.out_c[3 * pos + 1] = (unsigned char)(rgb >> 8);
+                    a.out_c[3 * pos + 2] = (unsigned char)(rgb >> 16);
+                    int yl = (int)((float)q * fd.inv_w);
+                    x = q - yl * w;
+                    if (x < 0) { yl--; x += w; }
+                    if (x >= w) { yl++; x -= w; }
+                    y = y0 - 1 + yl;
+                    // its hole successors now depend on the order: onto the frame's list (interior pixels only, :223-224)
+                    const bool below = y + 1 < h - 1;
+                    succ = ((nb[4] == 0 && x + 1 < w - 1) ? 1u : 0u) | ((nb[5] == 0 && x - 1 >= 1 && below) ? 2u : 0u) |
+                           ((nb[6] == 0 && below) ? 4u : 0u) | ((nb[7] == 0 && x + 1 < w - 1 && below) ? 8u : 0u);
+                }
+            }
+            int slot = wave_reserve(work_cnt, __popc(succ));
+#pragma unroll
+            for (int sidx = 0; sidx < 4; sidx++) {
+                if ((succ >> sidx) & 1u) {
+                    const int j = 4 + sidx;   // neighbours 4..7 are the successors
+                    if (slot < 2 * fd.npix) work[slot] = (unsigned int)((y + kDy[j]) * w + x + kDx[j]);   // (a frame lists < 24/13 npix entries)
+                    slot++;
+                }
+            }
+        }
+    }
 }
 
 constexpr int kFixThreads = 256;   // measured on 512 scene frames: 1024 threads 377 us, 512: 274, 256: 245 -- the rounds are short, idle waves only add barrier time
@@ -1153,8 +1170,10 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
     // bands: as many rows as fit the LDS budget of two workgroups per CU for the widest frame
     int max_w = 1, max_h = 1;
     for (int i = 0; i < p->n_maps; i++) { max_w = std::max(max_w, p->w[i]); max_h = std::max(max_h, p->h[i]); }
-    int rows = 16;
-    while (rows > 1 && band_lds_bytes(rows, max_w) > 79 * 1024) rows--;
+    // 12 rows of a 512-wide frame: 48 KB, three workgroups per CU (measured on 512 scene frames: 16 rows 0.775 ms for the whole correction,
+    // 12 rows 0.753, 8 rows 0.783, 4 rows 0.93)
+    int rows = 12;
+    while (rows > 1 && band_lds_bytes(rows, max_w) > 52 * 1024) rows--;
     if (const char *env = getenv("LSN_RADIAL_BAND_ROWS")) {  // tuning
         const int v = atoi(env);
         if (v >= 1 && band_lds_bytes(v, max_w) <= 160 * 1024) rows = v;
