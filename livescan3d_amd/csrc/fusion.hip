@@ -415,26 +415,28 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
         if (threadIdx.x == 0) atomicExch(a.error_flag, 2);
         return;
     }
-    if (a.pixmap) {
+    if (VEC ? a.pm_first != nullptr : a.pixmap != nullptr) {
         // depth_to_vertices_map (depthprocessing.cpp:166), already rebased to the tick's merged cloud like formMesh
-        // rebases triangle indices (:1614-1626): what the triangulation pass reads
+        // rebases triangle indices (:1614-1626): what the triangulation pass reads.  A lane's 8 pixels get consecutive indices,
+        // so the map is the lane's first index + an 8-bit mask (5 bytes per 8 pixels instead of 32); rigs the lanes do not fit
+        // (widths that are not multiples of 8) keep one int per pixel.
         const int p0 = t.px0 + threadIdx.x * kPxPerLane;
         if (p0 < t.npix) {
-            int *pm = a.pixmap + tick * a.tick_depth_stride + t.pix_base + p0;
             int r = base + wave_off + below;
-            int v[kPxPerLane];
-#pragma unroll
-            for (int k = 0; k < kPxPerLane; k++) {
-                v[k] = keep[k] ? r : -1;
-                r += keep[k] ? 1 : 0;
-            }
             if (VEC) {
-                reinterpret_cast<int4 *>(pm)[0] = make_int4(v[0], v[1], v[2], v[3]);
-                reinterpret_cast<int4 *>(pm)[1] = make_int4(v[4], v[5], v[6], v[7]);
-            } else {
+                unsigned int m = 0;
 #pragma unroll
-                for (int k = 0; k < kPxPerLane; k++)
-                    if (p0 + k < t.npix) pm[k] = v[k];
+                for (int k = 0; k < kPxPerLane; k++) m |= keep[k] ? (1u << k) : 0u;
+                const long long g = (tick * a.tick_depth_stride + t.pix_base + p0) >> 3;
+                a.pm_first[g] = r;
+                a.pm_mask[g] = (unsigned char)m;
+            } else {
+                int *pm = a.pixmap + tick * a.tick_depth_stride + t.pix_base + p0;
+#pragma unroll
+                for (int k = 0; k < kPxPerLane; k++) {
+                    if (p0 + k < t.npix) pm[k] = keep[k] ? r : -1;
+                    r += keep[k] ? 1 : 0;
+                }
             }
         }
     }
@@ -864,6 +866,8 @@ void lsn::fill_args(LsnFusion *p, FuseArgs &a, const void *d_depth, const void *
     a.ticket = p->misc.as<unsigned int>() + 32;
     a.offsets = d_offsets;
     a.pixmap = p->want_pixmap ? p->pixmap.as<int>() : nullptr;
+    a.pm_first = p->want_pixmap ? p->pm_first.as<int>() : nullptr;
+    a.pm_mask = p->want_pixmap ? p->pm_mask.as<unsigned char>() : nullptr;
     a.n_frames = p->n_maps;
     a.tiles_per_tick = p->tiles_per_tick;
     a.n_ticks = p->n_ticks;
@@ -1018,6 +1022,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
     // the wide-load path also needs 16-B aligned buffers and every tick to start 16-B / 8-B aligned
     const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 &&
                      (p->tick_depth_elems % 8) == 0;
+    if (with_pixmap) p->pixmap_compact = vec;   // the triangulation reads the form this run writes
     const int grid = p->tiles_per_tick * p->n_ticks;
     const size_t off_bytes = sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1);
 

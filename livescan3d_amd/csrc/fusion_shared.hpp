@@ -44,7 +44,9 @@ struct FuseArgs {
     unsigned long long *run_state;   // mode 1: [n_ticks * tiles_per_tick] {flag:2 | value}, indexed by run
     unsigned int *ticket;            // mode 1: per-tick run tickets, 32 words apart
     int *offsets;                    // [n_ticks][n_frames + 1]
-    int *pixmap;                     // optional [n_ticks][pixels per tick]: vertex index inside the tick's cloud, -1 = none
+    int *pixmap;                     // optional [n_ticks][pixels per tick]: vertex index inside the tick's cloud, -1 = none (rigs the 8-pixel lanes do not fit)
+    int *pm_first;                   // ... or its compact form, per lane of 8 pixels: index of the lane's first vertex ...
+    unsigned char *pm_mask;          // ... and which of the 8 pixels have one (0.625 instead of 4 bytes per pixel)
     const unsigned short *depth_next;  // streamed mode (MODE 3): the NEXT batch's depth, counted in the shadow of this write
     int *tile_counts_next;             // ... and where its per-tile counts go
     int *error_flag;                 // mode 1: set when a bounded spin gives up (sticky until read)
@@ -447,7 +449,8 @@ struct LsnFusion {
     float bounds[6] = {0, 0, 0, 0, 0, 0};
     lsn::DevBuf frames, tile_frame, params, tile_counts, tile_state, misc;  // misc: error flag (word 0) + tickets
     lsn::DevBuf xtab, ytab;
-    lsn::DevBuf pixmap, tri_counts, tri_codes;  // triangulation scratch, allocated on first use
+    lsn::DevBuf pixmap, pm_first, pm_mask, tri_counts, tri_codes;  // triangulation scratch, allocated on first use
+    bool pixmap_compact = false;     // which form of the pixel -> vertex map the last run wrote
     lsn::DevBuf winner, map_copy, colors_copy, radial;  // radial-correction scratch, allocated on first use
     lsn::DevBuf cand;                                   // [pixels per tick][4] warp candidates of the current intrinsics
     lsn::DevBuf ctab;                                   // [pixels per tick] their compact form (one dword per destination)

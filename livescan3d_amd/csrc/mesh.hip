@@ -17,7 +17,9 @@ struct TriArgs {
     const FrameDesc *frames;
     const TileDesc *tiles;
     const unsigned short *depth;
-    const int *pixmap;   // [n_ticks][pixels per tick]
+    const int *pixmap;   // [n_ticks][pixels per tick] (rigs whose widths are not multiples of 8) ...
+    const int *pm_first; // ... or [n_ticks][pixels per tick / 8]: the first vertex index of every lane of 8 pixels ...
+    const unsigned char *pm_mask;   // ... and the mask of its pixels that have a vertex
     int *tri;            // [n_ticks][tri_cap][3]
     int *tile_counts;    // [n_ticks * tiles_per_tick] counts, then exclusive prefixes (scan_kernel)
     unsigned int *codes; // [n_ticks * tiles_per_tick * 256] per-lane 4-bit-per-pixel triangle codes: count pass -> write pass
@@ -102,7 +104,8 @@ __device__ __forceinline__ unsigned int edge_metric_biased(unsigned int vA, unsi
     return min(a, min(f, b));
 }
 
-__device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerLane + 3], const int (&M)[2][kPxPerLane + 1], int x0, int w)
+// mU9 / mP9: bit c = the pixel of column x0 + c in row y - 1 / row y has a vertex (c = 0 .. 8)
+__device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerLane + 3], unsigned int mU9, unsigned int mP9, int x0, int w)
 {
     unsigned int Z[4][kPxPerLane + 3];
 #pragma unroll
@@ -131,7 +134,7 @@ __device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerL
         const bool alt = !(t0 | t1);                                                    // :120
         const bool t2 = alt & zP & zUR & zU & (d2 < th2) & (hU < th2) & (pu < th2);     // P,UR,U (:122)
         const bool t3 = alt & zP & zR & zUR & (hP < th3) & (ru < th3) & (d2 < th3);     // P,R,UR (:123)
-        const bool mP = M[1][k] != -1, mU = M[0][k] != -1, mUR = M[0][k + 1] != -1, mR = M[1][k + 1] != -1;
+        const bool mP = (mP9 >> k) & 1u, mU = (mU9 >> k) & 1u, mUR = (mU9 >> (k + 1)) & 1u, mR = (mP9 >> (k + 1)) & 1u;
         const bool in_cols = (x >= 1) & (x < w - 2);                                    // :87-90
         unsigned int m = 0;
         m |= (t0 & mR & mU) ? 1u : 0u;                                                  // :133-134
@@ -176,19 +179,34 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
     for (int r = 0; r < 2; r++)
 #pragma unroll
         for (int c = 0; c <= kPxPerLane; c++) M[r][c] = -1;
+    // VEC: the compact map of rows y-1 and y -- the lane's own group of 8 pixels and the first pixel of the group to its right
+    int first[2] = {0, 0}, first_next[2] = {0, 0};
+    unsigned int mask9[2] = {0, 0};
+    auto load_groups = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const long long g = (tick * a.tick_pix_stride + fd.depth_off + (long long)(y0 - 1 + r) * w + x0) >> 3;
+            first[r] = a.pm_first[g];
+            unsigned int m = a.pm_mask[g];
+            if (x0 + 8 < w) {
+                first_next[r] = a.pm_first[g + 1];
+                m |= ((unsigned int)a.pm_mask[g + 1] & 1u) << 8;
+            }
+            mask9[r] = m;
+        }
+    };
 
     const size_t code_slot = (size_t)blockIdx.x * kThreads + threadIdx.x;
     if (MODE == 1) {
-        // the count pass already evaluated every stencil: reload its verdicts, fetch only the vertex indices
+        // the count pass already evaluated every stencil: reload its verdicts, rebuild only the vertex indices
         code = a.codes[code_slot];
         if (VEC && code != 0) {
+            load_groups();
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                const int *mrow = map + (long long)(y0 - 1 + r) * w + x0;
-                const int4 m0 = reinterpret_cast<const int4 *>(mrow)[0], m1 = reinterpret_cast<const int4 *>(mrow)[1];
-                M[r][0] = m0.x; M[r][1] = m0.y; M[r][2] = m0.z; M[r][3] = m0.w;
-                M[r][4] = m1.x; M[r][5] = m1.y; M[r][6] = m1.z; M[r][7] = m1.w;
-                M[r][8] = x0 + 8 < w ? mrow[8] : -1;
+#pragma unroll
+                for (int c = 0; c < kPxPerLane; c++) M[r][c] = (mask9[r] >> c) & 1u ? first[r] + __popc(mask9[r] & ((1u << c) - 1u)) : -1;
+                M[r][8] = (mask9[r] >> 8) & 1u ? first_next[r] : -1;
             }
         }
     } else if (VEC) {
@@ -196,16 +214,8 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
         const bool row_ok = in_frame && y0 >= 2 && y0 < h - 2;   // :87-90 (bands clamp to [2, h-2))
         bool any_vertex = false;   // a pixel without a vertex emits nothing (:113-114): a lane whose 8 pixels have none skips the stencils --
         if (row_ok) {               // on real frames whole rows outside the crop box do, i.e. whole waves
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int *mrow = map + (long long)(y0 - 1 + r) * w + x0;
-                const int4 m0 = reinterpret_cast<const int4 *>(mrow)[0], m1 = reinterpret_cast<const int4 *>(mrow)[1];
-                M[r][0] = m0.x; M[r][1] = m0.y; M[r][2] = m0.z; M[r][3] = m0.w;
-                M[r][4] = m1.x; M[r][5] = m1.y; M[r][6] = m1.z; M[r][7] = m1.w;
-                M[r][8] = x0 + 8 < w ? mrow[8] : -1;
-            }
-#pragma unroll
-            for (int k = 0; k < kPxPerLane; k++) any_vertex |= M[1][k] != -1;
+            load_groups();
+            any_vertex = (mask9[1] & 0xFFu) != 0;
         }
         if (any_vertex) {
             int D[4][kPxPerLane + 3];
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
                 D[r][9] = right & 0xFFFFu;
                 D[r][10] = right >> 16;
             }
-            code = lane_triangles(D, M, x0, w);
+            code = lane_triangles(D, mask9[0], mask9[1], x0, w);
         }
     } else {
         // general widths: a lane's pixels may span rows; every pixel fetches its own 4 x 4 window
@@ -355,7 +365,11 @@ int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void 
     // two threads sharing a plan cannot interleave between them
     std::lock_guard<std::mutex> g(p->mu);
     LSN_HIP(hipSetDevice(p->device));
-    if (p->pixmap.reserve(sizeof(int) * (size_t)p->cap * p->n_ticks) ||
+    // the pixel -> vertex map: 5 bytes per 8 pixels when the vertex pass runs its wide-load form (the same test as in run_locked),
+    // else one int per pixel
+    const bool wide = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && (p->tick_depth_elems % 8) == 0;
+    if ((wide ? (p->pm_first.reserve(sizeof(int) * ((size_t)p->cap * p->n_ticks / 8 + 2)) || p->pm_mask.reserve((size_t)p->cap * p->n_ticks / 8 + 2))
+              : p->pixmap.reserve(sizeof(int) * (size_t)p->cap * p->n_ticks)) ||
         p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks) ||
         p->tri_codes.reserve(sizeof(unsigned int) * (size_t)p->tiles_per_tick * p->n_ticks * kThreads))
         return -1;
@@ -366,13 +380,15 @@ int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void 
     t.tiles = p->tile_frame.as<TileDesc>();
     t.depth = static_cast<const unsigned short *>(d_depth);
     t.pixmap = p->pixmap.as<int>();
+    t.pm_first = p->pm_first.as<int>();
+    t.pm_mask = p->pm_mask.as<unsigned char>();
     t.tri = static_cast<int *>(d_triangles);
     t.tile_counts = p->tri_counts.as<int>();
     t.codes = p->tri_codes.as<unsigned int>();
     t.tiles_per_tick = p->tiles_per_tick;
     t.tick_pix_stride = p->cap;
     t.tick_tri_stride = 2 * p->cap;
-    const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && (p->tick_depth_elems % 8) == 0;
+    const bool vec = p->pixmap_compact && ((uintptr_t)d_depth & 15) == 0;   // the vertex pass above wrote the compact map iff it ran its wide-load form
     const int grid = p->tiles_per_tick * p->n_ticks;
     if (vec) hipLaunchKernelGGL((tri_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, t);
     else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
