@@ -194,86 +194,80 @@ struct WarpSrc {
 // the winner's colour -- issued for all K pixels level by level.  Every load is unconditional (a pixel that needs none reads its own
 // position and drops the value): no exec-mask branches, so the K loads of a level really are in flight together.  pv: any valid
 // pixel of the frame (stands in for p[k] where in[k] is false).
+// (buffer addressing: a 128-bit resource in SGPRs + one 32-bit byte offset per lane -- no 64-bit vector arithmetic per load, and an
+// offset past the frame reads 0, which is what a candidate that does not exist has to read)
+constexpr unsigned int kRsrcWord3 = 0x00027000u;   // gfx9 raw buffer, 32-bit elements
+constexpr unsigned int kNowhere = 0xFFFFFFF0u;     // a byte offset outside every frame
+
 template <int K, bool SPEC = false>
-__device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, long long doff, int w, int pv, const int (&p)[K], const bool (&in)[K],
+__device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, long long doff, int npix, int pv, const int (&p)[K], const bool (&in)[K],
                                              unsigned int (&d)[K], unsigned int (&rgb)[K])
 {
-    // wave-uniform bases + 32-bit offsets: the loads address as SGPR pair + VGPR offset, no 64-bit vector arithmetic per pixel
-    const unsigned int *tab = S.ctab + doff;
-    const unsigned short *dep = S.depth + fb;
-    const unsigned char *col = S.rgb + 3 * fb;
-    const bool last_frame = fb + (long long)pv <= S.last_px && S.last_px - fb < (1ll << 30);   // the batch's last pixel may lie in this frame
-    const unsigned int last = last_frame ? (unsigned int)(S.last_px - fb) : 0xFFFFFFFFu;
-    auto colour = [&](unsigned int q) {     // 0x00BBGGRR of the frame's pixel q (see load_rgb_at)
-        const unsigned int adj = q == last ? 1u : 0u;
-        const unsigned int v = *reinterpret_cast<const u32_ua *>(col + (3u * q - adj));
+    (void)pv;
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(S.ctab + doff), 0, 4 * npix, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t dep = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(S.depth + fb), 0, 2 * npix, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t col = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(S.rgb + 3 * fb), 0, 3 * npix, kRsrcWord3);
+    const unsigned int last = (unsigned int)npix - 1u;
+    auto colour = [&](unsigned int q, bool real) {     // 0x00BBGGRR of the frame's pixel q: one unaligned dword (the byte behind the three belongs
+        const unsigned int adj = q == last ? 1u : 0u;   // to the next pixel; the frame's last pixel is read one byte early instead); !real reads 0
+        const unsigned int v = __builtin_amdgcn_raw_buffer_load_b32(col, real ? 3u * q - adj : kNowhere, 0, 0);
         return (v >> (8u * adj)) & 0x00FFFFFFu;
     };
-    unsigned int e[K], pk[K];
+    unsigned int e[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        pk[k] = (unsigned int)(in[k] ? p[k] : pv);
-        e[k] = tab[pk[k]];
-    }
+    for (int k = 0; k < K; k++) e[k] = __builtin_amdgcn_raw_buffer_load_b32(tab, in[k] ? 4u * (unsigned int)p[k] : kNowhere, 0, 0);
     unsigned int s0[K], s1[K], d0[K], d1[K], c0[K];
-    bool v0[K], v1[K];
     bool any_wide = false;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        if (!in[k]) e[k] = 0;
         const unsigned int a0 = e[k] & 0xFFFFu, a1 = e[k] >> 16;
         const bool wide = e[k] == kWide;
         any_wide |= wide;
-        v0[k] = a0 != 0 && !wide;
-        v1[k] = a1 != 0 && !wide;
-        s0[k] = v0[k] ? pk[k] + a0 - 32768u : pk[k];      // a candidate that does not exist reads the pixel's own position and is dropped
-        s1[k] = v1[k] ? pk[k] + a1 - 32768u : pk[k];
-        d0[k] = dep[s0[k]];
-        d1[k] = dep[s1[k]];
-        if (SPEC) c0[k] = colour(s0[k]);                   // the first candidate's colour rides with the depths
+        const bool v0 = a0 != 0 && !wide, v1 = a1 != 0 && !wide;
+        s0[k] = (unsigned int)p[k] + a0 - 32768u;
+        s1[k] = (unsigned int)p[k] + a1 - 32768u;
+        d0[k] = __builtin_amdgcn_raw_buffer_load_b16(dep, v0 ? 2u * s0[k] : kNowhere, 0, 0);
+        d1[k] = __builtin_amdgcn_raw_buffer_load_b16(dep, v1 ? 2u * s1[k] : kNowhere, 0, 0);
+        if (SPEC) c0[k] = colour(s0[k], v0);               // the first candidate's colour rides with the depths
     }
-    unsigned int src[K];
     bool second = false;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        if (!v0[k]) d0[k] = 0;
-        if (!v1[k]) d1[k] = 0;
-        const bool any = (d0[k] | d1[k]) != 0;
-        src[k] = d0[k] ? s0[k] : (d1[k] ? s1[k] : pk[k]);   // the highest valid source wins (:200-218: the last one in raster order)
+        const unsigned int src = d0[k] ? s0[k] : s1[k];     // the highest valid source wins (:200-218: the last one in raster order)
         d[k] = d0[k] ? d0[k] : d1[k];
         if (SPEC) {
             rgb[k] = d0[k] ? c0[k] : 0u;
             second |= !d0[k] && d1[k];
         } else {
-            rgb[k] = colour(src[k]);
-            if (!any) rgb[k] = 0;
+            rgb[k] = colour(src, d[k] != 0);
         }
     }
     if (SPEC && __any(second)) {                            // a zero-depth first candidate in front of a valid second one
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const bool need = !d0[k] && d1[k];
-            const unsigned int v = colour(need ? s1[k] : pk[k]);
+            const unsigned int v = colour(s1[k], need);
             if (need) rgb[k] = v;
         }
     }
     if (__any(any_wide)) {                                  // three or four sources, or a far one: the full table (a few pixels per frame)
+        const unsigned short *gdep = S.depth + fb;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if (e[k] == kWide) {
-                const uint4 c = S.cand[doff + pk[k]];
+                const uint4 c = S.cand[doff + p[k]];
                 const unsigned int cs[4] = {c.x, c.y, c.z, c.w};
                 int sw = -1;
                 unsigned int dd = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (sw < 0 && cs[j]) {
-                        const unsigned int v = dep[cs[j] - 1u];
+                        const unsigned int v = gdep[cs[j] - 1u];
                         if (v) { sw = (int)(cs[j] - 1u); dd = v; }
                     }
                 }
                 d[k] = dd;
-                rgb[k] = sw >= 0 ? colour((unsigned int)sw) : 0u;
+                rgb[k] = colour((unsigned int)(sw >= 0 ? sw : 0), sw >= 0);
             }
         }
     }
@@ -306,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void radial_gather_pack_kernel(const Fram
             in[k] = i0 + k * kThreads < kTile && p[k] < fd.npix;
         }
         unsigned int d[kFly], c[kFly];
-        gather_batch<kFly, true>(S, fb, fd.depth_off, fd.w, p0, p, in, d, c);
+        gather_batch<kFly>(S, fb, fd.depth_off, fd.npix, p0, p, in, d, c);
 #pragma unroll
         for (int k = 0; k < kFly; k++) {
             if (!in[k]) continue;
@@ -691,7 +685,7 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
                 in[k] = i0 + k * kBandThreads < hi;
             }
             unsigned int d[kFly], c[kFly];
-            gather_batch<kFly>(a.src, fb, fd.depth_off, w, pl0 + lo, p, in, d, c);
+            gather_batch<kFly>(a.src, fb, fd.depth_off, fd.npix, pl0 + lo, p, in, d, c);
 #pragma unroll
             for (int k = 0; k < kFly; k++) {
                 if (!in[k]) continue;
