@@ -336,6 +336,12 @@ long long lsnTransferFrameBound(int n_vertices, int n_triangles);
 long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles,
                           void *d_out, long long out_cap, void *stream);
 
+/* How the last lsnTransferPack of this handle formed its chunks (a measurement / test aid; the bytes do not depend on it):
+ * 0 = vertices only (formVerticesChunks), 1 = all chunks at once from one prefix sum over the index positions (meshes whose
+ * vertices are each used at most 16 times, consecutive uses < 64997 index positions apart: every grid mesh), 2 = chunk after
+ * chunk (any mesh; what 1 falls back to).  -1 on a null handle. */
+int lsnTransferLastPath(LsnTransfer *t);
+
 /* Binary PLY: header + 15-byte vertex records {f32 x,y,z; u8 r,g,b} + 13-byte face records {u8 3; i32 a,b,c}.
  * lsnPlyBinaryBytes gives the exact file length; lsnPlyPack writes the file image to d_out (device, any alignment),
  * asynchronously on `stream`, and returns its length (-1 on error). */

@@ -232,6 +232,386 @@ __global__ __launch_bounds__(kTriPerBlock) void chunk_emit_kernel(ChunkState *st
     }
 }
 
+// ---- the link path: formMeshChunks without a chunk-by-chunk walk --------------------------------------------------------------------
+//
+// The window walk above finds the chunks one after the other: three dependent launches per chunk, ~50 for the mesh of a tick.  For meshes
+// whose vertex re-use is LOCAL -- every vertex used at most 16 times, two consecutive uses less than a chunk's worth of index positions
+// apart: every grid mesh -- the chunks follow from one prefix sum:
+//   * prev[pos] = the previous index position that uses the same vertex (-1: none), last[pos] = no later position does.  A position opens
+//     a new vertex in the chunk that starts at triangle s iff prev[pos] < 3 s;
+//   * PF[t] = vertices used for the first time up to and including triangle t, PH[t] = vertices used for the last time up to and
+//     including t.  The chunk that starts at triangle s holds, through triangle e, PF[e] - PH[s - 1] vertices: those that have begun minus
+//     those that had already ended -- exact unless a vertex is used before s and after e but not in between, which a link shorter than
+//     64997 positions rules out from e = s + 21665 on, and a chunk cannot close earlier (a triangle opens at most three vertices).  The end
+//     of a chunk is therefore a search in PF; the chunks of a mesh are ~13 such searches by one wave;
+//   * the new index of a position = its rank among the chunk's opening positions (one more prefix sum), or the rank of the opening
+//     position its prev-chain leads to.
+// A vertex with more than 16 uses or a longer link sends the call down the window walk instead (same bytes).
+constexpr int kMaxUses = 16;
+constexpr int kScanPerBlock = 2048;   // elements per workgroup of the prefix sums (8 per thread)
+constexpr unsigned kLastUse = 0x80000000u;   // prev[] holds (previous position + 1) | kLastUse
+
+struct LinkState {
+    int n_chunks, n_send, bad, fallback;
+};
+
+__device__ __forceinline__ int link_prev_of(unsigned code) { return (int)(code & ~kLastUse) - 1; }
+
+__global__ __launch_bounds__(256) void link_uses_kernel(const int *__restrict__ tri, int n_pos, int nV, int *cnt, int *uses, LinkState *st)
+{
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= n_pos) return;
+    const int val = tri[pos];
+    if ((unsigned)val >= (unsigned)nV) { atomicOr(&st->bad, 1); return; }
+    const int k = atomicAdd(&cnt[val], 1);
+    if (k < kMaxUses) uses[(size_t)val * kMaxUses + k] = pos;
+    else atomicOr(&st->fallback, 1);
+}
+
+// the uses of one vertex, each against all: the previous use = the largest smaller one (no sort), the last use = none larger
+template <int N>
+__device__ __forceinline__ void link_row(const int (&u)[16], int n, unsigned *prev, LinkState *st)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (i < n) {
+            const int p = u[i];
+            int best = -1;
+            bool later = false;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const int q = u[j];                               // -2 where the row has no entry
+                best = (q < p && q > best) ? q : best;
+                later |= q > p;
+            }
+            prev[p] = (unsigned)(best + 1) | (later ? 0u : kLastUse);
+            if (best >= 0 && p - best >= kChunkLimit) atomicOr(&st->fallback, 1);   // a link as long as a chunk: the closed form does not hold
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void link_prev_kernel(const int *__restrict__ cnt, const int *__restrict__ uses, int nV, unsigned *prev, LinkState *st)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int n = v < nV ? min(cnt[v], kMaxUses) : 0;
+    const int4 *row = reinterpret_cast<const int4 *>(uses + (size_t)min(v, nV - 1) * kMaxUses);
+    int u[16];
+    const bool wide = __any(n > 8);
+    {
+        const int4 a = row[0], b = row[1];
+        u[0] = a.x; u[1] = a.y; u[2] = a.z; u[3] = a.w; u[4] = b.x; u[5] = b.y; u[6] = b.z; u[7] = b.w;
+    }
+    if (wide) {
+        const int4 a = row[2], b = row[3];
+        u[8] = a.x; u[9] = a.y; u[10] = a.z; u[11] = a.w; u[12] = b.x; u[13] = b.y; u[14] = b.z; u[15] = b.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (i >= n) u[i] = -2;
+    if (wide) link_row<16>(u, n, prev, st);
+    else link_row<8>(u, n, prev, st);
+}
+
+// one thread per triangle: how many of its positions are first uses (low half) and last uses (high half)
+__global__ __launch_bounds__(256) void link_pack_kernel(const unsigned *__restrict__ prev, int nT, unsigned long long *pack, const LinkState *st)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nT || (st->bad | st->fallback)) return;                  // prev[] is incomplete then: nothing below may follow it
+    unsigned f = 0, h = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const unsigned c = prev[3 * t + j];
+        f += (c & ~kLastUse) == 0;
+        h += c >> 31;
+    }
+    pack[t] = (unsigned long long)f | ((unsigned long long)h << 32);
+}
+
+// ---- prefix sums over a few million elements: block totals, one workgroup over the totals, blocks again ----
+template <typename T>
+__device__ __forceinline__ T block_scan_incl(T v, T *s_wave /* 4 */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const T y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    T add = 0;
+    for (int w2 = 0; w2 < wave; w2++) add += s_wave[w2];
+    __syncthreads();
+    return x + add;
+}
+
+// eight consecutive elements of a thread (the arrays are 32-byte aligned and padded to a multiple of eight)
+template <typename T>
+__device__ __forceinline__ void load8(const T *in, long long base, long long n, T (&v)[8])
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "");
+    constexpr int kVec = 16 / sizeof(T);
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + base);
+    uint4 raw[8 / kVec];
+    if (base < n) {
+#pragma unroll
+        for (int i = 0; i < 8 / kVec; i++) raw[i] = src[i];
+    }
+    const T *r = reinterpret_cast<const T *>(raw);
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = base + k < n ? r[k] : T(0);
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(T *out, long long base, long long n, const T (&v)[8])
+{
+    constexpr int kVec = 16 / sizeof(T);
+    if (base + 8 <= n) {
+        const uint4 *r = reinterpret_cast<const uint4 *>(v);
+        uint4 *dst = reinterpret_cast<uint4 *>(out + base);
+#pragma unroll
+        for (int i = 0; i < 8 / kVec; i++) dst[i] = r[i];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (base + k < n) out[base + k] = v[k];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scan_totals_kernel(const T *__restrict__ in, long long n, T *totals)
+{
+    __shared__ T s_wave[4];
+    const long long base = (long long)blockIdx.x * kScanPerBlock + threadIdx.x * 8;
+    T v[8], sum = 0;
+    load8(in, base, n, v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += v[k];
+    const T incl = block_scan_incl(sum, s_wave);
+    if (threadIdx.x == 255) totals[blockIdx.x] = incl;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scan_top_kernel(T *totals, int nb)   // totals -> exclusive prefixes, in place
+{
+    __shared__ T s_wave[4];
+    __shared__ T s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const T v = b < nb ? totals[b] : T(0);
+        const T incl = block_scan_incl(v, s_wave) + s_carry;
+        if (b < nb) totals[b] = incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = incl;
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scan_apply_kernel(T *data /* in place, inclusive */, long long n, const T *__restrict__ totals)
+{
+    __shared__ T s_wave[4];
+    const long long base = (long long)blockIdx.x * kScanPerBlock + threadIdx.x * 8;
+    T v[8], sum = 0;
+    load8(data, base, n, v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += v[k];
+    T run = block_scan_incl(sum, s_wave) - sum + totals[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        run += v[k];
+        v[k] = run;
+    }
+    store8(data, base, n, v);
+}
+
+// the first index in [lo, hi] whose value reaches `need` (values non-decreasing, get(hi) >= need), by the whole wave
+template <class Get>
+__device__ __forceinline__ int wave_first(int lo, int hi, int need, Get get)
+{
+    const int lane = threadIdx.x & 63;
+    while (hi - lo >= 64) {
+        const long long span = (long long)hi - lo;
+        const int probe = lo + (int)(span * (lane + 1) / 65);          // 64 interior probes
+        const unsigned long long m = __ballot(get(probe) >= need);
+        if (m == 0) {
+            lo = lo + (int)(span * 64 / 65) + 1;
+        } else {
+            const int first = __ffsll((long long)m) - 1;
+            const int new_hi = lo + (int)(span * (first + 1) / 65);
+            lo = first == 0 ? lo : lo + (int)(span * first / 65) + 1;
+            hi = new_hi;
+        }
+    }
+    const unsigned long long m = __ballot(get(min(lo + lane, hi)) >= need);
+    return lo + (__ffsll((long long)m) - 1);
+}
+
+constexpr int kLinkChunksLds = 1024;      // chunk starts a workgroup keeps in LDS
+constexpr int kLinkTotalsLds = 12288;     // block totals the chunk search keeps in LDS (>= 1024 chunks' worth of triangles / 2048)
+
+// one wave: the chunk ends, one search per chunk (TransferServer.cs:239-260 with its counters in closed form)
+__global__ __launch_bounds__(64) void link_chunks_kernel(const unsigned long long *__restrict__ P /* inclusive prefix of pack[], nT entries */,
+                                                         const unsigned long long *__restrict__ totals /* exclusive, per 2048 triangles */, int nT,
+                                                         int max_chunks, int *chunk_start /* [max_chunks + 1] */, int *chunk_vbase, int *v_chunks,
+                                                         int *t_chunks, LinkState *st)
+{
+    __shared__ int s_tot[kLinkTotalsLds];
+    const int lane = threadIdx.x;
+    if (st->bad | st->fallback) return;
+    const int nb = (nT + kScanPerBlock - 1) / kScanPerBlock;
+    for (int b = lane; b < nb; b += 64) s_tot[b] = (int)(unsigned)totals[b];                 // PF before block b
+    __syncthreads();
+    auto PF = [&](int t) { return (int)(unsigned)P[t]; };
+    int s = 0, c = 0, vbase = 0, tstart = 0;
+    const int pf_last = PF(nT - 1);
+    while (s < nT && c < max_chunks) {
+        const int ended = s > 0 ? (int)(P[s - 1] >> 32) : 0;           // vertices whose last use lies before the chunk
+        const int need = kChunkLimit + ended;                          // the chunk closes at the first e with PF[e] >= need ...
+        const int lo = s + (kChunkLimit + 2) / 3 - 1;                  // ... which is never before this triangle
+        if (lo > nT - 1 || pf_last < need) {                           // the mesh ends first (:256-260)
+            const int vcount = pf_last - ended;
+            if (lane == 0) {
+                chunk_start[c] = s;
+                chunk_vbase[c] = vbase;
+                if (vcount != 0) {
+                    v_chunks[c] = vcount;
+                    t_chunks[c] = (3 * nT - tstart) / 3;
+                }
+            }
+            if (vcount != 0) { c++; vbase += vcount; }
+            s = nT;
+            break;
+        }
+        // the block of 2048 triangles in which PF reaches `need`: the last one whose prefix is still short of it
+        int b;
+        {
+            const int first_not = s_tot[nb - 1] < need ? nb : wave_first(0, nb - 1, need, [&](int i) { return s_tot[i]; });
+            b = first_not - 1;                                         // s_tot[0] = 0 < need: b >= 0
+        }
+        const int e_any = wave_first(b * kScanPerBlock, min(b * kScanPerBlock + kScanPerBlock - 1, nT - 1), need, PF);
+        const int e = max(e_any, lo);
+        const int vcount = PF(e) - ended;
+        const int t = 3 * e + 2;
+        if (lane == 0) {
+            chunk_start[c] = s;
+            chunk_vbase[c] = vbase;
+            v_chunks[c] = vcount;
+            t_chunks[c] = (t - tstart) / 3;
+        }
+        tstart = t;                                                    // sic (:244)
+        vbase += vcount;
+        c++;
+        s = e + 1;
+    }
+    if (lane == 0) {
+        chunk_start[c] = nT;
+        if (s < nT) st->fallback = 1;                                  // more chunks than the tables hold
+        st->n_chunks = c;
+        st->n_send = vbase;
+    }
+}
+
+__device__ __forceinline__ int chunk_of(const int *s_start, int n_chunks, int t)
+{
+    int lo = 0, hi = n_chunks - 1;                                     // last chunk with start <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_start[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// which of a thread's eight positions open a vertex in their chunk (s_start[n_chunks] = nT)
+__device__ __forceinline__ void opening_flags(const unsigned *prev, long long base, int n_pos, const int *s_start, int nc, int (&flag)[8])
+{
+    unsigned code[8];
+    load8(prev, base, (long long)n_pos, code);
+    int c = base < n_pos ? chunk_of(s_start, nc, (int)(base / 3)) : 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int pos = (int)base + k;
+        if (pos < n_pos && pos / 3 >= s_start[c + 1]) c++;
+        flag[k] = pos < n_pos && link_prev_of(code[k]) < 3 * s_start[c];
+    }
+}
+
+__device__ __forceinline__ bool load_chunk_starts(int *s_start, const int *chunk_start, const LinkState *st, int &nc)
+{
+    if (st->bad | st->fallback) return false;
+    nc = st->n_chunks;
+    for (int i = threadIdx.x; i <= nc && i <= kLinkChunksLds; i += 256) s_start[i] = chunk_start[i];
+    __syncthreads();
+    return true;
+}
+
+__global__ __launch_bounds__(256) void rank_totals_kernel(const unsigned *__restrict__ prev, int n_pos, const int *__restrict__ chunk_start,
+                                                          const LinkState *st, int *totals)
+{
+    __shared__ int s_start[kLinkChunksLds + 1];
+    __shared__ int s_wave[4];
+    int nc;
+    if (!load_chunk_starts(s_start, chunk_start, st, nc)) return;
+    const long long base = (long long)blockIdx.x * kScanPerBlock + threadIdx.x * 8;
+    int flag[8], sum = 0;
+    opening_flags(prev, base, n_pos, s_start, nc, flag);
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += flag[k];
+    const int incl = block_scan_incl(sum, s_wave);
+    if (threadIdx.x == 255) totals[blockIdx.x] = incl;
+}
+
+// rank[pos] = opening positions before pos (exclusive prefix over the whole mesh)
+__global__ __launch_bounds__(256) void rank_apply_kernel(const unsigned *__restrict__ prev, int n_pos, const int *__restrict__ chunk_start,
+                                                         const LinkState *st, const int *__restrict__ totals, int *__restrict__ rank)
+{
+    __shared__ int s_start[kLinkChunksLds + 1];
+    __shared__ int s_wave[4];
+    int nc;
+    if (!load_chunk_starts(s_start, chunk_start, st, nc)) return;
+    const long long base = (long long)blockIdx.x * kScanPerBlock + threadIdx.x * 8;
+    int flag[8], sum = 0;
+    opening_flags(prev, base, n_pos, s_start, nc, flag);
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += flag[k];
+    int run = block_scan_incl(sum, s_wave) - sum + totals[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int f = flag[k];
+        flag[k] = run;
+        run += f;
+    }
+    store8(rank, base, (long long)n_pos, flag);
+}
+
+__global__ __launch_bounds__(256) void link_emit_kernel(const int *__restrict__ tri, const unsigned *__restrict__ prev, int n_pos,
+                                                        const uint4 *__restrict__ verts, const int *__restrict__ chunk_start,
+                                                        const int *__restrict__ chunk_vbase, const LinkState *st,
+                                                        const int *__restrict__ rank, uint4 *__restrict__ new_v, int *__restrict__ new_tri)
+{
+    __shared__ int s_start[kLinkChunksLds + 1];
+    int nc;
+    if (!load_chunk_starts(s_start, chunk_start, st, nc)) return;
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= n_pos) return;
+    const int c = chunk_of(s_start, nc, pos / 3);
+    const int p0 = 3 * s_start[c];
+    const int r0 = rank[p0];
+    int q = pos;
+    for (int hop = 0; hop < kMaxUses; hop++) {                              // the position that opened this vertex in the chunk
+        const int before = link_prev_of(prev[q]);
+        if (before < p0) break;
+        q = before;
+    }
+    const int li = rank[q] - r0;
+    new_tri[pos] = li;                                                       // verticesMap[val] / verticesInCurrentChunk (:231-241)
+    if (q == pos) new_v[chunk_vbase[c] + li] = verts[tri[pos]];              // newVertices[currentVertex] = lVertices[val] (:234)
+}
+
 // ---- byte-stream stores -------------------------------------------------------------------------------------------------------
 // Writes nbytes composed in LDS (dword 0 = stream byte 0; one readable dword past the end) to an arbitrarily aligned
 // destination: single bytes up to the first aligned dword, then aligned dwords rebuilt from two LDS words with
@@ -392,11 +772,17 @@ struct LsnTransfer {
     int device = 0;
     int max_v = 0, max_t = 0;
     lsn::DevBuf tag, lidx, new_v, new_tri, bsum, boff, v_chunks, t_chunks, state;
+    lsn::DevBuf l_cnt, l_uses, l_prev, l_pack, l_totals, l_rank, l_start, l_vbase, l_state;   // the link path
     ChunkState *h_state = nullptr;      // pinned
+    LinkState *h_link = nullptr;        // pinned
+    int last_path = 0;                  // 0: vertices only, 1: link path, 2: window walk
     int max_chunks = 0;
     int last_chunks = 0, last_send = 0;
     std::mutex mu;
-    ~LsnTransfer() { if (h_state) (void)hipHostFree(h_state); }
+    ~LsnTransfer() {
+        if (h_state) (void)hipHostFree(h_state);
+        if (h_link) (void)hipHostFree(h_link);
+    }
 };
 
 extern "C" {
@@ -419,7 +805,15 @@ LsnTransfer *lsnTransferCreate(int device, int max_vertices, int max_triangles)
     const size_t nv = (size_t)(max_vertices > 0 ? max_vertices : 1), nt3 = (size_t)(max_triangles > 0 ? 3ll * max_triangles : 1);
     if (t->tag.reserve(nv * 8) || t->lidx.reserve(nv * 4) || t->new_v.reserve(nt3 * 16) || t->new_tri.reserve(nt3 * 4) ||
         t->bsum.reserve(kWindowBlocks * 4) || t->boff.reserve(kWindowBlocks * 4) || t->v_chunks.reserve((size_t)t->max_chunks * 4) ||
-        t->t_chunks.reserve((size_t)t->max_chunks * 4) || t->state.reserve(sizeof(ChunkState))) {
+        t->t_chunks.reserve((size_t)t->max_chunks * 4) || t->state.reserve(sizeof(ChunkState)) ||
+        t->l_cnt.reserve(nv * 4) || t->l_uses.reserve(nv * 4 * kMaxUses) || t->l_prev.reserve(nt3 * 4 + 32) || t->l_pack.reserve((nt3 / 3 + 8) * 8) ||
+        t->l_totals.reserve((nt3 / kScanPerBlock + 2) * 8) || t->l_rank.reserve(nt3 * 4 + 32) || t->l_start.reserve(((size_t)t->max_chunks + 1) * 4) ||
+        t->l_vbase.reserve(((size_t)t->max_chunks + 1) * 4) || t->l_state.reserve(sizeof(LinkState))) {
+        delete t;
+        return nullptr;
+    }
+    if (hipHostMalloc(reinterpret_cast<void **>(&t->h_link), sizeof(LinkState), hipHostMallocDefault) != hipSuccess) {
+        lsn::set_error("lsnTransferCreate: hipHostMalloc failed");
         delete t;
         return nullptr;
     }
@@ -436,6 +830,13 @@ void lsnTransferDestroy(LsnTransfer *t)
     if (!t) return;
     (void)hipSetDevice(t->device);
     delete t;
+}
+
+int lsnTransferLastPath(LsnTransfer *t)
+{
+    if (!t) return -1;
+    std::lock_guard<std::mutex> guard(t->mu);
+    return t->last_path;
 }
 
 long long lsnTransferFrameBound(int n_vertices, int n_triangles)
@@ -463,7 +864,54 @@ long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices
     const uint4 *src_v = static_cast<const uint4 *>(d_vertices);
     const int *src_t = d_triangles;
     int n_send = n_vertices, n_chunks = 0, host_chunks = 1;
-    if (n_triangles > 0) {
+    bool linked = false;
+    static const bool no_links = getenv("LSN_TRANSFER_WINDOW_WALK") != nullptr;       // ablation: the chunk-by-chunk walk only
+    if (n_triangles > 0 && !no_links && 3ll * n_triangles / kChunkLimit + 2 <= kLinkChunksLds &&
+        (n_triangles + kScanPerBlock - 1) / kScanPerBlock <= kLinkTotalsLds && t->max_chunks <= kLinkChunksLds) {
+        const int n_pos = 3 * n_triangles;
+        LinkState *st = t->l_state.as<LinkState>();
+        int *cnt = t->l_cnt.as<int>(), *rank = t->l_rank.as<int>();
+        unsigned *prev = t->l_prev.as<unsigned>();
+        auto *pack = t->l_pack.as<unsigned long long>();
+        auto *totals64 = t->l_totals.as<unsigned long long>();
+        int *totals32 = t->l_totals.as<int>();
+        LSN_HIP(hipMemsetAsync(st, 0, sizeof(LinkState), s));
+        LSN_HIP(hipMemsetAsync(cnt, 0, (size_t)n_vertices * 4, s));
+        link_uses_kernel<<<(n_pos + 255) / 256, 256, 0, s>>>(src_t, n_pos, n_vertices, cnt, t->l_uses.as<int>(), st);
+        link_prev_kernel<<<(n_vertices + 255) / 256, 256, 0, s>>>(cnt, t->l_uses.as<int>(), n_vertices, prev, st);
+        link_pack_kernel<<<(n_triangles + 255) / 256, 256, 0, s>>>(prev, n_triangles, pack, st);
+        const int pb = (n_triangles + kScanPerBlock - 1) / kScanPerBlock;
+        scan_totals_kernel<unsigned long long><<<pb, 256, 0, s>>>(pack, n_triangles, totals64);
+        scan_top_kernel<unsigned long long><<<1, 256, 0, s>>>(totals64, pb);
+        scan_apply_kernel<unsigned long long><<<pb, 256, 0, s>>>(pack, n_triangles, totals64);
+        link_chunks_kernel<<<1, 64, 0, s>>>(pack, totals64, n_triangles, t->max_chunks, t->l_start.as<int>(), t->l_vbase.as<int>(),
+                                            t->v_chunks.as<int>(), t->t_chunks.as<int>(), st);
+        const int rb = (n_pos + kScanPerBlock - 1) / kScanPerBlock;
+        rank_totals_kernel<<<rb, 256, 0, s>>>(prev, n_pos, t->l_start.as<int>(), st, totals32);
+        scan_top_kernel<int><<<1, 256, 0, s>>>(totals32, rb);
+        rank_apply_kernel<<<rb, 256, 0, s>>>(prev, n_pos, t->l_start.as<int>(), st, totals32, rank);
+        link_emit_kernel<<<(n_pos + 255) / 256, 256, 0, s>>>(src_t, prev, n_pos, src_v, t->l_start.as<int>(), t->l_vbase.as<int>(), st, rank,
+                                                             t->new_v.as<uint4>(), t->new_tri.as<int>());
+        LSN_HIP(hipGetLastError());
+        LSN_HIP(hipMemcpyAsync(t->h_link, st, sizeof(LinkState), hipMemcpyDeviceToHost, s));
+        LSN_HIP(hipStreamSynchronize(s));
+        if (t->h_link->bad) {
+            lsn::set_error("lsnTransferPack: a triangle index lies outside [0, %d)", n_vertices);
+            return -1;
+        }
+        if (!t->h_link->fallback) {
+            linked = true;
+            host_chunks = 0;
+            n_send = t->h_link->n_send;
+            n_chunks = t->h_link->n_chunks;
+            src_v = t->new_v.as<uint4>();
+            src_t = t->new_tri.as<int>();
+            t->last_path = 1;
+        }
+    }
+    if (linked) {
+    } else if (n_triangles > 0) {
+        t->last_path = 2;
         host_chunks = 0;
         ChunkState init{};
         init.p_first = init.p_last = -1;
@@ -499,6 +947,7 @@ long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices
         src_v = t->new_v.as<uint4>();
         src_t = t->new_tri.as<int>();
     } else {
+        t->last_path = 0;
         n_chunks = (n_vertices + kChunkLimit - 1) / kChunkLimit;          // formVerticesChunks (:177-201)
     }
     const long long need = 12 + 8ll * n_chunks + 15ll * n_send + 12ll * n_triangles;

@@ -28,7 +28,7 @@ EXPORTS = [
     "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
     "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardPrepare", "lsnShardConnect", "lsnShardRcclPath", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
-    "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnPlyBinaryBytes", "lsnPlyPack",
+    "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnTransferLastPath", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
     "lsnZstdAvailable", "lsnFrameParseHeader", "lsnFrameDecode", "lsnFrameEncode", "lsnRecordingNext", "lsnRecordingAppend",
 ]
@@ -196,6 +196,8 @@ def lib():
     L.lsnTransferCreate.argtypes = [C.c_int, C.c_int, C.c_int]
     L.lsnTransferDestroy.restype = None
     L.lsnTransferDestroy.argtypes = [vp]
+    L.lsnTransferLastPath.restype = C.c_int
+    L.lsnTransferLastPath.argtypes = [C.c_void_p]
     L.lsnTransferFrameBound.restype = ll
     L.lsnTransferFrameBound.argtypes = [C.c_int, C.c_int]
     L.lsnTransferPack.restype = ll
@@ -648,6 +650,10 @@ class TransferPacker:
         if n < 0:
             raise NativeUtilsError(f"lsnTransferPack failed: {last_error()}")
         return int(n)
+
+    def last_path(self):
+        """0 vertices only, 1 all chunks from one prefix sum, 2 chunk after chunk (lsnTransferLastPath)."""
+        return int(lib().lsnTransferLastPath(self.h))
 
     def close(self):
         if getattr(self, "h", None):

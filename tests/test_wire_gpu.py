@@ -33,6 +33,7 @@ def _pack(v, tri, packer=None):
     p = packer or native.TransferPacker(0, max(len(v), 1), max(nt, 1))
     n = p.pack(dv.data_ptr(), len(v), 0 if dt is None else dt.data_ptr(), nt, out.data_ptr(), cap)
     assert (out[n:] == 0).all()                                 # nothing written past the stream
+    _pack.last_path = p.last_path()
     return out[:n].cpu().numpy().tobytes()
 
 
@@ -84,8 +85,51 @@ def test_chunk_that_spans_several_windows_and_reuse(gpu, orc):
     v, grid = _grid(rng, 600, 500)
     few = rng.integers(0, 1500, size=(450_000, 3)).astype(np.int32)
     packer = native.TransferPacker(0, len(v), len(few) + len(grid))
-    for tri in (few, np.concatenate([few, grid]), np.concatenate([grid[:150_000], few[:250_000], grid[150_000:]]), grid[:10]):
+    for tri, path in ((few, 2), (np.concatenate([few, grid]), 2), (np.concatenate([grid[:150_000], few[:250_000], grid[150_000:]]), 2), (grid[:10], 1)):
         assert _pack(v, tri, packer) == orc.transfer_frame(v, tri)
+        assert _pack.last_path == path
+
+
+def test_which_path_forms_the_chunks(gpu, orc):
+    """Grid meshes take the all-chunks-at-once path (1); a vertex used more than 16 times or two uses of one vertex a chunk's worth of
+    index positions apart take the chunk-after-chunk walk (2); both give the reference's bytes, at the limits of either condition too."""
+    rng = np.random.default_rng(5)
+    v, grid = _grid(rng, 700, 420)
+    none = np.zeros((0, 3), np.int32)
+    assert _pack(v, none) == orc.transfer_frame(v, none) and _pack.last_path == 0
+    assert _pack(v, grid) == orc.transfer_frame(v, grid) and _pack.last_path == 1
+    hub = int(grid[1000, 0])
+    uses = int((grid == hub).sum())
+    assert uses <= 6
+    far = grid[grid.min(1) > hub + 3000][:40]
+
+    def fan(extra):                                             # `extra` more triangles on the hub vertex, right behind its own
+        t = far[:extra].copy()
+        t[:, 0] = hub
+        return np.concatenate([grid[:1010], t, grid[1010:]])
+
+    for extra, path in ((16 - uses, 1), (17 - uses, 2)):
+        tri = fan(extra)
+        assert int((tri == hub).sum()) == 16 + (path == 2)
+        assert _pack(v, tri) == orc.transfer_frame(v, tri) and _pack.last_path == path
+    # a link of exactly 64996 / 64997 index positions: vertex 0's last use in the grid, then once more that much later
+    last = int(np.flatnonzero((grid == 0).ravel()).max())
+    for gap, path in ((64996, 1), (64997, 2)):
+        pos = last + gap
+        tri = grid.copy()
+        tri.reshape(-1)[pos] = 0
+        assert _pack(v, tri) == orc.transfer_frame(v, tri) and _pack.last_path == path
+    # degenerate triangles (one vertex three times), and a mesh that is one short of / exactly at / one past the first chunk end
+    tri = grid.copy()
+    tri[5000:5050] = tri[5000:5050, :1]
+    assert _pack(v, tri) == orc.transfer_frame(v, tri) and _pack.last_path == 1
+    want = orc.transfer_frame(v, grid)
+    first = int(np.frombuffer(want, "<i4", 4)[3])
+    assert first >= 64997
+    n_chunks = int(np.frombuffer(want, "<i4", 3)[2])
+    t0 = int(np.frombuffer(want, "<i4", 4 + 2 * n_chunks)[3 + n_chunks]) + 1     # triangles of the first chunk (its count is one short, :244)
+    for nt in (t0 - 1, t0, t0 + 1, 21665, 21666):
+        assert _pack(v, grid[:nt]) == orc.transfer_frame(v, grid[:nt]) and _pack.last_path == 1, nt
 
 
 def test_fused_mesh_of_eight_sensors(gpu, orc):
@@ -95,6 +139,7 @@ def test_fused_mesh_of_eight_sensors(gpu, orc):
     assert len(tri) > 1_000_000
     got, want = _pack(v, tri), orc.transfer_frame(v, tri)
     assert len(got) == len(want) and got == want
+    assert _pack.last_path == 1
     assert int(np.frombuffer(got, "<i4", 3)[2]) > 10
     assert _ply(v, tri, 2) == orc.ply_binary(v, tri)
 
