@@ -257,15 +257,59 @@ struct LinkState {
 
 __device__ __forceinline__ int link_prev_of(unsigned code) { return (int)(code & ~kLastUse) - 1; }
 
-__global__ __launch_bounds__(256) void link_uses_kernel(const int *__restrict__ tri, int n_pos, int nV, int *cnt, int *uses, LinkState *st)
+// uses[v][k] = the index positions that use vertex v, in no particular order.  A workgroup takes 12288 consecutive positions (4096
+// triangles, a few rows of a grid mesh), counts the vertices within 8192 ids of its smallest one in LDS and reserves each vertex's slots in
+// the global row with ONE atomic per vertex it touches; ids outside the window take one atomic per position.  (Device-scope atomics execute
+// at the memory side: one returning atomic per position costs 56 us for a tick's mesh, this 23 us, of which the scattered stores are most.)
+constexpr int kUsesThreads = 1024, kUsesPer = 12, kUsesWindow = 8192;
+
+__global__ __launch_bounds__(kUsesThreads) void link_uses_kernel(const int *__restrict__ tri, int n_pos, int nV, int *cnt, int *uses, LinkState *st)
 {
-    const int pos = blockIdx.x * 256 + threadIdx.x;
-    if (pos >= n_pos) return;
-    const int val = tri[pos];
-    if ((unsigned)val >= (unsigned)nV) { atomicOr(&st->bad, 1); return; }
-    const int k = atomicAdd(&cnt[val], 1);
-    if (k < kMaxUses) uses[(size_t)val * kMaxUses + k] = pos;
-    else atomicOr(&st->fallback, 1);
+    __shared__ int s_cnt[kUsesWindow];
+    __shared__ int s_base[kUsesWindow];
+    __shared__ int s_min[kUsesThreads / 64];
+    const int tid = threadIdx.x;
+    const long long block0 = (long long)blockIdx.x * (kUsesThreads * kUsesPer);
+    int val[kUsesPer], kl[kUsesPer];
+    int vmin = 0x7fffffff;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < kUsesPer; i++) {
+        const long long pos = block0 + i * kUsesThreads + tid;
+        val[i] = pos < n_pos ? tri[pos] : -1;
+        if (pos < n_pos && (unsigned)val[i] >= (unsigned)nV) { bad = true; val[i] = -1; }
+        if (val[i] >= 0) vmin = min(vmin, val[i]);
+    }
+    if (bad) atomicOr(&st->bad, 1);
+    for (int i = tid; i < kUsesWindow; i += kUsesThreads) s_cnt[i] = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmin = min(vmin, __shfl_xor(vmin, d, 64));
+    if ((tid & 63) == 0) s_min[tid >> 6] = vmin;
+    __syncthreads();
+    vmin = s_min[0];
+#pragma unroll
+    for (int w2 = 1; w2 < kUsesThreads / 64; w2++) vmin = min(vmin, s_min[w2]);
+#pragma unroll
+    for (int i = 0; i < kUsesPer; i++) {
+        const unsigned d = (unsigned)val[i] - (unsigned)vmin;
+        kl[i] = val[i] >= 0 && d < (unsigned)kUsesWindow ? atomicAdd(&s_cnt[d], 1) : -1;
+    }
+    __syncthreads();
+    for (int d = tid; d < kUsesWindow; d += kUsesThreads) {
+        const int n = s_cnt[d];
+        if (n) s_base[d] = atomicAdd(&cnt[vmin + d], n);
+    }
+    __syncthreads();
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < kUsesPer; i++) {
+        if (val[i] < 0) continue;
+        const long long pos = block0 + i * kUsesThreads + tid;
+        const int k = kl[i] >= 0 ? s_base[val[i] - vmin] + kl[i] : atomicAdd(&cnt[val[i]], 1);
+        if (k < kMaxUses) uses[(size_t)val[i] * kMaxUses + k] = (int)pos;
+        else over = true;
+    }
+    if (over) atomicOr(&st->fallback, 1);
 }
 
 // the uses of one vertex, each against all: the previous use = the largest smaller one (no sort), the last use = none larger
@@ -393,19 +437,29 @@ __global__ __launch_bounds__(256) void scan_totals_kernel(const T *__restrict__ 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void scan_top_kernel(T *totals, int nb)   // totals -> exclusive prefixes, in place
+__global__ __launch_bounds__(1024) void scan_top_kernel(T *totals, int nb)   // totals -> exclusive prefixes, in place
 {
-    __shared__ T s_wave[4];
+    __shared__ T s_wave[16];
     __shared__ T s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (int b0 = 0; b0 < nb; b0 += 256) {
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
         const int b = b0 + threadIdx.x;
         const T v = b < nb ? totals[b] : T(0);
-        const T incl = block_scan_incl(v, s_wave) + s_carry;
-        if (b < nb) totals[b] = incl - v;
+        T x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const T y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wave[wave] = x;
         __syncthreads();
-        if (threadIdx.x == 255) s_carry = incl;
+        T add = s_carry;
+        for (int w2 = 0; w2 < wave; w2++) add += s_wave[w2];
+        if (b < nb) totals[b] = x + add - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = x + add;
         __syncthreads();
     }
 }
@@ -428,26 +482,28 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(T *data /* in place, in
     store8(data, base, n, v);
 }
 
-// the first index in [lo, hi] whose value reaches `need` (values non-decreasing, get(hi) >= need), by the whole wave
-template <class Get>
-__device__ __forceinline__ int wave_first(int lo, int hi, int need, Get get)
+// the first index in [lo, hi] whose key reaches `need` (keys non-decreasing, key(get(hi)) >= need), by the whole wave; *found = get(index)
+template <class V, class Get, class Key>
+__device__ __forceinline__ int wave_first(int lo, int hi, int need, Get get, Key key, V *found)
 {
     const int lane = threadIdx.x & 63;
     while (hi - lo >= 64) {
-        const long long span = (long long)hi - lo;
-        const int probe = lo + (int)(span * (lane + 1) / 65);          // 64 interior probes
-        const unsigned long long m = __ballot(get(probe) >= need);
+        const int step = (hi - lo + 64) / 65;                          // probes lo + step, lo + 2 step, ... clipped to hi
+        const int probe = min(lo + (lane + 1) * step, hi);             // (no overflow: callers search ranges far below 2^31 / 64)
+        const unsigned long long m = __ballot(key(get(probe)) >= need);
         if (m == 0) {
-            lo = lo + (int)(span * 64 / 65) + 1;
+            lo = lo + 64 * step + 1;
         } else {
             const int first = __ffsll((long long)m) - 1;
-            const int new_hi = lo + (int)(span * (first + 1) / 65);
-            lo = first == 0 ? lo : lo + (int)(span * first / 65) + 1;
-            hi = new_hi;
+            hi = min(lo + (first + 1) * step, hi);
+            lo = first == 0 ? lo : lo + first * step + 1;
         }
     }
-    const unsigned long long m = __ballot(get(min(lo + lane, hi)) >= need);
-    return lo + (__ffsll((long long)m) - 1);
+    const V v = get(min(lo + lane, hi));
+    const unsigned long long m = __ballot(key(v) >= need);
+    const int first = __ffsll((long long)m) - 1;
+    *found = __shfl(v, first, 64);
+    return lo + first;
 }
 
 constexpr int kLinkChunksLds = 1024;      // chunk starts a workgroup keeps in LDS
@@ -465,11 +521,11 @@ __global__ __launch_bounds__(64) void link_chunks_kernel(const unsigned long lon
     const int nb = (nT + kScanPerBlock - 1) / kScanPerBlock;
     for (int b = lane; b < nb; b += 64) s_tot[b] = (int)(unsigned)totals[b];                 // PF before block b
     __syncthreads();
-    auto PF = [&](int t) { return (int)(unsigned)P[t]; };
+    auto low = [](unsigned long long v) { return (int)(unsigned)v; };
     int s = 0, c = 0, vbase = 0, tstart = 0;
-    const int pf_last = PF(nT - 1);
+    int ended = 0;                                                     // vertices whose last use lies before the chunk: PH[s - 1]
+    const int pf_last = low(P[nT - 1]);
     while (s < nT && c < max_chunks) {
-        const int ended = s > 0 ? (int)(P[s - 1] >> 32) : 0;           // vertices whose last use lies before the chunk
         const int need = kChunkLimit + ended;                          // the chunk closes at the first e with PF[e] >= need ...
         const int lo = s + (kChunkLimit + 2) / 3 - 1;                  // ... which is never before this triangle
         if (lo > nT - 1 || pf_last < need) {                           // the mesh ends first (:256-260)
@@ -487,14 +543,16 @@ __global__ __launch_bounds__(64) void link_chunks_kernel(const unsigned long lon
             break;
         }
         // the block of 2048 triangles in which PF reaches `need`: the last one whose prefix is still short of it
-        int b;
-        {
-            const int first_not = s_tot[nb - 1] < need ? nb : wave_first(0, nb - 1, need, [&](int i) { return s_tot[i]; });
-            b = first_not - 1;                                         // s_tot[0] = 0 < need: b >= 0
+        int b = nb - 1, unused;
+        if (s_tot[nb - 1] >= need)                                     // s_tot[0] = 0 < need: the first block that is not short is >= 1
+            b = wave_first(0, nb - 1, need, [&](int i) { return s_tot[i]; }, [](int v) { return v; }, &unused) - 1;
+        unsigned long long at_e;
+        int e = wave_first(b * kScanPerBlock, min(b * kScanPerBlock + kScanPerBlock - 1, nT - 1), need, [&](int t) { return P[t]; }, low, &at_e);
+        if (e < lo) {                                                  // the closed form over-counts before `lo` (vertices used on both sides of a short window only); it is monotone, so then the chunk closes at `lo`
+            e = lo;
+            at_e = P[e];
         }
-        const int e_any = wave_first(b * kScanPerBlock, min(b * kScanPerBlock + kScanPerBlock - 1, nT - 1), need, PF);
-        const int e = max(e_any, lo);
-        const int vcount = PF(e) - ended;
+        const int vcount = low(at_e) - ended;
         const int t = 3 * e + 2;
         if (lane == 0) {
             chunk_start[c] = s;
@@ -504,6 +562,7 @@ __global__ __launch_bounds__(64) void link_chunks_kernel(const unsigned long lon
         }
         tstart = t;                                                    // sic (:244)
         vbase += vcount;
+        ended = (int)(at_e >> 32);                                     // PH[e]: what has ended before the next chunk
         c++;
         s = e + 1;
     }
@@ -877,18 +936,19 @@ long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices
         int *totals32 = t->l_totals.as<int>();
         LSN_HIP(hipMemsetAsync(st, 0, sizeof(LinkState), s));
         LSN_HIP(hipMemsetAsync(cnt, 0, (size_t)n_vertices * 4, s));
-        link_uses_kernel<<<(n_pos + 255) / 256, 256, 0, s>>>(src_t, n_pos, n_vertices, cnt, t->l_uses.as<int>(), st);
+        link_uses_kernel<<<(n_pos + kUsesThreads * kUsesPer - 1) / (kUsesThreads * kUsesPer), kUsesThreads, 0, s>>>(src_t, n_pos, n_vertices, cnt,
+                                                                                                                 t->l_uses.as<int>(), st);
         link_prev_kernel<<<(n_vertices + 255) / 256, 256, 0, s>>>(cnt, t->l_uses.as<int>(), n_vertices, prev, st);
         link_pack_kernel<<<(n_triangles + 255) / 256, 256, 0, s>>>(prev, n_triangles, pack, st);
         const int pb = (n_triangles + kScanPerBlock - 1) / kScanPerBlock;
         scan_totals_kernel<unsigned long long><<<pb, 256, 0, s>>>(pack, n_triangles, totals64);
-        scan_top_kernel<unsigned long long><<<1, 256, 0, s>>>(totals64, pb);
+        scan_top_kernel<unsigned long long><<<1, 1024, 0, s>>>(totals64, pb);
         scan_apply_kernel<unsigned long long><<<pb, 256, 0, s>>>(pack, n_triangles, totals64);
         link_chunks_kernel<<<1, 64, 0, s>>>(pack, totals64, n_triangles, t->max_chunks, t->l_start.as<int>(), t->l_vbase.as<int>(),
                                             t->v_chunks.as<int>(), t->t_chunks.as<int>(), st);
         const int rb = (n_pos + kScanPerBlock - 1) / kScanPerBlock;
         rank_totals_kernel<<<rb, 256, 0, s>>>(prev, n_pos, t->l_start.as<int>(), st, totals32);
-        scan_top_kernel<int><<<1, 256, 0, s>>>(totals32, rb);
+        scan_top_kernel<int><<<1, 1024, 0, s>>>(totals32, rb);
         rank_apply_kernel<<<rb, 256, 0, s>>>(prev, n_pos, t->l_start.as<int>(), st, totals32, rank);
         link_emit_kernel<<<(n_pos + 255) / 256, 256, 0, s>>>(src_t, prev, n_pos, src_v, t->l_start.as<int>(), t->l_vbase.as<int>(), st, rank,
                                                              t->new_v.as<uint4>(), t->new_tri.as<int>());
