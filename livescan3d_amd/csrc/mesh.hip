@@ -24,11 +24,18 @@ struct TriArgs {
     int *tile_counts;    // [n_ticks * tiles_per_tick] counts, then exclusive prefixes (scan_kernel)
     unsigned int *codes; // [n_ticks * tiles_per_tick * 256] per-lane 4-bit-per-pixel triangle codes: count pass -> write pass
     int tiles_per_tick;
+    int win;                    // triangles staged per LDS round of the write pass
     long long tick_pix_stride;  // pixels per tick
     long long tick_tri_stride;  // triangles per tick (capacity)
 };
 
-constexpr int kTriWin = 1536;  // triangles staged per LDS round (18 KB)
+constexpr int kTriWinDefault = 1536;  // triangles staged per LDS round (18 KB); a multiple of 16 (LSN_TRI_WINDOW: 256 .. 4096)
+// The staged window is padded by one int per 16 triangles: a lane of 8 pixels on a closed surface holds 16 triangles, so the k-th
+// triangles of the lanes of a wave lie 48 ints apart -- 4 banks for 64 lanes (SQ_LDS_BANK_CONFLICT: 77 % of the LDS cycles of the
+// write pass, which made it LDS-bound); 49 ints apart they take 64 different banks.
+__host__ __device__ constexpr int stage_ints(int win) { return 3 * win + win / 16 + 8; }
+__device__ __forceinline__ int stage_slot(int lead, int r) { return lead + 3 * r + (r >> 4); }                 // where triangle r of the window starts
+__device__ __forceinline__ int stage_phys(int lead, int i) { return i + (int)((unsigned int)(i - lead) / 48u); }  // where int i >= lead of the unpadded window lies
 
 // MeshGenerator::checkTriangleConstraints (meshGenerator.cpp:14-61) on a pixel's 4 x 4 depth window W[dy + 2][dx + 1],
 // dx in [-1, 2], dy in [-2, 1]; the three corners are compile-time offsets, so are the forward / backward probes.
@@ -150,7 +157,8 @@ __device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerL
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const TriArgs a)
 {
-    __shared__ alignas(16) int stage[MODE == 1 ? 3 * kTriWin + 4 : 1];
+    extern __shared__ int stage[];   // write pass: stage_ints(a.win) + 3 * 64 ints
+    const int kTriWin = a.win;
     __shared__ int s_wave_tot[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -200,13 +208,18 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
     if (MODE == 1) {
         // the count pass already evaluated every stencil: reload its verdicts, rebuild only the vertex indices
         code = a.codes[code_slot];
-        if (VEC && code != 0) {
+        if (VEC && in_frame && y0 >= 2 && y0 < h - 2) {   // every row that can hold a triangle (:87-90); not behind `code`: the two loads fly together
             load_groups();
 #pragma unroll
             for (int r = 0; r < 2; r++) {
+                // a pixel without a vertex gets the index of the next one: never read, its triangles are not in `code` (:133-134)
+                int run = first[r];
 #pragma unroll
-                for (int c = 0; c < kPxPerLane; c++) M[r][c] = (mask9[r] >> c) & 1u ? first[r] + __popc(mask9[r] & ((1u << c) - 1u)) : -1;
-                M[r][8] = (mask9[r] >> 8) & 1u ? first_next[r] : -1;
+                for (int c = 0; c < kPxPerLane; c++) {
+                    M[r][c] = run;
+                    run += (int)((mask9[r] >> c) & 1u);
+                }
+                M[r][8] = first_next[r];
             }
         }
     } else if (VEC) {
@@ -287,35 +300,57 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
     for (int w0 = 0; w0 < tile_tot; w0 += kTriWin) {
         int r = rank0 - w0;
         int x = x0, y = y0;
+        // a pixel emits triangles {0}, {1}, {0, 1}, {2}, {3} or {2, 3} of :101-104 (2 and 3 only when neither 0 nor 1 passed, :120):
+        // at most two, a first and a second one, each three selects -- not four predicated slots.  Lanes whose triangles lie
+        // outside this window sit the round out (ranks ascend with the lane: whole waves do).
+        if (cnt != 0 && r < kTriWin && r + cnt > 0) {
+            if (VEC) {
+                // no branches: a triangle that does not exist, or lies outside the window, goes to a slot of the lane's own behind it
+                const int nowhere = stage_ints(kTriWin) + 3 * lane;
 #pragma unroll
-        for (int k = 0; k < kPxPerLane; k++) {
-            const unsigned int m = (code >> (4 * k)) & 15u;
-            if (m) {
-                int mP, mU, mUR, mR;
-                if (VEC) {
-                    mP = M[1][k]; mU = M[0][k]; mUR = M[0][k + 1]; mR = M[1][k + 1];
-                } else {
-                    const long long p = (long long)y * w + x;
-                    mP = map[p]; mU = map[p - w]; mUR = map[p - w + 1]; mR = map[p + 1];
+                for (int k = 0; k < kPxPerLane; k++) {
+                    const unsigned int m = (code >> (4 * k)) & 15u;
+                    const int mP = M[1][k], mU = M[0][k], mUR = M[0][k + 1], mR = M[1][k + 1];
+                    const bool b0 = (m & 1u) != 0, b12 = (m & 6u) != 0, low = (m & 3u) != 0, two = (m == 3u) | (m == 12u);
+                    const int o1 = ((m != 0) & ((unsigned int)r < (unsigned int)kTriWin)) ? stage_slot(lead, r) : nowhere;
+                    stage[o1] = low ? mR : mP;                                         // 0: R,U,P  1: R,UR,U  2: P,UR,U  3: P,R,UR
+                    stage[o1 + 1] = b0 ? mU : (b12 ? mUR : mR);
+                    stage[o1 + 2] = b0 ? mP : (b12 ? mU : mUR);
+                    r += m != 0;
+                    const int o2 = (two & ((unsigned int)r < (unsigned int)kTriWin)) ? stage_slot(lead, r) : nowhere;
+                    stage[o2] = low ? mR : mP;                                         // the second one: 1 after 0, 3 after 2
+                    stage[o2 + 1] = low ? mUR : mR;
+                    stage[o2 + 2] = low ? mU : mUR;
+                    r += two;
                 }
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (m & (1u << i)) {
+                for (int k = 0; k < kPxPerLane; k++) {
+                    const unsigned int m = (code >> (4 * k)) & 15u;
+                    if (m) {
+                        const long long p = (long long)y * w + x;
+                        const int mP = map[p], mU = map[p - w], mUR = map[p - w + 1], mR = map[p + 1];
+                        const bool b0 = (m & 1u) != 0, b12 = (m & 6u) != 0, low = (m & 3u) != 0;
                         if ((unsigned int)r < (unsigned int)kTriWin) {
-                            const int i0 = i == 0 ? mR : (i == 1 ? mR : mP);
-                            const int i1 = i == 0 ? mU : (i == 1 ? mUR : (i == 2 ? mUR : mR));
-                            const int i2 = i == 0 ? mP : (i == 1 ? mU : (i == 2 ? mU : mUR));
-                            stage[lead + 3 * r] = i0;
-                            stage[lead + 3 * r + 1] = i1;
-                            stage[lead + 3 * r + 2] = i2;
+                            const int o = stage_slot(lead, r);
+                            stage[o] = low ? mR : mP;
+                            stage[o + 1] = b0 ? mU : (b12 ? mUR : mR);
+                            stage[o + 2] = b0 ? mP : (b12 ? mU : mUR);
                         }
                         r++;
+                        if (m == 3u || m == 12u) {
+                            if ((unsigned int)r < (unsigned int)kTriWin) {
+                                const int o = stage_slot(lead, r);
+                                stage[o] = low ? mR : mP;
+                                stage[o + 1] = low ? mUR : mR;
+                                stage[o + 2] = low ? mU : mUR;
+                            }
+                            r++;
+                        }
                     }
+                    x++;
+                    if (x == w) { x = 0; y++; }
                 }
-            }
-            if (!VEC) {
-                x++;
-                if (x == w) { x = 0; y++; }
             }
         }
         __syncthreads();
@@ -325,9 +360,14 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
             const int end = lead + n;                      // in ints, relative to the aligned start of the first chunk
             const int c0 = lead ? 1 : 0, c1 = end >> 2;     // chunks [c0, c1) are whole
             int4 *g16 = reinterpret_cast<int4 *>(out - lead);
-            const int4 *l16 = reinterpret_cast<const int4 *>(stage);
             for (int j = c0 + (int)threadIdx.x; j < c1; j += kThreads) {
-                const int4 v = l16[j];                      // written once, never read again by this launch sequence
+                int4 v;                                     // written once, never read again by this launch sequence
+                const unsigned int o = (unsigned int)(4 * j - lead), q = o / 48u, rem = o - 48u * q;   // one division per chunk: a pad may fall inside it
+                const int ph = 4 * j + (int)q;
+                v.x = stage[ph];
+                v.y = stage[ph + 1 + (rem + 1 >= 48u)];
+                v.z = stage[ph + 2 + (rem + 2 >= 48u)];
+                v.w = stage[ph + 3 + (rem + 3 >= 48u)];
                 __builtin_nontemporal_store(v.x, &g16[j].x);
                 __builtin_nontemporal_store(v.y, &g16[j].y);
                 __builtin_nontemporal_store(v.z, &g16[j].z);
@@ -335,8 +375,8 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
             }
             const int head = lead ? min(n, 4 - lead) : 0;   // the ragged ends: the neighbouring tiles own the rest of those chunks
             const int tail0 = max(head, 4 * c1 - lead);
-            if ((int)threadIdx.x < head) out[threadIdx.x] = stage[lead + threadIdx.x];
-            if (tail0 + (int)threadIdx.x < n) out[tail0 + threadIdx.x] = stage[lead + tail0 + threadIdx.x];
+            if ((int)threadIdx.x < head) out[threadIdx.x] = stage[stage_phys(lead, lead + threadIdx.x)];
+            if (tail0 + (int)threadIdx.x < n) out[tail0 + threadIdx.x] = stage[stage_phys(lead, lead + tail0 + threadIdx.x)];
         }
         __syncthreads();
     }
@@ -386,6 +426,9 @@ int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void 
     t.tile_counts = p->tri_counts.as<int>();
     t.codes = p->tri_codes.as<unsigned int>();
     t.tiles_per_tick = p->tiles_per_tick;
+    static const int win_env = getenv("LSN_TRI_WINDOW") ? atoi(getenv("LSN_TRI_WINDOW")) : kTriWinDefault;
+    t.win = std::min(4096, std::max(256, win_env)) & ~15;
+    const size_t stage_bytes = sizeof(int) * (size_t)(stage_ints(t.win) + 3 * 64);
     t.tick_pix_stride = p->cap;
     t.tick_tri_stride = 2 * p->cap;
     const bool vec = p->pixmap_compact && ((uintptr_t)d_depth & 15) == 0;   // the vertex pass above wrote the compact map iff it ran its wide-load form
@@ -397,8 +440,8 @@ int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void 
     if (hooks && hooks->h_tri_offsets)
         LSN_HIP(hipMemcpyAsync(hooks->h_tri_offsets, d_tri_offsets, sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1), hipMemcpyDeviceToHost, s));
     if (hooks && hooks->tri_counted) LSN_HIP(hipEventRecord(hooks->tri_counted, s));
-    if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), 0, s, t);
-    else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), 0, s, t);
+    if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
+    else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
     LSN_HIP(hipGetLastError());
     return 0;
 }
