@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
     if (MODE == 1) {
         // the count pass already evaluated every stencil: reload its verdicts, rebuild only the vertex indices
         code = a.codes[code_slot];
-        if (VEC && in_frame && y0 >= 2 && y0 < h - 2) {   // every row that can hold a triangle (:87-90); not behind `code`: the two loads fly together
+        if (VEC && code != 0) {
             load_groups();
 #pragma unroll
             for (int r = 0; r < 2; r++) {
