@@ -132,6 +132,36 @@ def test_which_path_forms_the_chunks(gpu, orc):
         assert _pack(v, grid[:nt]) == orc.transfer_frame(v, grid[:nt]) and _pack.last_path == 1, nt
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_meshes_on_either_path(gpu, orc, seed):
+    """Grid meshes disturbed at random -- indices replaced by nearby or by far-away vertices (valences up to and past 16, links up to
+    and past a chunk's worth of positions), triangles dropped, duplicated and shuffled in blocks: whichever path the packer takes, the
+    bytes are the reference's."""
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(200, 700)), int(rng.integers(150, 450))
+    v, tri = _grid(rng, w, h, drop=float(rng.uniform(0.0, 0.2)))
+    tri = tri.copy()
+    n = len(tri)
+    flat = tri.reshape(-1)
+    k = int(rng.integers(0, n // 50 + 1))                        # nearby replacements: more uses of some vertices
+    pos = rng.integers(0, flat.size, k)
+    flat[pos] = np.clip(flat[pos] + rng.integers(-3, 4, k), 0, len(v) - 1)
+    if seed % 3 == 1:                                            # a few far-away ones: long links (usually the walk)
+        pos = rng.integers(0, flat.size, 5)
+        flat[pos] = rng.integers(0, len(v), 5)
+    if seed % 4 == 2:                                            # blocks of triangles swapped: vertices first used late
+        a, b = sorted(rng.integers(0, n - 2000, 2))
+        if b - a > 2000:
+            blk = tri[a:a + 1000].copy()
+            tri[a:a + 1000] = tri[b:b + 1000]
+            tri[b:b + 1000] = blk
+    keep = rng.random(n) >= rng.uniform(0.0, 0.3)
+    tri = np.concatenate([tri[keep], tri[: int(rng.integers(0, 500))]])
+    got, want = _pack(v, tri), orc.transfer_frame(v, tri)
+    assert len(got) == len(want) and got == want, (seed, _pack.last_path)
+    assert _pack.last_path in (1, 2)
+
+
 def test_fused_mesh_of_eight_sensors(gpu, orc):
     """The real thing: the merged mesh of 8 x 512x424 sensors (about 1 M vertices, 1.7 M triangles, ~25 chunks)."""
     rig = synth.make_rig("scene", 8, 512, 424, seed=3)
