@@ -765,12 +765,20 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
                     const unsigned int hb = ~(m[1] >> 1) & 0xFFu;      // bit k: pixel x0 + k is a hole
                     holes[(hole_bit0 + (long long)y * w + x0) >> 3] = (unsigned char)hb;
                     if (y >= 1 && y < h - 1) {                         // :223-224 interior pixels only
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const int nv = __popc((m[0] >> k) & 7u) + __popc((m[1] >> k) & 5u) + __popc((m[2] >> k) & 7u);
-                            cb |= (nv >= 5 && x0 + k >= 1 && x0 + k < w - 1) ? (1u << k) : 0u;
-                        }
-                        cb &= hb;
+                        // at least five of the eight neighbours valid, for the eight pixels at once: bit k of each word below is one neighbour
+                        // of pixel x0 + k, a bit-sliced adder counts them (total = t0 + 2 v0 + 4 w0 + 8 g1)
+                        const unsigned int n0 = m[0], n1 = m[0] >> 1, n2 = m[0] >> 2, n3 = m[1], n4 = m[1] >> 2, n5 = m[2], n6 = m[2] >> 1, n7 = m[2] >> 2;
+                        const unsigned int s1 = n0 ^ n1 ^ n2, c1 = (n0 & n1) | (n2 & (n0 ^ n1));
+                        const unsigned int s2 = n5 ^ n6 ^ n7, c2 = (n5 & n6) | (n7 & (n5 ^ n6));
+                        const unsigned int s3 = n3 ^ n4, c3 = n3 & n4;
+                        const unsigned int t0 = s1 ^ s2 ^ s3, d1 = (s1 & s2) | (s3 & (s1 ^ s2));
+                        const unsigned int u0 = c1 ^ c2 ^ c3, e1 = (c1 & c2) | (c3 & (c1 ^ c2));
+                        const unsigned int v0 = u0 ^ d1, f1 = u0 & d1;
+                        const unsigned int w0 = e1 ^ f1, g1 = e1 & f1;
+                        unsigned int inside = 0xFFu;                                   // 1 <= x < w - 1
+                        if (x0 == 0) inside &= ~1u;
+                        if (x0 + 8 == w) inside &= ~0x80u;
+                        cb = (g1 | (w0 & (v0 | t0))) & hb & inside;
                     }
                 }
                 int slot = wave_reserve(s_n, __popc(cb));
