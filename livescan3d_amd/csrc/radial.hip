@@ -643,6 +643,14 @@ __device__ __forceinline__ void store_band_run(unsigned char *dst, const unsigne
     if (tail0 + (int)threadIdx.x < n) dst[tail0 + threadIdx.x] = lds[tail0 + threadIdx.x];
 }
 
+// both 16-bit halves of x replaced by min(half, 1): one v_pk_min_u16 (the compiler splits the vector form into two scalar ones)
+__device__ __forceinline__ unsigned int pk_min1(unsigned int x)
+{
+    unsigned int r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(0x00010001u));
+    return r;
+}
+
 template <bool GATHER, bool VEC>
 __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArgs a)
 {
@@ -752,15 +760,10 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
                         const unsigned short *row = s_d + li + (rr - 1) * w;
                         const uint4 c = *reinterpret_cast<const uint4 *>(row);
                         const unsigned int left = x0 > 0 ? row[-1] : 0u, right = x0 + 8 < w ? row[8] : 0u;
-                        const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
-                        unsigned int bits = left ? 1u : 0u;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            bits |= (cw[k] & 0xFFFFu) ? (2u << (2 * k)) : 0u;
-                            bits |= (cw[k] >> 16) ? (4u << (2 * k)) : 0u;
-                        }
-                        bits |= right ? (1u << 9) : 0u;
-                        m[rr] = bits;                                  // bit c: column x0 - 1 + c holds a valid depth
+                        // min(depth, 1) of two pixels at a time (packed u16), then the 0/1 halves of four dwords gathered into eight bits
+                        const unsigned int p0 = pk_min1(c.x) | (pk_min1(c.y) << 2), p1 = pk_min1(c.z) | (pk_min1(c.w) << 2);   // bits 0, 2 | 16, 18
+                        const unsigned int q0 = (p0 | (p0 >> 15)) & 0xFu, q1 = (p1 | (p1 >> 15)) & 0xFu;                        // pixels 0..3, 4..7
+                        m[rr] = (left ? 1u : 0u) | ((q0 | (q1 << 4)) << 1) | (right ? (1u << 9) : 0u);   // bit c: column x0 - 1 + c holds a valid depth
                     }
                     const unsigned int hb = ~(m[1] >> 1) & 0xFFu;      // bit k: pixel x0 + k is a hole
                     holes[(hole_bit0 + (long long)y * w + x0) >> 3] = (unsigned char)hb;
