@@ -162,6 +162,16 @@ def test_random_meshes_on_either_path(gpu, orc, seed):
     assert _pack.last_path in (1, 2)
 
 
+def test_the_stream_does_not_depend_on_the_run(gpu):
+    """The all-chunks-at-once path collects the uses of a vertex with atomics, in whatever order they land: the stream must not show it."""
+    v, tri = _grid(np.random.default_rng(77), 900, 500)
+    packer = native.TransferPacker(0, len(v), len(tri))
+    first = _pack(v, tri, packer)
+    assert _pack.last_path == 1
+    for _ in range(7):
+        assert _pack(v, tri, packer) == first
+
+
 def test_fused_mesh_of_eight_sensors(gpu, orc):
     """The real thing: the merged mesh of 8 x 512x424 sensors (about 1 M vertices, 1.7 M triangles, ~25 chunks)."""
     rig = synth.make_rig("scene", 8, 512, 424, seed=3)
