@@ -131,6 +131,12 @@ long long lsnFusionTickCapacity(const LsnFusion *plan);
 int lsnFusionSetParams(LsnFusion *plan, const float *intr_params, const float *wtransform_params,
                        const float *bounds6, void *stream);
 
+/* Host-only (no device needed): the 16 floats the kernels read for one sensor -- {cx, cy, fx, fy, t[3], R[3][3] row-major} -- from the
+ * caller's 7 intrinsics and 12 world-transform floats, exactly as lsnFusionSetParams packs them.  Exists so that the unpack order can be
+ * held against the reference's IntrinsicCameraParameters(float*) / WorldTranformation(float*) constructors
+ * (include/NativeUtils/depthprocessing.h:56-63,96-97) without a GPU. */
+int lsnPackSensorParams(const float *intr7, const float *wt12, float *out16);
+
 /* Selects how the raster-order compaction gets its global offsets: 0 = two-pass (count kernel + write kernel),
  * 1 = single launch, runs of tiles counted then re-evaluated, decoupled look-back per run, 2 = single pass, every tile
  * evaluated once, decoupled look-back per tile.  Results are identical; 0 is the fastest on MI355X. */

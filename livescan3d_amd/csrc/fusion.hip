@@ -733,6 +733,32 @@ extern "C" void lsnFusionDestroy(LsnFusion *p)
 
 extern "C" long long lsnFusionTickCapacity(const LsnFusion *p) { return p ? p->cap : 0; }
 
+// IntrinsicCameraParameters(float*) / WorldTranformation(float*), include/NativeUtils/depthprocessing.h:56-63,96-97: the caller's 7 and 12
+// floats of one sensor as the kernels read them.  The one place the unpack order is written down (tests/test_abi.py holds it against
+// the reference's own constructors through lsnPackSensorParams).
+static void pack_sensor_params(const float *ip, const float *tp, SensorParams &s)
+{
+    s.cx = ip[0]; s.cy = ip[1]; s.fx = ip[2]; s.fy = ip[3];
+    s.t0 = tp[0]; s.t1 = tp[1]; s.t2 = tp[2];
+    s.r00 = tp[3]; s.r01 = tp[4]; s.r02 = tp[5];
+    s.r10 = tp[6]; s.r11 = tp[7]; s.r12 = tp[8];
+    s.r20 = tp[9]; s.r21 = tp[10]; s.r22 = tp[11];
+}
+
+extern "C" int lsnPackSensorParams(const float *intr7, const float *wt12, float *out16)
+{
+    lsn::clear_error();
+    if (!intr7 || !wt12 || !out16) {
+        lsn::set_error("lsnPackSensorParams: null argument");
+        return -1;
+    }
+    SensorParams s;
+    pack_sensor_params(intr7, wt12, s);
+    static_assert(sizeof(SensorParams) == 16 * sizeof(float), "SensorParams is 16 floats");
+    memcpy(out16, &s, sizeof(s));
+    return 0;
+}
+
 extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *wt, const float *bounds6, void *stream)
 {
     lsn::clear_error();
@@ -750,16 +776,7 @@ extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *
             return 0;
     }
     std::vector<SensorParams> sp(p->n_maps);
-    for (int i = 0; i < p->n_maps; i++) {
-        // IntrinsicCameraParameters(float*) / WorldTranformation(float*), include/NativeUtils/depthprocessing.h:56-63,96-97
-        const float *ip = intr + 7 * i, *tp = wt + 12 * i;
-        SensorParams &s = sp[i];
-        s.cx = ip[0]; s.cy = ip[1]; s.fx = ip[2]; s.fy = ip[3];
-        s.t0 = tp[0]; s.t1 = tp[1]; s.t2 = tp[2];
-        s.r00 = tp[3]; s.r01 = tp[4]; s.r02 = tp[5];
-        s.r10 = tp[6]; s.r11 = tp[7]; s.r12 = tp[8];
-        s.r20 = tp[9]; s.r21 = tp[10]; s.r22 = tp[11];
-    }
+    for (int i = 0; i < p->n_maps; i++) pack_sensor_params(intr + 7 * i, wt + 12 * i, sp[i]);
     // pageable source: hipMemcpyAsync copies it out before returning, so the local vector may die
     LSN_HIP(hipMemcpyAsync(p->params.p, sp.data(), sizeof(SensorParams) * p->n_maps, hipMemcpyHostToDevice,
                            lsn::as_stream(stream)));

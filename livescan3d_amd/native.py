@@ -22,7 +22,7 @@ VERTEX_DTYPE = np.dtype([("R", "u1"), ("G", "u1"), ("B", "u1"), ("A", "u1"),
 EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh",
-    "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnFusionSetMode",
+    "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnPackSensorParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
     "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
@@ -105,6 +105,8 @@ def lib():
     L.lsnFusionTickCapacity.argtypes = [vp]
     L.lsnFusionSetParams.restype = C.c_int
     L.lsnFusionSetParams.argtypes = [vp, vp, vp, vp, vp]
+    L.lsnPackSensorParams.restype = C.c_int
+    L.lsnPackSensorParams.argtypes = [vp, vp, vp]
     L.lsnFusionSetMode.restype = C.c_int
     L.lsnFusionSetMode.argtypes = [vp, C.c_int]
     L.lsnFusionRunStreamed.restype = C.c_int

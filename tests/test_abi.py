@@ -27,11 +27,66 @@ def test_library_exports_every_declared_symbol():
     assert set(native.EXPORTS) == set(names)
 
 
+def _abi_fixture():
+    """tests/golden/abi_reference.json: what the reference's own header gives (generator: tests/golden/make_abi_golden.py)."""
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "abi_reference.json")))
+
+
+def _layout_here():
+    """The same 17 numbers as oracle/ref_abi_harness.cpp::ref_abi_layout, from this package's ctypes / numpy mirrors."""
+    v = native.VERTEX_DTYPE
+    p3 = np.dtype([("X", "<f4"), ("Y", "<f4"), ("Z", "<f4")])     # Point3f as native.icp passes it: n x 3 float32, C order
+    return ([v.itemsize] + [v.fields[k][1] for k in "RGBAXYZ"] +
+            [C.sizeof(native.Mesh), native.Mesh.nVertices.offset, native.Mesh.vertices.offset, native.Mesh.nTriangles.offset,
+             native.Mesh.triangles.offset] + [p3.itemsize] + [p3.fields[k][1] for k in "XYZ"])
+
+
 def test_struct_layouts_match_the_reference():
-    assert native.VERTEX_DTYPE.itemsize == 16                        # Utils.cs: SizeInBytes = 16; depthprocessing.h:29-33
-    assert [native.VERTEX_DTYPE.fields[k][1] for k in "RGBAXYZ"] == [0, 1, 2, 3, 4, 8, 12]
-    assert C.sizeof(native.Mesh) == 32                               # depthprocessing.h:42-48 on LP64
-    assert native.Mesh.vertices.offset == 8 and native.Mesh.nTriangles.offset == 16 and native.Mesh.triangles.offset == 24
+    """VertexC4ubV3f / Mesh / Point3f against sizeof / offsetof from the reference's header (depthprocessing.h:29-33,42-48, icp.h:15-18)
+    as its compiler lays them out -- the committed fixture, not literals."""
+    fx = _abi_fixture()
+    assert _layout_here() == fx["layout"]
+    assert fx["layout"][0] == 16 and fx["layout"][8] == 32     # Utils.cs: SizeInBytes = 16; Mesh 32 bytes on LP64
+
+
+def test_sensor_params_packing_matches_the_reference_constructors():
+    """lsnPackSensorParams (= what lsnFusionSetParams uploads) against IntrinsicCameraParameters(float*) and WorldTranformation(float*)
+    (depthprocessing.h:56-63,96-97) run on position-coded inputs: every float must land where the reference's members read it."""
+    fx = _abi_fixture()
+    intr = np.array(fx["intr_in"], np.float32)
+    wt = np.array(fx["world_in"], np.float32)
+    out = np.zeros(16, np.float32)
+    assert native.lib().lsnPackSensorParams(intr.ctypes.data, wt.ctypes.data, out.ctypes.data) == 0
+    cx, cy, fxx, fy = fx["intr_members_cx_cy_fx_fy_r2_r4_r6"][:4]
+    assert out[:4].tolist() == [cx, cy, fxx, fy]
+    assert out[4:7].tolist() == fx["world_t"]
+    assert out[7:16].tolist() == fx["world_R_rowmajor"]
+    # the oracle reads the same arrays the same way (lsn_oracle.c unpacks intr[0..3], wt[0..2], wt[3..11])
+    assert fx["icp_default_maxIter"] == 10
+
+
+def test_live_reference_header_agrees_with_the_fixture():
+    """Where oracle/_ref/libref_abi.so exists (built from the reference's header in the build container; travels to the GPU box), the live
+    values equal the committed ones, and random parameters unpack identically through the reference's constructors and this library."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_abi.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_abi.so not built (needs /root/reference)")
+    R = C.CDLL(path)
+    lay = (C.c_int * 32)()
+    n = R.ref_abi_layout(lay, 32)
+    fx = _abi_fixture()
+    assert list(lay[:n]) == fx["layout"] == _layout_here()
+    rng = np.random.default_rng(5)
+    for _ in range(8):
+        intr = rng.standard_normal(7).astype(np.float32)
+        wt = rng.standard_normal(12).astype(np.float32)
+        o7 = np.zeros(7, np.float32); t3 = np.zeros(3, np.float32); R9 = np.zeros(9, np.float32)
+        R.ref_unpack_intrinsics(C.c_void_p(intr.ctypes.data), C.c_void_p(o7.ctypes.data))
+        R.ref_unpack_world(C.c_void_p(wt.ctypes.data), 0, C.c_void_p(t3.ctypes.data), C.c_void_p(R9.ctypes.data))
+        out = np.zeros(16, np.float32)
+        assert native.lib().lsnPackSensorParams(intr.ctypes.data, wt.ctypes.data, out.ctypes.data) == 0
+        assert out[:4].tobytes() == o7[:4].tobytes() and out[4:7].tobytes() == t3.tobytes() and out[7:].tobytes() == R9.tobytes()
 
 
 def test_create_and_delete_mesh_without_gpu():
