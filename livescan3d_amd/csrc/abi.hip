@@ -7,20 +7,27 @@
 // device buffers and serialise on one lock; ICP has its own buffers, stream and lock, so a multi-millisecond refine call does
 // not hold up the merge calls (LiveScanServer runs them on two BackgroundWorkers, MainWindowForm.cs:238,304).
 //
-// A merge call is PCIe-bound (8 x 512x424: 8.7 MB up, 15-35 MB down, against ~30 us of kernels), so the hops are laid out
-// to keep the link busy and nothing else in the way:
-//   * the caller's arrays are uploaded as they are.  Registering them once with hipHostRegister (C# keeps the same arrays
-//     from tick to tick, KinectServer.cs:74-80) buys nothing on this platform -- measured on the MI355X box
-//     (tools/pcie_probe.cpp): pageable 3.5 / 5.2 / 15 MB copies run at 49-55 GB/s, registered and hipHostMalloc'ed ones at
-//     47-55 GB/s -- and a stale registration (the caller frees an array, the allocator hands the pages to another one) makes
-//     later copies fail with "invalid argument".  The cache is therefore OFF unless $LSN_HOST_REGISTER=1;
-//   * depth goes up first: the count pass needs nothing else and runs while the colours are still on the link;
-//   * the offset table comes back through a small pinned block right behind the scan, so the host knows the vertex count
-//     (and has the output block ready) before the write pass has finished;
-//   * the vertices leave on a second stream as soon as they are written, while the triangulation kernels are still running.
+// A merge call is PCIe-bound (8 x 512x424: 8.7 MB up, 15-35 MB down, against ~30 us of kernels), so the call is laid out around the
+// link (round 4; numbers from tools/link_probe.hip on the MI355X box):
+//   * OUTPUT: the write kernels store the vertices and the triangles STRAIGHT INTO the pinned host blocks that become
+//     Mesh::vertices / Mesh::triangles (hipHostMalloc memory is device-visible).  16-byte stores of consecutive lanes cross the
+//     link at the rate of the copy engine (55 GB/s), but need no length in advance -- so there is no count round trip, no
+//     download to issue, and the bytes start to leave as soon as the first sensors have been fused;
+//   * INPUT: the caller's arrays are pageable (C# pins them, the runtime does not know).  A pageable hipMemcpy of >= 1 MiB pins the
+//     pages in place and runs at ~52 GB/s but keeps the calling thread until it is done; below 1 MiB the runtime stages through a
+//     bounce buffer at ~15 GB/s.  So the sensors go up in GROUPS whose depth and colour copies both reach 1 MiB (three 512x424
+//     sensors), each group on the upload stream, blocking; the group's kernels are launched behind it and store to the host while
+//     the next group is on its way up -- both directions of the link are busy at once;
+//   * a group has its own plan (its own scratch, thresholds, radial tables); its vertex / triangle prefixes start where the
+//     previous group's ended (scan_kernel's carry), so all groups write one contiguous mesh in formMesh's order;
+//   * registering the caller's arrays (hipHostRegister) was measured again: 1.4 ms to register 8.7 MB, copies from registered
+//     memory 43 GB/s, kernel loads from it 40 GB/s -- slower than the pageable copy.  The cache stays OFF unless $LSN_HOST_REGISTER=1.
+// $LSN_HOST_PATH=copy selects round 3's flow (device-resident output + copy engine, download behind the count) for A/B runs;
+// $LSN_HOST_GROUP=n fixes the sensors per group.
 #include "lsn_common.hpp"
 
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -30,30 +37,41 @@
 
 namespace lsn {
 
-std::string &last_error()
+// The error text lives in a fixed thread-local buffer: reporting a failure (an allocation failure, for one) must not allocate.
+char *error_buffer() noexcept
 {
-    static thread_local std::string s;
-    return s;
+    static thread_local char buf[kErrorLen] = {0};
+    return buf;
 }
 
-void set_error(const char *fmt, ...)
+void set_error(const char *fmt, ...) noexcept
 {
-    char buf[1024];
+    char *buf = error_buffer();
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(buf, kErrorLen, fmt, ap);
     va_end(ap);
-    last_error() = buf;
     if (getenv("LSN_VERBOSE")) fprintf(stderr, "[NativeUtils] %s\n", buf);
+}
+
+// Test hook of the exception trampoline (lsn::guarded): $LSN_TEST_THROW=n makes the n-th guarded entry of the process throw
+// std::bad_alloc from inside the guarded region; $LSN_TEST_FAIL_ALLOC=n makes the n-th device / pinned allocation throw it
+// (what a std::vector or std::map growing under memory pressure would do).  Read once.
+void test_fault_point(int kind)
+{
+    static const long want[2] = {getenv("LSN_TEST_THROW") ? atol(getenv("LSN_TEST_THROW")) : 0,
+                                 getenv("LSN_TEST_FAIL_ALLOC") ? atol(getenv("LSN_TEST_FAIL_ALLOC")) : 0};
+    static std::atomic<long> seen[2];
+    if (want[kind] > 0 && ++seen[kind] == want[kind]) throw std::bad_alloc();
 }
 
 }  // namespace lsn
 
 extern "C" int lsnGetLastError(char *buf, int len)
 {
-    const std::string &s = lsn::last_error();
-    if (buf && len > 0) snprintf(buf, (size_t)len, "%s", s.c_str());
-    return (int)s.size();
+    const char *s = lsn::error_buffer();
+    if (buf && len > 0) snprintf(buf, (size_t)len, "%s", s);
+    return (int)strlen(s);
 }
 
 extern "C" int lsnDeviceCount(void)
@@ -145,26 +163,56 @@ namespace {
 // What one call in flight needs: streams, events, device buffers.  LiveScanServer runs its merge calls (updateWorker: radial correction,
 // generateMeshFromDepthMaps) and its refine calls (refineWorker: generateVerticesFromDepthMap per sensor, then ICP) on two threads
 // (MainWindowForm.cs:238,304); each of the three families has its own lane, so they only meet at the short shared tables below.
+// One group of consecutive sensors of a call: fused by one launch as soon as its frames are on the device (file comment).
+struct Group {
+    int first = 0, count = 0;        // sensors [first, first + count) of the caller's arrays
+    size_t d_off = 0, c_off = 0;     // where the group's frames start in the lane's device buffers (bytes)
+    size_t d_src = 0, c_src = 0;     // ... and in the caller's arrays
+    size_t dbytes = 0, cbytes = 0;
+    int ready_after = 0;             // how many copies of the call's upload schedule must have landed before its launch
+    LsnFusion *radial_plan = nullptr;   // calls that start with the radial correction: the group's own plan for it (its warp tables)
+};
+
+// One blocking upload of the schedule: a run of whole frames of the caller's depth or colour array.
+struct Copy {
+    size_t dev_off = 0, src_off = 0, bytes = 0;
+    bool colours = false;
+};
+
+constexpr int kMaxGroups = 16;
+
 struct Lane {
     std::mutex mu;
     hipStream_t stream = nullptr, up = nullptr, down = nullptr;
     hipEvent_t ev_depth = nullptr, ev_col = nullptr, ev_counted = nullptr, ev_written = nullptr, ev_tri_counted = nullptr, ev_down = nullptr;
+    hipEvent_t ev_group[kMaxGroups] = {};    // "group g's corrected maps are final" (the write-back of the one-call tick waits for it)
     int *h_off = nullptr, *h_toff = nullptr;   // pinned: the offset tables of the call in progress
     int h_off_cap = 0;
     lsn::DevBuf d_depth, d_colors, d_depth2, d_colors2, d_out, d_off, d_tri, d_tri_off;
-    int last_nv = -1, last_nt = 0;   // the mesh of the lane's last call is still in d_out / d_tri (lsnLastMesh* read the merge lane's)
+    // the lane's plans: key = n sensors, first sensor, widths..., heights...  Owned by the lane and only touched under its lock, so a
+    // plan never runs on two lanes' streams at once and an eviction cannot pull a plan from under the other lane's call
+    std::map<std::vector<int>, LsnFusion *> plans;
+    // The mesh of the lane's last call (lsnLastMesh* read it): its vertex / triangle counts, and whether it is in d_out / d_tri.
+    // The direct path stores the mesh to host memory only; the inputs stay in d_depth / d_colors (d_depth2 / d_colors2 after the
+    // radial correction), so the mesh can be rebuilt in HBM by last_plan when somebody asks for it.
+    int last_nv = -1, last_nt = 0;
+    bool last_in_hbm = false, last_radial = false, last_tri = false;
+    LsnFusion *last_plan = nullptr;
+    std::vector<Group> groups;
+    std::vector<Copy> copies;
 };
 
 struct Ctx {
     Lane merge, single;       // lane of the merge / radial / last-mesh calls; lane of the single-sensor calls
     std::mutex icp_mu;        // ICP: own buffers, own stream
     std::mutex init_mu;
-    std::mutex tab_mu;        // the shared tables: plans, the pinned-block pool, the registered host ranges
+    std::mutex tab_mu;        // the shared tables: the pinned-block pool, the registered host ranges
     std::atomic<Lane *> last_lane{nullptr};   // the lane whose call finished last: lsnLastMesh* read the mesh it left in HBM
     bool ready = false;
     int device = 0;
+    bool direct = true;       // $LSN_HOST_PATH=copy: round 3's flow (output in HBM, copy engine home) for A/B runs
+    int group_override = 0;   // $LSN_HOST_GROUP: sensors per group (0 = by size)
     hipStream_t icp_stream = nullptr;
-    std::map<std::vector<int>, LsnFusion *> plans;  // key: n_maps, widths..., heights...
     lsn::DevBuf d_v1, d_v2, d_Rt;
     LsnIcp *icp = nullptr;
     int icp_n1 = 0, icp_n2 = 0;
@@ -219,8 +267,11 @@ int ensure_ready(Ctx &c)
         for (hipStream_t *s : {&l->stream, &l->up, &l->down}) LSN_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
         for (hipEvent_t *e : {&l->ev_depth, &l->ev_col, &l->ev_counted, &l->ev_written, &l->ev_tri_counted, &l->ev_down})
             LSN_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (int i = 0; i < kMaxGroups; i++) LSN_HIP(hipEventCreateWithFlags(&l->ev_group[i], hipEventDisableTiming));
     }
     if (const char *e = getenv("LSN_HOST_REGISTER")) c.reg_enabled = atoi(e) != 0;
+    if (const char *e = getenv("LSN_HOST_PATH")) c.direct = strcmp(e, "copy") != 0;
+    if (const char *e = getenv("LSN_HOST_GROUP")) c.group_override = atoi(e);
     c.ready = true;
     return 0;
 }
@@ -301,6 +352,7 @@ void drain(Lane &l)
 void *pinned_get(Ctx &c, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
+    lsn::test_fault_point(1);
     std::lock_guard<std::mutex> tg(c.tab_mu);
     auto it = c.pool.lower_bound(bytes);
     if (it != c.pool.end() && it->first <= bytes * 2 + 4096) {
@@ -345,10 +397,9 @@ void empty_mesh(Ctx &c, Mesh *m)
     }
 }
 
-// The cached single-tick plan for sensors [first, first + count) of a call.
-LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, int count)
+// The lane's cached single-tick plan for sensors [first, first + count) of a call.  The lane's lock is held.
+LsnFusion *get_plan(Ctx &c, Lane &l, const int *widths, const int *heights, int first, int count)
 {
-    std::lock_guard<std::mutex> tg(c.tab_mu);
     // `first` is part of the key: generateVerticesFromDepthMap is called for sensor 0, 1, ... in turn (KinectServer.cs:527-554) and every
     // sensor keeps its own plan, so its calibration stays set (no parameter upload, no table rebuild per call) and its count pass
     // can run from the per-pixel depth thresholds from the second round on
@@ -357,16 +408,46 @@ LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, in
     key.push_back(first);
     for (int i = 0; i < count; i++) key.push_back(widths[first + i]);
     for (int i = 0; i < count; i++) key.push_back(heights[first + i]);
-    auto it = c.plans.find(key);
-    if (it != c.plans.end()) return it->second;
+    auto it = l.plans.find(key);
+    if (it != l.plans.end()) return it->second;
+    if (l.plans.size() > 64) {
+        // unbounded variety of geometries: start over.  Only this lane's plans, with nothing of this lane in flight (its lock is
+        // held, its streams are drained here), and none of the plans the call in progress has already picked
+        drain(l);
+        for (auto kv = l.plans.begin(); kv != l.plans.end();) {
+            bool in_use = kv->second == l.last_plan;
+            for (const Group &g : l.groups) in_use |= g.radial_plan == kv->second;
+            if (in_use) {
+                ++kv;
+                continue;
+            }
+            lsnFusionDestroy(kv->second);
+            kv = l.plans.erase(kv);
+        }
+    }
     LsnFusion *plan = lsnFusionCreate(c.device, 1, count, widths + first, heights + first);
     if (!plan) return nullptr;
-    if (c.plans.size() > 64) {  // unbounded variety of geometries: start over
-        for (auto &kv : c.plans) lsnFusionDestroy(kv.second);
-        c.plans.clear();
+    try {
+        l.plans[key] = plan;
+    } catch (...) {
+        lsnFusionDestroy(plan);
+        throw;
     }
-    c.plans[key] = plan;
     return plan;
+}
+
+// The pinned offset-table mirrors of a lane hold at least n ints each.
+int ensure_tables(Lane &l, int n)
+{
+    if (l.h_off_cap >= n) return 0;
+    if (l.h_off) (void)hipHostFree(l.h_off);
+    if (l.h_toff) (void)hipHostFree(l.h_toff);
+    l.h_off = l.h_toff = nullptr;
+    l.h_off_cap = 0;
+    LSN_HIP(hipHostMalloc((void **)&l.h_off, sizeof(int) * (size_t)(n + 64), hipHostMallocDefault));
+    LSN_HIP(hipHostMalloc((void **)&l.h_toff, sizeof(int) * (size_t)(n + 64), hipHostMallocDefault));
+    l.h_off_cap = n + 64;
+    return 0;
 }
 
 // Fuses `count` sensors of one tick from host buffers into out_mesh.  first/count select the sensors
@@ -374,13 +455,16 @@ LsnFusion *get_plan(Ctx &c, const int *widths, const int *heights, int first, in
 // knows them (what gets registered).  c.mu held.
 // radial (optional): the call starts with the radial correction of the frames (depthMapAndColorSetRadialCorrection) on the device;
 // radial_back_d / radial_back_c (optional): the corrected maps are also copied to these host arrays, like the separate export does.
-int fuse_host_inner(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, size_t total_d, size_t total_c,
-                    const int *widths, const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first,
-                    int count, bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr,
-                    unsigned char *radial_back_c = nullptr)
+int fuse_host_copy(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, size_t total_d, size_t total_c,
+                   const int *widths, const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first,
+                   int count, bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr,
+                   unsigned char *radial_back_c = nullptr)
 {
-    LsnFusion *plan = get_plan(c, widths, heights, first, count);
+    l.groups.clear();
+    l.last_plan = nullptr;
+    LsnFusion *plan = get_plan(c, l, widths, heights, first, count);
     if (!plan) return -1;
+    l.last_plan = plan;
     // sensor `first` starts after the frames before it (depthprocessing.cpp:1646-1650)
     size_t dskip = 0, cskip = 0, dbytes = 0, cbytes = 0;
     for (int i = 0; i < first; i++) {
@@ -396,15 +480,7 @@ int fuse_host_inner(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsi
     if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_out.reserve((size_t)cap * 16) ||
         l.d_off.reserve(sizeof(int) * (count + 1)))
         return -1;
-    if (l.h_off_cap < count + 1) {
-        if (l.h_off) (void)hipHostFree(l.h_off);
-        if (l.h_toff) (void)hipHostFree(l.h_toff);
-        l.h_off = l.h_toff = nullptr;
-        l.h_off_cap = 0;
-        LSN_HIP(hipHostMalloc((void **)&l.h_off, sizeof(int) * (size_t)(count + 1 + 64), hipHostMallocDefault));
-        LSN_HIP(hipHostMalloc((void **)&l.h_toff, sizeof(int) * (size_t)(count + 1 + 64), hipHostMallocDefault));
-        l.h_off_cap = count + 1 + 64;
-    }
+    if (ensure_tables(l, count + 1)) return -1;
     // the merge call sees the whole arrays the caller keeps from tick to tick: those get registered; a single-sensor call
     // (which only knows a prefix of them) profits when its slice lies inside
     (void)host_range_pinned(c, depth_maps, total_d, with_triangles);
@@ -486,7 +562,7 @@ int fuse_host_inner(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsi
             bad = !host_tri || hipMemcpyAsync(host_tri, l.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, l.stream) != hipSuccess;
         }
         if (bad) {
-            if (lsn::last_error().empty()) lsn::set_error("NativeUtils: triangle download failed: %s", hipGetErrorString(hipGetLastError()));
+            if (!lsn::has_error()) lsn::set_error("NativeUtils: triangle download failed: %s", hipGetErrorString(hipGetLastError()));
             drain(l);
             pinned_put(c, host);
             if (host_tri) pinned_put(c, host_tri);
@@ -502,6 +578,7 @@ int fuse_host_inner(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsi
     }
     l.last_nv = nv;
     l.last_nt = nt;
+    l.last_in_hbm = true;
     out->nVertices = nv;
     out->vertices = static_cast<VertexC4ubV3f *>(host);
     out->nTriangles = nt;
@@ -519,17 +596,302 @@ int fuse_host_inner(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsi
     return 0;
 }
 
+// The upload schedule of a call.  A pageable copy of >= 1 MiB is pinned in place by the runtime (~52 GB/s, ~10 us of fixed cost),
+// a smaller one is staged through a bounce buffer at a quarter of the rate, so frames go up in runs of at least 1 MiB.  The groups
+// are the runs of the COLOUR array (two 512x424 sensors); the depth array is cut independently (three sensors), a run going up
+// just before the first group that needs it -- a group is launched as soon as its frames are there, i.e. after `ready_after`
+// copies.  8 x 512x424:  D[0-2] C[0-1] | D[3-7] C[2-3] | C[4-5] | C[6-7].
+int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int first, int count, bool radial)
+{
+    l.groups.clear();
+    l.copies.clear();
+    constexpr size_t kPinnedCopy = (size_t)1 << 20;
+    const int end = first + count;
+    auto dsz = [&](int i) { return (size_t)widths[i] * heights[i] * 2; };
+    auto csz = [&](int i) { return (size_t)widths[i] * heights[i] * 3; };
+    size_t d_src0 = 0, c_src0 = 0;
+    for (int i = 0; i < first; i++) {   // sensor `first` starts after the frames before it (depthprocessing.cpp:1646-1650)
+        d_src0 += dsz(i);
+        c_src0 += csz(i);
+    }
+    int per = c.group_override > 0 ? c.group_override : 0;
+    if (per == 0 && count > kMaxGroups) {
+        size_t cb = 0;
+        for (int i = first; i < end; i++) cb += csz(i);
+        if (cb / kMaxGroups >= kPinnedCopy) per = (count + kMaxGroups - 1) / kMaxGroups;   // many big sensors: at most kMaxGroups groups
+    }
+    size_t d_off = 0, c_off = 0;
+    for (int i = first; i < end;) {
+        Group g;
+        g.first = i;
+        g.d_off = d_off; g.c_off = c_off;
+        g.d_src = d_src0 + d_off; g.c_src = c_src0 + c_off;
+        while (i < end && (per > 0 ? g.count < per : (g.count == 0 || g.cbytes < kPinnedCopy))) {
+            g.dbytes += dsz(i);
+            g.cbytes += csz(i);
+            g.count++;
+            i++;
+        }
+        d_off += g.dbytes;
+        c_off += g.cbytes;
+        if (per == 0 && !l.groups.empty() && i == end && g.cbytes * 2 < kPinnedCopy) {
+            Group &b = l.groups.back();   // a short tail: one more bounce-buffer copy would cost more than the overlap wins
+            b.count += g.count;
+            b.dbytes += g.dbytes;
+            b.cbytes += g.cbytes;
+        } else {
+            l.groups.push_back(g);
+        }
+    }
+    // a group's radial correction works on its slice of the buffers through a plan of its own: the slices must keep the alignment
+    // the wide-load kernels ask for (16 B depth, 8 B colours); and there are kMaxGroups events.  A rig that breaks either goes as
+    // one group
+    bool ok = l.groups.size() <= (size_t)kMaxGroups;
+    for (const Group &g : l.groups) ok &= (g.d_off % 16) == 0 && (g.c_off % 8) == 0;
+    if (!ok && l.groups.size() > 1) {
+        Group all = l.groups.front();
+        for (size_t k = 1; k < l.groups.size(); k++) {
+            all.count += l.groups[k].count;
+            all.dbytes += l.groups[k].dbytes;
+            all.cbytes += l.groups[k].cbytes;
+        }
+        l.groups.assign(1, all);
+    }
+    // copies: depth runs interleaved with the groups' colour runs
+    int depth_to = first;          // sensors [first, depth_to) have their depth scheduled
+    size_t depth_off = 0;
+    for (Group &g : l.groups) {
+        if (depth_to < g.first + g.count) {
+            Copy d;
+            d.dev_off = depth_off;
+            d.src_off = d_src0 + depth_off;
+            int to = depth_to;
+            while (to < end && (to < g.first + g.count || d.bytes < kPinnedCopy)) d.bytes += dsz(to++);
+            size_t rest = 0;
+            for (int i = to; i < end; i++) rest += dsz(i);
+            if (rest > 0 && rest < kPinnedCopy) {   // what is left would be a bounce-buffer copy: take it along
+                d.bytes += rest;
+                to = end;
+            }
+            l.copies.push_back(d);
+            depth_to = to;
+            depth_off += d.bytes;
+        }
+        Copy cc;
+        cc.colours = true;
+        cc.dev_off = g.c_off;
+        cc.src_off = g.c_src;
+        cc.bytes = g.cbytes;
+        l.copies.push_back(cc);
+        g.ready_after = (int)l.copies.size();
+    }
+    if (radial)
+        for (Group &g : l.groups) {
+            g.radial_plan = get_plan(c, l, widths, heights, g.first, g.count);
+            if (!g.radial_plan) return -1;
+        }
+    return 0;
+}
+
+// $LSN_HOST_TRACE=1: wall-clock marks of the phases of a direct call, printed for three calls once the first ten have gone by
+struct PhaseTrace {
+    bool on = false;
+    int n = 0;
+    const char *name[64];
+    double t[64];
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void mark(const char *what)
+    {
+        if (on && n < 64) {
+            name[n] = what;
+            t[n++] = now();
+        }
+    }
+    void print() const
+    {
+        if (!on || n == 0) return;
+        fprintf(stderr, "[NativeUtils trace]");
+        for (int i = 1; i < n; i++) fprintf(stderr, " %s +%.1f", name[i], 1e6 * (t[i] - t[i - 1]));
+        fprintf(stderr, " | total %.1f us\n", 1e6 * (t[n - 1] - t[0]));
+    }
+};
+
+// Fuses `count` sensors of one tick from host buffers into out_mesh, the kernels storing straight into the mesh's host blocks
+// (file comment).  first/count select the sensors (generateVerticesFromDepthMap uses one).  The lane's lock is held.
+// radial (optional): the call starts with the radial correction of the frames (depthMapAndColorSetRadialCorrection) on the device;
+// radial_back_d / radial_back_c (optional): the corrected maps are also copied to these host arrays, like the separate export does.
+int fuse_host_direct(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths, const int *heights,
+                     const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count, bool with_triangles, bool radial,
+                     unsigned char *radial_back_d, unsigned char *radial_back_c)
+{
+    l.last_nv = -1;
+    l.last_plan = nullptr;
+    static const bool trace_env = getenv("LSN_HOST_TRACE") && atoi(getenv("LSN_HOST_TRACE")) != 0;
+    static std::atomic<int> trace_calls{0};
+    PhaseTrace tr;
+    if (trace_env) {
+        const int k = trace_calls++;
+        tr.on = k >= 10 && k < 13;
+    }
+    tr.mark("enter");
+    l.groups.clear();
+    LsnFusion *plan = get_plan(c, l, widths, heights, first, count);
+    if (!plan) return -1;
+    l.last_plan = plan;
+    if (make_schedule(c, l, widths, heights, first, count, radial)) return -1;
+    const size_t G = l.groups.size();
+    size_t dbytes = 0, cbytes = 0;
+    for (const Group &g : l.groups) {
+        dbytes += g.dbytes;
+        cbytes += g.cbytes;
+    }
+    const long long cap = lsnFusionTickCapacity(plan);
+    if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_off.reserve(sizeof(int) * (size_t)(count + 1)) ||
+        l.d_tri_off.reserve(sizeof(int) * (size_t)(count + 1)) || ensure_tables(l, count + 2))
+        return -1;
+    if (radial && (l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16))) return -1;
+    const bool back = radial && radial_back_d && radial_back_c;
+    // the mesh's host blocks, sized for the most the frames can give (recycled through the pool: the same blocks tick after tick)
+    void *host = pinned_get(c, (size_t)cap * sizeof(VertexC4ubV3f));
+    void *host_tri = with_triangles ? pinned_get(c, (size_t)cap * 2 * 12) : nullptr;
+    auto fail = [&]() {
+        drain(l);   // nothing of a failed call stays in flight: no kernel may store to a block that goes back to the pool
+        if (host) pinned_put(c, host);
+        if (host_tri) pinned_put(c, host_tri);
+        return -1;
+    };
+    if (!host || (with_triangles && !host_tri)) return fail();
+    l.h_off[count] = -1;       // the total: stored by the last tile of the last group
+    l.h_off[count + 1] = 0;    // the look-back's give-up flag
+    l.h_toff[count] = 0;
+    if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, l.stream)) return fail();
+    tr.mark("setup");
+
+    // what the fusion and triangle launches read: the raw frames, or the corrected ones
+    const char *run_d = radial ? l.d_depth2.as<char>() : l.d_depth.as<char>();
+    const char *run_c = radial ? l.d_colors2.as<char>() : l.d_colors.as<char>();
+    // One group (a single sensor: ~1 MB up, ~2 MB down, all fixed latency; or frames the scheme cannot cut): its copies go
+    // asynchronously on the kernels' stream.  Several groups: every copy blocks on the upload stream until the bytes are there, so
+    // the launch behind it needs no event, and runs (storing to the host) while the next copy is on its way up.
+    size_t next_group = 0;
+    for (size_t i = 0; i < l.copies.size(); i++) {
+        const Copy &cp = l.copies[i];
+        char *dst = (cp.colours ? l.d_colors.as<char>() : l.d_depth.as<char>()) + cp.dev_off;
+        const unsigned char *src = (cp.colours ? depth_colors : depth_maps) + cp.src_off;
+        const hipError_t e = G == 1 ? hipMemcpyAsync(dst, src, cp.bytes, hipMemcpyHostToDevice, l.stream)
+                                    : hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyHostToDevice, l.up);
+        if (e != hipSuccess) {
+            lsn::set_error("NativeUtils: upload failed: %s", hipGetErrorString(e));
+            return fail();
+        }
+        tr.mark(cp.colours ? "upC" : "upD");
+        for (; next_group < G && l.groups[next_group].ready_after == (int)i + 1; next_group++) {
+            const Group &g = l.groups[next_group];
+            if (radial) {
+                // out of place: raw frames in d_depth / d_colors, corrected ones in the second pair, which the launches below read
+                if (lsnFusionRadialCorrectTo(g.radial_plan, intr + 7 * g.first, l.d_depth.as<char>() + g.d_off, l.d_colors.as<char>() + g.c_off,
+                                             l.d_depth2.as<char>() + g.d_off, l.d_colors2.as<char>() + g.c_off, l.stream))
+                    return fail();
+                if (back && hipEventRecord(l.ev_group[next_group], l.stream) != hipSuccess) return fail();
+            }
+            if (lsn::run_frames(plan, run_d, run_c, host, l.d_off.as<int>(), g.first - first, g.first - first + g.count, next_group == 0, with_triangles,
+                                l.h_off, l.stream))
+                return fail();
+            tr.mark("launch");
+        }
+    }
+    if (with_triangles && lsn::run_triangles(plan, run_d, host_tri, l.d_tri_off.as<int>(), l.h_toff, l.stream)) return fail();
+    if (back) {
+        // the corrected maps go home group by group (copy engine, pageable destination: each copy blocks) while the launches run
+        for (size_t k = 0; k < G; k++) {
+            const Group &b = l.groups[k];
+            if (hipStreamWaitEvent(l.down, l.ev_group[k], 0) != hipSuccess ||
+                hipMemcpyWithStream(radial_back_d + b.d_src, l.d_depth2.as<char>() + b.d_off, b.dbytes, hipMemcpyDeviceToHost, l.down) != hipSuccess ||
+                hipMemcpyWithStream(radial_back_c + b.c_src, l.d_colors2.as<char>() + b.c_off, b.cbytes, hipMemcpyDeviceToHost, l.down) != hipSuccess) {
+                lsn::set_error("NativeUtils: write-back of the corrected maps failed: %s", hipGetErrorString(hipGetLastError()));
+                return fail();
+            }
+            tr.mark("back");
+        }
+    }
+    tr.mark("queued");
+    if (hipStreamSynchronize(l.stream) != hipSuccess) {
+        lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
+        return fail();
+    }
+    tr.mark("sync");
+    // the kernels left the counts in the pinned tables
+    const int nv = l.h_off[count], nt = with_triangles ? l.h_toff[count] : 0;
+    if (l.h_off[count + 1] != 0) {
+        (void)lsnFusionCheck(plan, l.stream);   // clears the plan's sticky flag
+        lsn::set_error("NativeUtils: the single-pass fusion gave up on a predecessor tile (look-back spin limit)");
+        return fail();
+    }
+    if (nv < 0 || nv > cap || nt < 0 || nt > 2 * cap) {
+        lsn::set_error("NativeUtils: device returned impossible counts (%d vertices, %d triangles)", nv, nt);
+        return fail();
+    }
+    int *tri = nullptr;
+    if (nt == 0) {
+        if (host_tri) pinned_put(c, host_tri);
+        host_tri = nullptr;
+        tri = (int *)malloc(sizeof(int));  // "new int[0]": valid, never dereferenced (KinectServer.cs:344-345)
+        if (tri) {
+            std::lock_guard<std::mutex> tg(c.tab_mu);
+            c.live_tri[tri] = 1;
+        }
+    }
+    l.last_nv = nv;
+    l.last_nt = nt;
+    l.last_in_hbm = false;
+    l.last_radial = radial;
+    l.last_tri = with_triangles;
+    out->nVertices = nv;
+    out->vertices = static_cast<VertexC4ubV3f *>(host);
+    out->nTriangles = nt;
+    out->triangles = nt > 0 ? static_cast<int *>(host_tri) : tri;
+    c.last_lane.store(&l);
+    tr.mark("done");
+    tr.print();
+    return 0;
+}
+
+// lsnLastMesh*: the mesh of the lane's last call in d_out / d_tri.  The direct path left it in host memory only; its inputs are
+// still resident, so the plan's ordinary launches rebuild it in HBM (bit-identical: same arithmetic, same frames).  Lane lock held.
+int materialize(Lane &l)
+{
+    if (l.last_nv < 0 || l.last_in_hbm) return 0;
+    LsnFusion *plan = l.last_plan;
+    if (!plan) return -1;
+    const long long cap = lsnFusionTickCapacity(plan);
+    if (l.d_out.reserve((size_t)cap * 16) || (l.last_tri && l.d_tri.reserve((size_t)cap * 2 * 12))) return -1;
+    const void *run_d = l.last_radial ? l.d_depth2.p : l.d_depth.p, *run_c = l.last_radial ? l.d_colors2.p : l.d_colors.p;
+    if (l.last_tri ? lsn::run_mesh(plan, run_d, run_c, l.d_out.p, l.d_off.as<int>(), l.d_tri.p, l.d_tri_off.as<int>(), l.stream, nullptr)
+                   : lsn::run_hooked(plan, run_d, run_c, l.d_out.p, l.d_off.as<int>(), l.stream, nullptr))
+        return -1;
+    LSN_HIP(hipStreamSynchronize(l.stream));
+    l.last_in_hbm = true;
+    return 0;
+}
+
 int fuse_host(Ctx &c, Lane &l, int n_maps_known, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
               const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count,
               bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr, unsigned char *radial_back_c = nullptr)
 {
+    // Calls that start with the radial correction keep the device-resident output + copy engine: while a kernel streams to host
+    // memory no other kernel completes (tools/link_probe.hip, F), so the correction of the next group -- ~100 us of latency-bound
+    // closing rounds per launch -- cannot hide behind the previous group's stores, and the grouped form loses (1.32 against 1.17 ms)
+    static const bool radial_direct = getenv("LSN_HOST_RADIAL_DIRECT") && atoi(getenv("LSN_HOST_RADIAL_DIRECT")) != 0;
+    if (c.direct && (!radial || radial_direct))
+        return fuse_host_direct(c, l, depth_maps, depth_colors, widths, heights, intr, wt, out, bounds6, first, count, with_triangles, radial,
+                                radial_back_d, radial_back_c);
     size_t total_d = 0, total_c = 0;
     for (int i = 0; i < n_maps_known; i++) {
         total_d += (size_t)widths[i] * heights[i] * 2;
         total_c += (size_t)widths[i] * heights[i] * 3;
     }
-    const int rc = fuse_host_inner(c, l, depth_maps, depth_colors, total_d, total_c, widths, heights, intr, wt, out, bounds6, first, count,
-                                   with_triangles, radial, radial_back_d, radial_back_c);
+    const int rc = fuse_host_copy(c, l, depth_maps, depth_colors, total_d, total_c, widths, heights, intr, wt, out, bounds6, first, count,
+                                  with_triangles, radial, radial_back_d, radial_back_c);
     if (rc) drain(l);   // nothing of a failed call stays in flight
     return rc;
 }
@@ -623,7 +985,8 @@ extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *d
     Lane &l = c.merge;
     std::lock_guard<std::mutex> g(l.mu);
     if (ensure_ready(c)) return;
-    LsnFusion *plan = get_plan(c, widths, heights, 0, n_maps);
+    l.last_nv = -1;   // the lane's buffers are about to be reused
+    LsnFusion *plan = get_plan(c, l, widths, heights, 0, n_maps);
     if (!plan) return;
     size_t dbytes = 0, cbytes = 0;
     for (int i = 0; i < n_maps; i++) {
@@ -745,6 +1108,7 @@ long long last_mesh_bytes(Ctx &c, Lane &l, int kind, unsigned char *out, long lo
     const int nv = l.last_nv, nt = l.last_nt;
     const long long bound = kind == 0 ? lsnTransferFrameBound(nv, nt) : lsnPlyBinaryBytes(nv, nt);
     if (!out) return bound;
+    if (materialize(l)) return -1;
     std::lock_guard<std::mutex> wg(c.wire_mu);
     if (c.d_wire.reserve((size_t)bound + 16)) return -1;
     long long n = -1;

@@ -323,7 +323,7 @@ int lsn::pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors,
     FuseArgs a;
     fill_args(p, a, d_depth, d_colors, nullptr, d_offsets);
     launch_count(p, true, s, a);
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames, a.offsets);
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames, a.offsets, nullptr, nullptr);
     PackArgs pk;
     pk.mask = static_cast<unsigned char *>(d_mask);
     pk.depth_c = static_cast<unsigned short *>(d_depth_c);
@@ -734,7 +734,7 @@ extern "C" LsnShard *lsnShardPrepare(int device, int rank, int world, int n_tick
         }
     }
     if (bad) {
-        if (lsn::last_error().empty()) lsn::set_error("lsnShardPrepare: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        if (!lsn::has_error()) lsn::set_error("lsnShardPrepare: allocation failed: %s", hipGetErrorString(hipGetLastError()));
         lsnShardDestroy(sh);
         return nullptr;
     }
@@ -778,7 +778,7 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
     LsnShard *sh = lsnShardPrepare(device, rank, world, n_ticks, n_maps, widths, heights);
     if (!sh) return nullptr;
     if (lsnShardConnect(sh, id128)) {
-        const std::string why = lsn::last_error();
+        const std::string why = lsn::error_buffer();
         lsnShardDestroy(sh);
         lsn::set_error("%s", why.c_str());
         return nullptr;
@@ -832,7 +832,7 @@ extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void 
     const int rc = shard_step(sh, d_depth_local, d_colors_local, d_merged, d_merged_offsets, stream);
     if (rc) {
         sh->failed = true;
-        sh->failure = lsn::last_error();
+        sh->failure = lsn::error_buffer();
     }
     return rc;
 }

@@ -274,6 +274,7 @@ __device__ __forceinline__ int tile_lookback(const FuseArgs &a, int tick, int ti
             if (poisoned || ++spins > kSpinLimit) {
                 if (lane == 0) {
                     atomicExch(a.error_flag, 1);
+                    if (a.offsets_mirror) a.offsets_mirror[a.n_frames + 1] = 1;
                     __hip_atomic_store(&st[tile], tag | (3ull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 return -1;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
         tick = r / width;
         tile = chunk * a.chunk + (r - tick * width);
     }
+    tile += a.tile0;   // a launch over a group of sensors of a one-tick plan (run_frames); 0 everywhere else
     const int lin = tick * a.tiles_per_tick + tile;
 
     const Tile t = locate(a, tick, tile);
@@ -406,6 +408,10 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
             int *off = a.offsets + tick * (a.n_frames + 1);
             if (t.frame_start) off[t.f] = base;
             if (tile == a.tiles_per_tick - 1) off[a.n_frames] = base + tile_tot;
+            if (a.offsets_mirror) {
+                if (t.frame_start) a.offsets_mirror[t.f] = base;
+                if (tile == a.tiles_per_tick - 1) a.offsets_mirror[a.n_frames] = base + tile_tot;
+            }
         }
     }
     if (MODE != 4 && tile_tot != counted) {
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
             }
         }
     }
-    stage_and_store(stage, keep, vert, wave_off + below, tile_tot, a.out + tick * a.tick_vert_stride + base);
+    stage_and_store(stage, keep, vert, wave_off + below, tile_tot, a.out + tick * a.tick_vert_stride + base, MODE == 4 && a.host_out != 0);
 }
 
 // ---- mode 1: one launch, runs of tiles with a decoupled look-back per run ---------------------------------------
@@ -652,6 +658,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
         fr[i].h = heights[i];
         fr[i].npix = npix;
         fr[i].tile_start = tiles;
+        p->tile_start.push_back(tiles);
         fr[i].depth_off = doff;
         fr[i].rgb_off = coff;
         fr[i].xtab_off = xoff;
@@ -680,6 +687,7 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
     p->tick_depth_elems = doff;
     p->tick_rgb_bytes = coff;
     p->tiles_per_tick = tiles;
+    p->tile_start.push_back(tiles);
     p->vec_ok = vec;
     if (doff > 0x7FFFFFFFll) {
         lsn::set_error("lsnFusionCreate: a tick may not exceed 2^31-1 pixels (Mesh.nVertices is an int)");
@@ -909,6 +917,9 @@ void lsn::fill_args(LsnFusion *p, FuseArgs &a, const void *d_depth, const void *
     a.depth_next = nullptr;
     a.tile_counts_next = nullptr;
     a.thr = p->thr_valid ? p->thr.as<unsigned int>() : nullptr;
+    a.tile0 = 0;
+    a.host_out = 0;
+    a.offsets_mirror = nullptr;
 }
 
 // Called at the top of every run (p->mu held): from the second run with the same parameters on, the count pass uses the
@@ -1060,7 +1071,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         ac.offsets = off_int;
         launch_count(p, vec, p->side, ac);
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, p->side, ac.tile_counts, ac.tiles_per_tick, ac.frames,
-                           ac.n_frames, off_int);
+                           ac.n_frames, off_int, nullptr, nullptr);
         LSN_HIP(hipEventRecord(p->ev_counted, p->side));
         LSN_HIP(hipStreamWaitEvent(s, p->ev_counted, 0));
         LSN_HIP(hipMemcpyAsync(d_offsets, off_int, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
@@ -1071,9 +1082,12 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         p->calls++;
     } else if (p->mode == 0 || with_pixmap || hooks) {
         launch_count(p, vec, s, a);
+        const bool mirror = hooks && hooks->mirror && hooks->h_offsets;
+        if (hooks && hooks->carry_wait) LSN_HIP(hipStreamWaitEvent(s, hooks->carry_wait, 0));
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
-                           a.offsets);
-        if (hooks && hooks->h_offsets) LSN_HIP(hipMemcpyAsync(hooks->h_offsets, d_offsets, off_bytes, hipMemcpyDeviceToHost, s));
+                           a.offsets, hooks ? hooks->carry : nullptr, mirror ? hooks->h_offsets : nullptr);
+        if (hooks && hooks->carry_record) LSN_HIP(hipEventRecord(hooks->carry_record, s));
+        if (hooks && hooks->h_offsets && !mirror) LSN_HIP(hipMemcpyAsync(hooks->h_offsets, d_offsets, off_bytes, hipMemcpyDeviceToHost, s));
         if (hooks && hooks->counted) LSN_HIP(hipEventRecord(hooks->counted, s));
         if (hooks && hooks->colours_ready) LSN_HIP(hipStreamWaitEvent(s, hooks->colours_ready, 0));
         if (e0) LSN_HIP(hipEventRecord(e0, s));
@@ -1105,6 +1119,57 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         else     hipLaunchKernelGGL((run_kernel<false>), dim3(rgrid), dim3(kThreads), 0, s, a);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
     }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+// A one-tick plan fused group by group: frames [f0, f1) in ONE launch, single pass (a tile computes its vertices once, publishes
+// its count and resolves its offset by look-back over the tiles before it -- fuse_kernel<4>, the mode-2 kernel), so the groups of
+// a tick can be launched one after the other as their frames arrive, each continuing where the previous one stopped: the tiles of
+// a later launch find the inclusive prefixes of the earlier launches' tiles in place (same epoch).  This is the form the host
+// exports use (abi.hip): their output block is pinned host memory, the launch is bound by the PCIe link, and any further kernel
+// boundary -- a separate count, a scan -- is time in which nothing crosses it.  first_of_tick starts a tick (new epoch).
+// offsets_mirror (optional, pinned host memory, n_maps + 2 ints): the offset table as the tiles resolve it, then a give-up flag.
+int lsn::run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, int f0, int f1, bool first_of_tick,
+                    bool with_pixmap, int *offsets_mirror, hipStream_t s)
+{
+    if (!p || !d_depth || !d_colors || !d_vertices || !d_offsets || f0 < 0 || f1 > p->n_maps || f0 >= f1 || p->n_ticks != 1) {
+        lsn::set_error("run_frames: bad arguments");
+        return -1;
+    }
+    if (!p->params_set) {
+        lsn::set_error("run_frames: lsnFusionSetParams has not been called");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && (p->tick_depth_elems % 8) == 0;
+    if (with_pixmap) {
+        if (vec ? (p->pm_first.reserve(sizeof(int) * ((size_t)p->cap / 8 + 2)) || p->pm_mask.reserve((size_t)p->cap / 8 + 2))
+                : p->pixmap.reserve(sizeof(int) * (size_t)p->cap))
+            return -1;
+        p->pixmap_compact = vec;
+    }
+    struct PixmapScope {
+        LsnFusion *p;
+        PixmapScope(LsnFusion *q, bool on) : p(q) { p->want_pixmap = on; }
+        ~PixmapScope() { p->want_pixmap = false; }
+    } scope(p, with_pixmap);
+    FuseArgs a;
+    fill_args(p, a, d_depth, d_colors, d_vertices, d_offsets);
+    if (first_of_tick) {
+        if (p->epoch == 0 || p->epoch >= (1u << 30) - 1) {
+            LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)p->tiles_per_tick, s));
+            p->epoch = 0;
+        }
+        ++p->epoch;
+    }
+    a.epoch = p->epoch;
+    a.chunk = 0;
+    a.tile0 = p->tile_start[f0];
+    a.offsets_mirror = offsets_mirror;
+    a.host_out = offsets_mirror != nullptr;   // the hosts that mirror the counts are the ones whose output block is host memory
+    launch<4>(vec, p->tile_start[f1] - p->tile_start[f0], s, a, p->lazy_rgb);
     LSN_HIP(hipGetLastError());
     return 0;
 }
@@ -1144,7 +1209,7 @@ extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const voi
         // nothing (valid) was counted ahead for this batch: do it now, like mode 0
         a.offsets = off_cur;
         launch_count(p, vec, s, a);
-        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, cur, a.tiles_per_tick, a.frames, a.n_frames, off_cur);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, cur, a.tiles_per_tick, a.frames, a.n_frames, off_cur, nullptr, nullptr);
     }
     LSN_HIP(hipMemcpyAsync(d_offsets, off_cur, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
     a.offsets = d_offsets;
@@ -1160,7 +1225,7 @@ extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const voi
     }
     if (e1) LSN_HIP(hipEventRecord(e1, s));
     if (d_next_depth) {
-        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, nxt, a.tiles_per_tick, a.frames, a.n_frames, off_nxt);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, nxt, a.tiles_per_tick, a.frames, a.n_frames, off_nxt, nullptr, nullptr);
         p->counted_for = d_next_depth;
         p->counted_gen = p->params_gen;
         p->stream_half ^= 1;

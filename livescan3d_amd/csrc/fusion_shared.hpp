@@ -57,6 +57,9 @@ struct FuseArgs {
     int tiles_per_run;               // mode 1
     unsigned int epoch;              // mode 2: tag of this launch's look-back words (run_state is never cleared)
     int chunk;                       // write pass block order: 0 = tick-major; C > 0 = chunks of C consecutive tiles, all ticks of a chunk before the next chunk
+    int tile0;                       // one-tick plans only: the launch covers tiles [tile0, tile0 + gridDim.x) of the tick (a group of sensors, run_frames)
+    int host_out;                    // mode 2: `out` is pinned host memory (plain, destination-aligned stores; see stage_and_store)
+    int *offsets_mirror;             // mode 2, optional: the offset table entries are also stored here (pinned host memory), [n_frames + 1] = give-up flag
     int runs_per_tick;               // mode 1
     long long tick_depth_stride;  // u16 elements
     long long tick_rgb_stride;    // bytes
@@ -367,8 +370,11 @@ __device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, c
 // 8-way conflict).  A typical tile (crop + invalid pixels) fits in one window of kWin; the 20.7 KB footprint (instead of
 // 36.9 KB for a whole tile) lets 7 workgroups share a CU.  Every thread must call this (barriers inside); rank0 is the
 // lane's first rank inside the tile, tile_tot is uniform.  On return the LDS window is free again.
+// host_dst: the destination is pinned host memory (the exports' output block, abi.hip) -- the stores cross PCIe, where plain stores
+// move ~5 % more than streaming ones and a wave whose 1 KB starts on a 1 KB boundary ~3 % more than one that straddles lines
+// (tools/link_probe.hip), so the copy-out is shifted to the destination's alignment.
 __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)[kPxPerLane], const uint4 (&vert)[kPxPerLane], int rank0,
-                                                int tile_tot, uint4 *dst)
+                                                int tile_tot, uint4 *dst, bool host_dst = false)
 {
     for (int w0 = 0; w0 < tile_tot; w0 += kWin) {
         int r = rank0 - w0;
@@ -381,6 +387,11 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
         }
         __syncthreads();
         const int n = min(kWin, tile_tot - w0);
+        if (host_dst) {
+            const int mis = (int)((reinterpret_cast<uintptr_t>(dst + w0) >> 4) & 63);
+            for (int i = (int)threadIdx.x - mis; i < n; i += kThreads)
+                if (i >= 0) dst[w0 + i] = stage[i + (i >> 3)];
+        } else
         for (int i = threadIdx.x; i < n; i += kThreads) {
             const uint4 v = stage[i + (i >> 3)];
             if (kNontemporalStores) {   // written once, never read again by this launch sequence
@@ -398,8 +409,13 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
 
 // Mode 0, between the count and the write launch: one workgroup per tick turns that tick's tile counts into exclusive
 // prefixes in place and fills the per-sensor offset table (offsets[tick][f] = first vertex of sensor f, [n_frames] = total).
+// carry_in (optional, single-tick plans): the prefixes start at *carry_in instead of 0 -- the host exports fuse a tick as several
+// groups of sensors, each with a plan of its own, and a group's vertices / triangles follow the previous group's in the same
+// output block (abi.hip); carry_in then points at the previous group's total, offsets[n_frames] of its table.
+// mirror (optional): the offset table is also stored there -- pinned host memory, so the host has the counts when the stream
+// is idle without a copy of its own.
 __attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(int *tile_counts, int tiles_per_tick, const FrameDesc *frames, int n_frames,
-                                                        int *offsets)
+                                                        int *offsets, const int *carry_in, int *mirror)
 {
     __shared__ int s_wave[4];
     __shared__ int s_carry;
@@ -407,7 +423,7 @@ __attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(
     int *tc = tile_counts + (long long)tick * tiles_per_tick;
     int *off = offsets + (long long)tick * (n_frames + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
+    if (threadIdx.x == 0) s_carry = carry_in ? *carry_in : 0;
     __syncthreads();
     for (int c0 = 0; c0 < tiles_per_tick; c0 += kThreads) {
         const int i = c0 + threadIdx.x;
@@ -423,7 +439,11 @@ __attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(
         __syncthreads();
     }
     // frames are few: thread f looks up the prefix at its first tile (written above by this workgroup)
-    for (int f = threadIdx.x; f <= n_frames; f += kThreads) off[f] = f < n_frames ? tc[frames[f].tile_start] : s_carry;
+    for (int f = threadIdx.x; f <= n_frames; f += kThreads) {
+        const int v = f < n_frames ? tc[frames[f].tile_start] : s_carry;
+        off[f] = v;
+        if (mirror) mirror[(long long)tick * (n_frames + 1) + f] = v;
+    }
 }
 
 
@@ -437,6 +457,7 @@ struct LsnFusion {
     int device = 0;
     int n_ticks = 0, n_maps = 0;
     std::vector<int> w, h;
+    std::vector<int> tile_start;  // first tile of every frame inside a tick, [n_maps] = tiles_per_tick
     long long cap = 0;  // vertices per tick
     long long tick_depth_elems = 0, tick_rgb_bytes = 0;
     int tiles_per_tick = 0;

@@ -1752,7 +1752,7 @@ extern "C" int lsnRefine(int device, int n_sensors, float *const *clouds, const 
         if (ws) lsnIcpDestroy(ws);
         (void)hipStreamDestroy(s);
         if (rc) {
-            if (lsn::last_error().empty()) lsn::set_error("lsnRefine: %s", hipGetErrorString(hipGetLastError()));
+            if (!lsn::has_error()) lsn::set_error("lsnRefine: %s", hipGetErrorString(hipGetLastError()));
             return -1;
         }
         for (int i = 0; i < n_sensors; i++) memcpy(clouds[i], back.data() + 3 * off[i], sizeof(float) * 3 * (size_t)counts[i]);

@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 
 #include "../../include/NativeUtils.h"
@@ -15,9 +17,41 @@ namespace lsn {
 // Thread-local error text behind lsnGetLastError().  The reference's exports have no error channel at all
 // (void / constant returns, src/NativeUtils/depthprocessing.cpp:1631,1715; icp.cpp:176); nothing may throw
 // across the C-ABI, so failures end up here.
-std::string &last_error();
-void set_error(const char *fmt, ...);
-inline void clear_error() { last_error().clear(); }
+constexpr int kErrorLen = 1024;
+char *error_buffer() noexcept;                         // fixed thread-local storage: setting an error never allocates
+void set_error(const char *fmt, ...) noexcept;
+inline void clear_error() noexcept { error_buffer()[0] = 0; }
+inline bool has_error() noexcept { return error_buffer()[0] != 0; }
+void test_fault_point(int kind);                       // 0 = guarded entry, 1 = allocation; throws std::bad_alloc when a test asks for it
+
+// Every extern "C" entry point runs its body through this: no exception may cross the C-ABI into a P/Invoke frame
+// (SURVEY 8b "exceptions must not escape"; the reference itself lets nanoflann throw, include/nanoflann.h:904).
+template <class R, class F>
+inline R guarded(const char *name, R fail, F &&body) noexcept
+{
+    try {
+        test_fault_point(0);
+        return body();
+    } catch (const std::exception &e) {
+        set_error("%s: %s", name, e.what());
+    } catch (...) {
+        set_error("%s: unknown exception", name);
+    }
+    return fail;
+}
+template <class F>
+inline void guarded_void(const char *name, F &&body) noexcept
+{
+    try {
+        test_fault_point(0);
+        body();
+        return;
+    } catch (const std::exception &e) {
+        set_error("%s: %s", name, e.what());
+    } catch (...) {
+        set_error("%s: unknown exception", name);
+    }
+}
 
 #define LSN_HIP(expr)                                                                                    \
     do {                                                                                                 \
@@ -53,6 +87,7 @@ struct DevBuf {
     // grow-only
     int reserve(size_t n) {
         if (n <= bytes) return 0;
+        test_fault_point(1);
         release();
         LSN_HIP(hipMalloc(&p, n));
         bytes = n;
@@ -71,6 +106,13 @@ struct RunHooks {
     hipEvent_t written = nullptr;         // recorded after the write pass (the vertices may leave while the triangulation runs)
     int *h_tri_offsets = nullptr;         // lsnFusionRunMesh: pinned host copy of the triangle offset table ...
     hipEvent_t tri_counted = nullptr;     // ... and the event behind it
+    // a tick fused as several groups of sensors into ONE output block (abi.hip): this group's vertex / triangle prefixes start at
+    // *carry / *tri_carry (device memory: the previous group's total), and its vertex indices (pixel -> vertex map, triangles) with them
+    const int *carry = nullptr;
+    const int *tri_carry = nullptr;
+    bool mirror = false;                  // h_offsets / h_tri_offsets are stored by the scan kernels themselves (pinned, device-visible memory): no copy
+    // ... and the groups run on different streams: the scan that reads *carry waits for carry_wait, and records carry_record behind itself
+    hipEvent_t carry_wait = nullptr, carry_record = nullptr, tri_carry_wait = nullptr, tri_carry_record = nullptr;
 };
 // lsnFusionRun with the plan's mutex already held; with_pixmap also fills the pixel -> vertex map the triangulation reads.
 int run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, hipStream_t s, bool with_pixmap,
@@ -80,6 +122,12 @@ int run_hooked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_
 // lsnFusionRunMesh with hooks (takes the mutex once for the vertex and the triangle passes).
 int run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, void *d_triangles, int *d_tri_offsets,
              hipStream_t s, const RunHooks *hooks);
+
+// One launch, single pass, over frames [f0, f1) of a one-tick plan (fusion.hip); and the triangle passes alone over the whole tick, for
+// a pixel -> vertex map that run_frames(with_pixmap) launches have filled (mesh.hip).  tri_mirror: optional pinned copy of the table.
+int run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, int f0, int f1, bool first_of_tick,
+               bool with_pixmap, int *offsets_mirror, hipStream_t s);
+int run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, hipStream_t s);
 
 // The survivor exchange's two ends with the back-to-back stream layout (exchange.hip; see their definitions).
 int pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c, int *d_tile_prefix,

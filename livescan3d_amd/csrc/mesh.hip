@@ -25,6 +25,7 @@ struct TriArgs {
     unsigned int *codes; // [n_ticks * tiles_per_tick * 256] per-lane 4-bit-per-pixel triangle codes: count pass -> write pass
     int tiles_per_tick;
     int win;                    // triangles staged per LDS round of the write pass
+    int host_out;               // `tri` is pinned host memory: plain stores, rounds aligned to the destination (stage_and_store's note)
     long long tick_pix_stride;  // pixels per tick
     long long tick_tri_stride;  // triangles per tick (capacity)
 };
@@ -360,7 +361,9 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
             const int end = lead + n;                      // in ints, relative to the aligned start of the first chunk
             const int c0 = lead ? 1 : 0, c1 = end >> 2;     // chunks [c0, c1) are whole
             int4 *g16 = reinterpret_cast<int4 *>(out - lead);
-            for (int j = c0 + (int)threadIdx.x; j < c1; j += kThreads) {
+            const int mis = a.host_out ? (int)((reinterpret_cast<uintptr_t>(g16 + c0) >> 4) & 63) : 0;
+            for (int j = c0 + (int)threadIdx.x - mis; j < c1; j += kThreads) {
+                if (j < c0) continue;
                 int4 v;                                     // written once, never read again by this launch sequence
                 const unsigned int o = (unsigned int)(4 * j - lead), q = o / 48u, rem = o - 48u * q;   // one division per chunk: a pad may fall inside it
                 const int ph = 4 * j + (int)q;
@@ -368,10 +371,14 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
                 v.y = stage[ph + 1 + (rem + 1 >= 48u)];
                 v.z = stage[ph + 2 + (rem + 2 >= 48u)];
                 v.w = stage[ph + 3 + (rem + 3 >= 48u)];
-                __builtin_nontemporal_store(v.x, &g16[j].x);
-                __builtin_nontemporal_store(v.y, &g16[j].y);
-                __builtin_nontemporal_store(v.z, &g16[j].z);
-                __builtin_nontemporal_store(v.w, &g16[j].w);
+                if (a.host_out) {
+                    g16[j] = v;
+                } else {
+                    __builtin_nontemporal_store(v.x, &g16[j].x);
+                    __builtin_nontemporal_store(v.y, &g16[j].y);
+                    __builtin_nontemporal_store(v.z, &g16[j].z);
+                    __builtin_nontemporal_store(v.w, &g16[j].w);
+                }
             }
             const int head = lead ? min(n, 4 - lead) : 0;   // the ragged ends: the neighbouring tiles own the rest of those chunks
             const int tail0 = max(head, 4 * c1 - lead);
@@ -384,6 +391,44 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
 
 
 }  // namespace
+
+// The triangle passes of a tick whose pixel -> vertex map is filled (count -> scan -> write); p->mu held.
+static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, hipStream_t s, const lsn::RunHooks *hooks)
+{
+    TriArgs t;
+    t.frames = p->frames.as<FrameDesc>();
+    t.tiles = p->tile_frame.as<TileDesc>();
+    t.depth = static_cast<const unsigned short *>(d_depth);
+    t.pixmap = p->pixmap.as<int>();
+    t.pm_first = p->pm_first.as<int>();
+    t.pm_mask = p->pm_mask.as<unsigned char>();
+    t.tri = static_cast<int *>(d_triangles);
+    t.tile_counts = p->tri_counts.as<int>();
+    t.codes = p->tri_codes.as<unsigned int>();
+    t.tiles_per_tick = p->tiles_per_tick;
+    static const int win_env = getenv("LSN_TRI_WINDOW") ? atoi(getenv("LSN_TRI_WINDOW")) : kTriWinDefault;
+    t.win = std::min(4096, std::max(256, win_env)) & ~15;
+    const size_t stage_bytes = sizeof(int) * (size_t)(stage_ints(t.win) + 3 * 64);
+    t.host_out = hooks && hooks->mirror;   // the hosts that mirror the counts are the ones whose output block is host memory
+    t.tick_pix_stride = p->cap;
+    t.tick_tri_stride = 2 * p->cap;
+    const bool vec = p->pixmap_compact && ((uintptr_t)d_depth & 15) == 0;   // the vertex pass above wrote the compact map iff it ran its wide-load form
+    const int grid = p->tiles_per_tick * p->n_ticks;
+    if (vec) hipLaunchKernelGGL((tri_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, t);
+    else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
+    const bool mirror = hooks && hooks->mirror && hooks->h_tri_offsets;
+    if (hooks && hooks->tri_carry_wait) LSN_HIP(hipStreamWaitEvent(s, hooks->tri_carry_wait, 0));
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, t.tile_counts, t.tiles_per_tick, t.frames, p->n_maps,
+                       d_tri_offsets, hooks ? hooks->tri_carry : nullptr, mirror ? hooks->h_tri_offsets : nullptr);
+    if (hooks && hooks->tri_carry_record) LSN_HIP(hipEventRecord(hooks->tri_carry_record, s));
+    if (hooks && hooks->h_tri_offsets && !mirror)
+        LSN_HIP(hipMemcpyAsync(hooks->h_tri_offsets, d_tri_offsets, sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1), hipMemcpyDeviceToHost, s));
+    if (hooks && hooks->tri_counted) LSN_HIP(hipEventRecord(hooks->tri_counted, s));
+    if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
+    else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" long long lsnFusionTickTriangleCapacity(const LsnFusion *p) { return p ? 2 * p->cap : 0; }
 
@@ -415,33 +460,23 @@ int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void 
         return -1;
     // vertices + depth_to_vertices_map (count / scan / write launches)
     if (lsn::run_locked(p, d_depth, d_colors, d_vertices, d_offsets, s, true, hooks)) return -1;
-    TriArgs t;
-    t.frames = p->frames.as<FrameDesc>();
-    t.tiles = p->tile_frame.as<TileDesc>();
-    t.depth = static_cast<const unsigned short *>(d_depth);
-    t.pixmap = p->pixmap.as<int>();
-    t.pm_first = p->pm_first.as<int>();
-    t.pm_mask = p->pm_mask.as<unsigned char>();
-    t.tri = static_cast<int *>(d_triangles);
-    t.tile_counts = p->tri_counts.as<int>();
-    t.codes = p->tri_codes.as<unsigned int>();
-    t.tiles_per_tick = p->tiles_per_tick;
-    static const int win_env = getenv("LSN_TRI_WINDOW") ? atoi(getenv("LSN_TRI_WINDOW")) : kTriWinDefault;
-    t.win = std::min(4096, std::max(256, win_env)) & ~15;
-    const size_t stage_bytes = sizeof(int) * (size_t)(stage_ints(t.win) + 3 * 64);
-    t.tick_pix_stride = p->cap;
-    t.tick_tri_stride = 2 * p->cap;
-    const bool vec = p->pixmap_compact && ((uintptr_t)d_depth & 15) == 0;   // the vertex pass above wrote the compact map iff it ran its wide-load form
-    const int grid = p->tiles_per_tick * p->n_ticks;
-    if (vec) hipLaunchKernelGGL((tri_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, t);
-    else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, t.tile_counts, t.tiles_per_tick, t.frames, p->n_maps,
-                       d_tri_offsets);
-    if (hooks && hooks->h_tri_offsets)
-        LSN_HIP(hipMemcpyAsync(hooks->h_tri_offsets, d_tri_offsets, sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1), hipMemcpyDeviceToHost, s));
-    if (hooks && hooks->tri_counted) LSN_HIP(hipEventRecord(hooks->tri_counted, s));
-    if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
-    else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
-    LSN_HIP(hipGetLastError());
-    return 0;
+    return triangle_passes(p, d_depth, d_triangles, d_tri_offsets, s, hooks);
 }
+
+int lsn::run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, hipStream_t s)
+{
+    if (!p || !d_depth || !d_triangles || !d_tri_offsets) {
+        lsn::set_error("run_triangles: null argument");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    if (p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks) ||
+        p->tri_codes.reserve(sizeof(unsigned int) * (size_t)p->tiles_per_tick * p->n_ticks * kThreads))
+        return -1;
+    lsn::RunHooks hooks;
+    hooks.mirror = tri_mirror != nullptr;
+    hooks.h_tri_offsets = tri_mirror;
+    return triangle_passes(p, d_depth, d_triangles, d_tri_offsets, s, &hooks);
+}
+

@@ -146,12 +146,15 @@ def test_public_header_is_plain_c_and_cpp():
 
 
 @pytest.mark.gpu
-def test_merge_and_single_sensor_calls_from_two_threads(gpu, orc):
+@pytest.mark.parametrize("n_sensors", [4, 1])
+def test_merge_and_single_sensor_calls_from_two_threads(gpu, orc, n_sensors):
     """LiveScanServer's updateWorker (merge calls) and refineWorker (single-sensor calls) run concurrently (MainWindowForm.cs:238,304):
-    the two families have their own lanes (streams, buffers, lock) inside the library; every result must be the oracle's."""
+    the two families have their own lanes (streams, buffers, lock, PLANS) inside the library; every result must be the oracle's.
+    One sensor: generateMeshFromDepthMaps(n_maps = 1) and generateVerticesFromDepthMap(index 0) describe the same geometry -- a plan
+    table shared between the lanes would hand both the same plan and run it on two streams at once."""
     import threading
     from livescan3d_amd import synth
-    rig = synth.make_rig("scene", 4, 256, 212, seed=41, bounds=synth.CROP_BOUNDS)
+    rig = synth.make_rig("scene", n_sensors, 256, 212, seed=41, bounds=synth.CROP_BOUNDS)
     want_v, counts, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
     edges = np.concatenate([[0], np.cumsum(counts)])
     errors = []
@@ -167,7 +170,7 @@ def test_merge_and_single_sensor_calls_from_two_threads(gpu, orc):
     def singles():
         try:
             for rep in range(12):
-                i = rep % 4
+                i = rep % n_sensors
                 v = native.generate_vertices_from_depth_map(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, i)
                 assert v.tobytes() == want_v[edges[i]:edges[i + 1]].tobytes()
         except Exception as ex:  # noqa: BLE001

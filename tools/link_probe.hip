@@ -109,6 +109,21 @@ int main()
                 printf("A %9zu B  kernel %s 16-B stores, %4d wgs : %7.1f us  %5.1f GB/s (wall %7.1f us)%s\n", n, nt ? "nt   " : "plain", wgs,
                        bestk * 1e3, n / (bestk * 1e-3) / 1e9, bestw * 1e6, ok ? "" : "  HOST DOES NOT SEE THE DATA");
             }
+        for (int shift : {1, 2, 3}) {
+            // the same stores, every wave's 1 KB starting 16 / 32 / 48 bytes past a 64-byte line (what a compaction's output looks like)
+            float bestk = 1e9f;
+            for (int r = 0; r < 8; r++) {
+                CK(hipEventRecord(e0, sa));
+                store_kernel<1><<<1024, 256, 0, sa>>>((uint4 *)pin + shift, n16 - 4, r);
+                CK(hipEventRecord(e1, sa));
+                CK(hipStreamSynchronize(sa));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                bestk = std::min(bestk, ms);
+            }
+            printf("A %9zu B  kernel nt    16-B stores, 1024 wgs, runs shifted by %2d B: %7.1f us  %5.1f GB/s\n", n, 16 * shift, bestk * 1e3,
+                   n / (bestk * 1e-3) / 1e9);
+        }
         float bestk = 1e9f;
         for (int r = 0; r < 8; r++) {
             CK(hipEventRecord(e0, sa));
@@ -136,6 +151,15 @@ int main()
         }
         printf("B %9zu B  pageable H2D: call returns after %7.1f us, done after %7.1f us  %5.1f GB/s\n", n, best_call * 1e6, best_done * 1e6,
                n / best_done / 1e9);
+    }
+    for (size_t n : {up_depth, up_depth + up_col, 3 * up_depth, 3 * up_col}) {
+        double best = 1e9;
+        for (int r = 0; r < 20; r++) {
+            double t0 = now();
+            CK(hipMemcpyWithStream(d2, pageable, n, hipMemcpyHostToDevice, sa));
+            best = std::min(best, now() - t0);
+        }
+        printf("B %9zu B  pageable hipMemcpyWithStream H2D: %7.1f us  %5.1f GB/s\n", n, best * 1e6, n / best / 1e9);
     }
     {
         // the same 8.7 MB as 16 copies back to back on one stream
@@ -210,6 +234,70 @@ int main()
             best = std::min(best, t1 - t0);
         }
         printf("D launch + record + wait + launch (two streams): host %6.2f us per hand-over\n", best * 1e6 / 50);
+    }
+
+    // ---- F: does a small kernel on another stream run WHILE a kernel streams to host memory? -------------------------------------
+    {
+        hipEvent_t ea, eb, ec, e_nosys;
+        CK(hipEventCreate(&ea));
+        CK(hipEventCreate(&eb));
+        CK(hipEventCreateWithFlags(&ec, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&e_nosys, hipEventDisableTiming | hipEventDisableSystemFence));
+        const size_t n16 = down_noise / 16;
+        for (int variant = 0; variant < 5; variant++) {
+            // 0: tiny kernel alone on sb while sa streams;  1: tiny kernel behind a wait for an (already complete) event of sa;
+            // 2: the same with an event created with hipEventDisableSystemFence;  3: tiny kernel that stores 64 B to HOST memory;
+            // 4: three tiny kernels back to back on sb
+            double best_small = 1e9, best_all = 1e9;
+            for (int r = 0; r < 6; r++) {
+                CK(hipStreamSynchronize(sa));
+                CK(hipStreamSynchronize(sb));
+                if (variant == 1) { empty_kernel<<<1, 64, 0, sa>>>(); CK(hipEventRecord(ec, sa)); }
+                if (variant == 2) { empty_kernel<<<1, 64, 0, sa>>>(); CK(hipEventRecord(e_nosys, sa)); }
+                double t0 = now();
+                store_kernel<1><<<1024, 256, 0, sa>>>((uint4 *)pin, n16, r);
+                // give the big kernel a head start so that it is streaming when the small one is dispatched
+                while (now() - t0 < 40e-6) {}
+                if (variant == 1) CK(hipStreamWaitEvent(sb, ec, 0));
+                if (variant == 2) CK(hipStreamWaitEvent(sb, e_nosys, 0));
+                if (variant == 3) store_kernel<0><<<1, 4, 0, sb>>>((uint4 *)(pin + (48 << 20)), 4, r);
+                else load_kernel<<<4, 256, 0, sb>>>((const uint4 *)d, 4096, sink);
+                if (variant == 4) { load_kernel<<<4, 256, 0, sb>>>((const uint4 *)d, 4096, sink); load_kernel<<<4, 256, 0, sb>>>((const uint4 *)d, 4096, sink); }
+                CK(hipStreamSynchronize(sb));
+                double t1 = now();
+                CK(hipStreamSynchronize(sa));
+                double t2 = now();
+                best_small = std::min(best_small, t1 - t0);
+                best_all = std::min(best_all, t2 - t0);
+            }
+            const char *names[] = {"tiny kernel", "tiny kernel behind a stream-wait (default event)", "tiny kernel behind a stream-wait (no-system-fence event)",
+                                   "tiny kernel storing 64 B to host", "three tiny kernels"};
+            printf("F while 15.1 MB stream to the host on another stream: %-58s done after %7.1f us (big kernel: %7.1f us)\n", names[variant],
+                   best_small * 1e6, best_all * 1e6);
+        }
+        // G: the 15.1 MB as two kernels on two streams at once
+        double best = 1e9;
+        for (int r = 0; r < 6; r++) {
+            CK(hipStreamSynchronize(sa));
+            CK(hipStreamSynchronize(sb));
+            double t0 = now();
+            store_kernel<1><<<512, 256, 0, sa>>>((uint4 *)pin, n16 / 2, r);
+            store_kernel<1><<<512, 256, 0, sb>>>((uint4 *)pin + n16 / 2, n16 / 2, r);
+            CK(hipStreamSynchronize(sa));
+            CK(hipStreamSynchronize(sb));
+            best = std::min(best, now() - t0);
+        }
+        printf("G 15.1 MB as two store kernels on two streams at once: %7.1f us\n", best * 1e6);
+        // H: four store kernels of 3.77 MB back to back on ONE stream (the bubbles between dependent launches)
+        best = 1e9;
+        for (int r = 0; r < 6; r++) {
+            CK(hipStreamSynchronize(sa));
+            double t0 = now();
+            for (int q = 0; q < 4; q++) store_kernel<1><<<512, 256, 0, sa>>>((uint4 *)pin + q * (n16 / 4), n16 / 4, r);
+            CK(hipStreamSynchronize(sa));
+            best = std::min(best, now() - t0);
+        }
+        printf("H 15.1 MB as four store kernels back to back on one stream: %7.1f us\n", best * 1e6);
     }
 
     // ---- E: zero-copy upload from a registered caller array --------------------------------------------------------------------
