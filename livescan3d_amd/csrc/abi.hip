@@ -8,22 +8,26 @@
 // not hold up the merge calls (LiveScanServer runs them on two BackgroundWorkers, MainWindowForm.cs:238,304).
 //
 // A merge call is PCIe-bound (8 x 512x424: 8.7 MB up, 15-35 MB down, against ~30 us of kernels), so the call is laid out around the
-// link (round 4; numbers from tools/link_probe.hip on the MI355X box):
+// link (round 4; numbers from tools/link_probe.hip on the MI355X box, DESIGN.md "host path"):
 //   * OUTPUT: the write kernels store the vertices and the triangles STRAIGHT INTO the pinned host blocks that become
 //     Mesh::vertices / Mesh::triangles (hipHostMalloc memory is device-visible).  16-byte stores of consecutive lanes cross the
 //     link at the rate of the copy engine (55 GB/s), but need no length in advance -- so there is no count round trip, no
 //     download to issue, and the bytes start to leave as soon as the first sensors have been fused;
 //   * INPUT: the caller's arrays are pageable (C# pins them, the runtime does not know).  A pageable hipMemcpy of >= 1 MiB pins the
 //     pages in place and runs at ~52 GB/s but keeps the calling thread until it is done; below 1 MiB the runtime stages through a
-//     bounce buffer at ~15 GB/s.  So the sensors go up in GROUPS whose depth and colour copies both reach 1 MiB (three 512x424
-//     sensors), each group on the upload stream, blocking; the group's kernels are launched behind it and store to the host while
-//     the next group is on its way up -- both directions of the link are busy at once;
-//   * a group has its own plan (its own scratch, thresholds, radial tables); its vertex / triangle prefixes start where the
-//     previous group's ended (scan_kernel's carry), so all groups write one contiguous mesh in formMesh's order;
+//     bounce buffer at ~15 GB/s.  So the frames go up in runs of >= 1 MiB (make_schedule), and a GROUP of sensors is launched the
+//     moment its frames are there, storing to the host while the next run is on its way up -- both directions of the link busy;
+//   * while a kernel streams to host memory NO other kernel completes, on any stream (probe F: a 4-workgroup kernel launched beside a
+//     15 MB store kernel finishes with it), and every dependent launch between two storing kernels is time in which nothing
+//     crosses the link.  So a group is ONE launch: the single-pass form of the fusion (fuse_kernel<4>: a tile keeps its vertices
+//     in registers, publishes its count, finds its offset by look-back -- over the tiles of the earlier groups too), no count
+//     kernel, no scan; the triangle passes run once, behind the last group, over the whole tick;
+//   * calls that START WITH THE RADIAL CORRECTION (lsnCorrectAndGenerateMesh) keep round 3's flow -- output in HBM, copy engine
+//     home behind the count: ~100 us of latency-bound closing rounds per group cannot hide behind the previous group's stores
+//     (same probe), measured 1.32 against 1.17 ms;
 //   * registering the caller's arrays (hipHostRegister) was measured again: 1.4 ms to register 8.7 MB, copies from registered
 //     memory 43 GB/s, kernel loads from it 40 GB/s -- slower than the pageable copy.  The cache stays OFF unless $LSN_HOST_REGISTER=1.
-// $LSN_HOST_PATH=copy selects round 3's flow (device-resident output + copy engine, download behind the count) for A/B runs;
-// $LSN_HOST_GROUP=n fixes the sensors per group.
+// $LSN_HOST_PATH=copy selects round 3's flow for every call (A/B runs); $LSN_HOST_GROUP=n fixes the sensors per group.
 #include "lsn_common.hpp"
 
 #include <atomic>
@@ -67,6 +71,7 @@ void test_fault_point(int kind)
 
 }  // namespace lsn
 
+// (not routed through lsn::guarded: nothing in here can throw, and reading the message must not disturb it)
 extern "C" int lsnGetLastError(char *buf, int len)
 {
     const char *s = lsn::error_buffer();
@@ -74,7 +79,7 @@ extern "C" int lsnGetLastError(char *buf, int len)
     return (int)strlen(s);
 }
 
-extern "C" int lsnDeviceCount(void)
+static int lsnDeviceCount_impl(void)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -84,9 +89,14 @@ extern "C" int lsnDeviceCount(void)
     return n;
 }
 
+extern "C" int lsnDeviceCount(void)
+{
+    return lsn::guarded<int>("lsnDeviceCount", static_cast<int>(-1), [&]() { return lsnDeviceCount_impl(); });
+}
+
 // ---- device memory / streams for hosts without a HIP of their own ------------------------------------------------------------
 
-extern "C" void *lsnDeviceMalloc(int device, long long bytes)
+static void * lsnDeviceMalloc_impl(int device, long long bytes)
 {
     lsn::clear_error();
     if (bytes <= 0) {
@@ -99,7 +109,12 @@ extern "C" void *lsnDeviceMalloc(int device, long long bytes)
     return p;
 }
 
-extern "C" int lsnDeviceFree(int device, void *d_ptr)
+extern "C" void * lsnDeviceMalloc(int device, long long bytes)
+{
+    return lsn::guarded<void *>("lsnDeviceMalloc", static_cast<void *>(nullptr), [&]() { return lsnDeviceMalloc_impl(device, bytes); });
+}
+
+static int lsnDeviceFree_impl(int device, void *d_ptr)
 {
     lsn::clear_error();
     if (!d_ptr) return 0;
@@ -108,7 +123,12 @@ extern "C" int lsnDeviceFree(int device, void *d_ptr)
     return 0;
 }
 
-extern "C" int lsnDeviceUpload(int device, void *d_dst, const void *h_src, long long bytes, void *stream)
+extern "C" int lsnDeviceFree(int device, void *d_ptr)
+{
+    return lsn::guarded<int>("lsnDeviceFree", static_cast<int>(-1), [&]() { return lsnDeviceFree_impl(device, d_ptr); });
+}
+
+static int lsnDeviceUpload_impl(int device, void *d_dst, const void *h_src, long long bytes, void *stream)
 {
     lsn::clear_error();
     if (!d_dst || !h_src || bytes < 0) {
@@ -120,7 +140,12 @@ extern "C" int lsnDeviceUpload(int device, void *d_dst, const void *h_src, long 
     return 0;
 }
 
-extern "C" int lsnDeviceDownload(int device, void *h_dst, const void *d_src, long long bytes, void *stream)
+extern "C" int lsnDeviceUpload(int device, void *d_dst, const void *h_src, long long bytes, void *stream)
+{
+    return lsn::guarded<int>("lsnDeviceUpload", static_cast<int>(-1), [&]() { return lsnDeviceUpload_impl(device, d_dst, h_src, bytes, stream); });
+}
+
+static int lsnDeviceDownload_impl(int device, void *h_dst, const void *d_src, long long bytes, void *stream)
 {
     lsn::clear_error();
     if (!h_dst || !d_src || bytes < 0) {
@@ -132,7 +157,12 @@ extern "C" int lsnDeviceDownload(int device, void *h_dst, const void *d_src, lon
     return 0;
 }
 
-extern "C" void *lsnStreamCreate(int device)
+extern "C" int lsnDeviceDownload(int device, void *h_dst, const void *d_src, long long bytes, void *stream)
+{
+    return lsn::guarded<int>("lsnDeviceDownload", static_cast<int>(-1), [&]() { return lsnDeviceDownload_impl(device, h_dst, d_src, bytes, stream); });
+}
+
+static void * lsnStreamCreate_impl(int device)
 {
     lsn::clear_error();
     LSN_HIP_NULL(hipSetDevice(device));
@@ -141,7 +171,12 @@ extern "C" void *lsnStreamCreate(int device)
     return s;
 }
 
-extern "C" int lsnStreamDestroy(int device, void *stream)
+extern "C" void * lsnStreamCreate(int device)
+{
+    return lsn::guarded<void *>("lsnStreamCreate", static_cast<void *>(nullptr), [&]() { return lsnStreamCreate_impl(device); });
+}
+
+static int lsnStreamDestroy_impl(int device, void *stream)
 {
     lsn::clear_error();
     if (!stream) return 0;
@@ -150,12 +185,22 @@ extern "C" int lsnStreamDestroy(int device, void *stream)
     return 0;
 }
 
-extern "C" int lsnStreamSynchronize(int device, void *stream)
+extern "C" int lsnStreamDestroy(int device, void *stream)
+{
+    return lsn::guarded<int>("lsnStreamDestroy", static_cast<int>(-1), [&]() { return lsnStreamDestroy_impl(device, stream); });
+}
+
+static int lsnStreamSynchronize_impl(int device, void *stream)
 {
     lsn::clear_error();
     LSN_HIP(hipSetDevice(device));
     LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
     return 0;
+}
+
+extern "C" int lsnStreamSynchronize(int device, void *stream)
+{
+    return lsn::guarded<int>("lsnStreamSynchronize", static_cast<int>(-1), [&]() { return lsnStreamSynchronize_impl(device, stream); });
 }
 
 namespace {
@@ -219,7 +264,6 @@ struct Ctx {
     // pinned host blocks handed out as Mesh::vertices, recycled by deleteMesh
     std::unordered_map<void *, size_t> live;          // ptr -> capacity (bytes)
     std::multimap<size_t, void *> pool;               // capacity -> ptr
-    std::unordered_map<void *, int> live_tri;         // triangles arrays we own
     std::mutex wire_mu;       // the packer and its output buffer (lsnLastMesh*)
     LsnTransfer *xfer = nullptr;
     int xfer_v = 0, xfer_t = 0;
@@ -384,17 +428,17 @@ void pinned_put(Ctx &c, void *p)
     else c.pool.emplace(cap, p);
 }
 
-void empty_mesh(Ctx &c, Mesh *m)
+// The reference hands out `new int[0]` when a mesh has no triangles (depthprocessing.cpp:1640): a valid pointer that is never
+// dereferenced (KinectServer.cs:344-345).  Here it is one static word: nothing to allocate, nothing to track, and deleteMesh leaves it
+// alone like every pointer it does not own.
+int g_no_triangles[1] = {0};
+
+void empty_mesh(Mesh *m) noexcept
 {
     m->nVertices = 0;
     m->vertices = nullptr;
     m->nTriangles = 0;
-    int *tri = (int *)malloc(sizeof(int));  // "new int[0]": valid, never dereferenced (KinectServer.cs:344-345)
-    m->triangles = tri;
-    if (tri) {
-        std::lock_guard<std::mutex> tg(c.tab_mu);
-        c.live_tri[tri] = 1;
-    }
+    m->triangles = g_no_triangles;
 }
 
 // The lane's cached single-tick plan for sensors [first, first + count) of a call.  The lane's lock is held.
@@ -582,16 +626,7 @@ int fuse_host_copy(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsig
     out->nVertices = nv;
     out->vertices = static_cast<VertexC4ubV3f *>(host);
     out->nTriangles = nt;
-    if (nt > 0) {
-        out->triangles = static_cast<int *>(host_tri);
-    } else {
-        int *tri = (int *)malloc(sizeof(int));  // "new int[0]": valid, never dereferenced (KinectServer.cs:344-345)
-        out->triangles = tri;
-        if (tri) {
-            std::lock_guard<std::mutex> tg(c.tab_mu);
-            c.live_tri[tri] = 1;
-        }
-    }
+    out->triangles = nt > 0 ? static_cast<int *>(host_tri) : g_no_triangles;
     c.last_lane.store(&l);
     return 0;
 }
@@ -831,15 +866,9 @@ int fuse_host_direct(Ctx &c, Lane &l, const unsigned char *depth_maps, const uns
         lsn::set_error("NativeUtils: device returned impossible counts (%d vertices, %d triangles)", nv, nt);
         return fail();
     }
-    int *tri = nullptr;
     if (nt == 0) {
         if (host_tri) pinned_put(c, host_tri);
         host_tri = nullptr;
-        tri = (int *)malloc(sizeof(int));  // "new int[0]": valid, never dereferenced (KinectServer.cs:344-345)
-        if (tri) {
-            std::lock_guard<std::mutex> tg(c.tab_mu);
-            c.live_tri[tri] = 1;
-        }
     }
     l.last_nv = nv;
     l.last_nt = nt;
@@ -849,7 +878,7 @@ int fuse_host_direct(Ctx &c, Lane &l, const unsigned char *depth_maps, const uns
     out->nVertices = nv;
     out->vertices = static_cast<VertexC4ubV3f *>(host);
     out->nTriangles = nt;
-    out->triangles = nt > 0 ? static_cast<int *>(host_tri) : tri;
+    out->triangles = nt > 0 ? static_cast<int *>(host_tri) : g_no_triangles;
     c.last_lane.store(&l);
     tr.mark("done");
     tr.print();
@@ -898,7 +927,7 @@ int fuse_host(Ctx &c, Lane &l, int n_maps_known, const unsigned char *depth_maps
 
 }  // namespace
 
-extern "C" void generateVerticesFromDepthMap(unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+static void generateVerticesFromDepthMap_impl(unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
                                              float *intr_params, float *wtransform_params, Mesh *out_mesh, float minX, float minY,
                                              float minZ, float maxX, float maxY, float maxZ, int depth_map_index)
 {
@@ -909,16 +938,24 @@ extern "C" void generateVerticesFromDepthMap(unsigned char *depth_maps, unsigned
     std::lock_guard<std::mutex> g(l.mu);
     if (!depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params || depth_map_index < 0) {
         lsn::set_error("generateVerticesFromDepthMap: bad arguments");
-        empty_mesh(c, out_mesh);
+        empty_mesh(out_mesh);
         return;
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
     if (ensure_ready(c) || fuse_host(c, l, depth_map_index + 1, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params,
                                      out_mesh, b, depth_map_index, 1, false))
-        empty_mesh(c, out_mesh);
+        empty_mesh(out_mesh);
 }
 
-extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+extern "C" void generateVerticesFromDepthMap(unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+                                             float *intr_params, float *wtransform_params, Mesh *out_mesh, float minX, float minY,
+                                             float minZ, float maxX, float maxY, float maxZ, int depth_map_index)
+{
+    const bool done = lsn::guarded<bool>("generateVerticesFromDepthMap", false, [&]() { generateVerticesFromDepthMap_impl(depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, minX, minY, minZ, maxX, maxY, maxZ, depth_map_index); return true; });
+    if (!done && out_mesh) empty_mesh(out_mesh);   // nothing reaches the caller but an empty mesh and the message
+}
+
+static void generateMeshFromDepthMaps_impl(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
                                           float *intr_params, float *wtransform_params, Mesh *out_mesh, bool bcolor_transfer, float minX,
                                           float minY, float minZ, float maxX, float maxY, float maxZ, bool bgenerate_triangles)
 {
@@ -929,13 +966,13 @@ extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps,
     std::lock_guard<std::mutex> g(l.mu);
     if (n_maps <= 0 || !depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params) {
         if (n_maps != 0) lsn::set_error("generateMeshFromDepthMaps: bad arguments");
-        empty_mesh(c, out_mesh);
+        empty_mesh(out_mesh);
         return;
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
     if (ensure_ready(c) ||
         fuse_host(c, l, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps, true)) {
-        empty_mesh(c, out_mesh);
+        empty_mesh(out_mesh);
         return;
     }
     if (bcolor_transfer || bgenerate_triangles) {
@@ -953,7 +990,15 @@ extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps,
     }
 }
 
-extern "C" void lsnCorrectAndGenerateMesh(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+extern "C" void generateMeshFromDepthMaps(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+                                          float *intr_params, float *wtransform_params, Mesh *out_mesh, bool bcolor_transfer, float minX,
+                                          float minY, float minZ, float maxX, float maxY, float maxZ, bool bgenerate_triangles)
+{
+    const bool done = lsn::guarded<bool>("generateMeshFromDepthMaps", false, [&]() { generateMeshFromDepthMaps_impl(n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, bcolor_transfer, minX, minY, minZ, maxX, maxY, maxZ, bgenerate_triangles); return true; });
+    if (!done && out_mesh) empty_mesh(out_mesh);   // nothing reaches the caller but an empty mesh and the message
+}
+
+static void lsnCorrectAndGenerateMesh_impl(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
                                           float *intr_params, float *wtransform_params, Mesh *out_mesh, float minX, float minY, float minZ,
                                           float maxX, float maxY, float maxZ, int write_back_corrected)
 {
@@ -964,16 +1009,24 @@ extern "C" void lsnCorrectAndGenerateMesh(int n_maps, unsigned char *depth_maps,
     std::lock_guard<std::mutex> g(l.mu);
     if (n_maps <= 0 || !depth_maps || !depth_colors || !widths || !heights || !intr_params || !wtransform_params) {
         if (n_maps != 0) lsn::set_error("lsnCorrectAndGenerateMesh: bad arguments");
-        empty_mesh(c, out_mesh);
+        empty_mesh(out_mesh);
         return;
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
     if (ensure_ready(c) || fuse_host(c, l, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps,
                                      true, true, write_back_corrected ? depth_maps : nullptr, write_back_corrected ? depth_colors : nullptr))
-        empty_mesh(c, out_mesh);
+        empty_mesh(out_mesh);
 }
 
-extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
+extern "C" void lsnCorrectAndGenerateMesh(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths, int *heights,
+                                          float *intr_params, float *wtransform_params, Mesh *out_mesh, float minX, float minY, float minZ,
+                                          float maxX, float maxY, float maxZ, int write_back_corrected)
+{
+    const bool done = lsn::guarded<bool>("lsnCorrectAndGenerateMesh", false, [&]() { lsnCorrectAndGenerateMesh_impl(n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, minX, minY, minZ, maxX, maxY, maxZ, write_back_corrected); return true; });
+    if (!done && out_mesh) empty_mesh(out_mesh);   // nothing reaches the caller but an empty mesh and the message
+}
+
+static void depthMapAndColorSetRadialCorrection_impl(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
                                                     int *heights, float *intr_params)
 {
     lsn::clear_error();
@@ -1014,35 +1067,39 @@ extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *d
     }
 }
 
-extern "C" Mesh *createMesh(void)
+extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
+                                                    int *heights, float *intr_params)
+{
+    lsn::guarded_void("depthMapAndColorSetRadialCorrection", [&]() { depthMapAndColorSetRadialCorrection_impl(n_maps, depth_maps, depth_colors, widths, heights, intr_params); });
+}
+
+static Mesh * createMesh_impl(void)
 {
     Mesh *m = (Mesh *)calloc(1, sizeof(Mesh));  // zeroed like depthprocessing.cpp:1820-1825
     return m;
 }
 
-extern "C" void deleteMesh(Mesh *mesh)
+extern "C" Mesh * createMesh(void)
+{
+    return lsn::guarded<Mesh *>("createMesh", static_cast<Mesh *>(nullptr), [&]() { return createMesh_impl(); });
+}
+
+static void deleteMesh_impl(Mesh *mesh)
 {
     if (!mesh) return;
     Ctx &c = ctx();
-    if (mesh->triangles) {
-        bool plain = false;
-        {
-            std::lock_guard<std::mutex> tg(c.tab_mu);
-            auto it = c.live_tri.find(mesh->triangles);
-            if (it != c.live_tri.end()) {
-                c.live_tri.erase(it);
-                plain = true;
-            }
-        }
-        if (plain) free(mesh->triangles);
-        else pinned_put(c, mesh->triangles);  // a pinned block of ours, or not ours at all (then left alone)
-    }
+    if (mesh->triangles) pinned_put(c, mesh->triangles);   // a pinned block of ours; the static empty array or a foreign pointer is left alone
     if (mesh->vertices) pinned_put(c, mesh->vertices);
     mesh->triangles = nullptr;
     mesh->vertices = nullptr;
 }
 
-extern "C" float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2, float *R, float *t, int maxIter)
+extern "C" void deleteMesh(Mesh *mesh)
+{
+    lsn::guarded_void("deleteMesh", [&]() { deleteMesh_impl(mesh); });
+}
+
+static float ICP_impl(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2, float *R, float *t, int maxIter)
 {
     lsn::clear_error();
     const float error = 1.0f;  // icp.cpp:85,176
@@ -1079,19 +1136,30 @@ extern "C" float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2,
     if (lsnIcpRun(c.icp, c.d_v1.as<float>(), nVerts1, c.d_v2.as<float>(), nVerts2, c.d_Rt.as<float>(), c.d_Rt.as<float>() + 9, maxIter,
                   nn_mode, c.icp_stream))
         return fail();
-    // results go to a scratch first so that the caller's buffers stay untouched when anything fails
-    std::vector<float> v2((size_t)nVerts2 * 3);
-    float Rt[12];
-    if (hipMemcpyAsync(v2.data(), c.d_v2.p, sizeof(float) * 3 * (size_t)nVerts2, hipMemcpyDeviceToHost, c.icp_stream) != hipSuccess ||
+    // results go to a scratch first so that the caller's buffers stay untouched when anything fails: a pinned block of the pool
+    // (recycled call after call; the download runs as DMA into it)
+    const size_t v2_bytes = sizeof(float) * 3 * (size_t)nVerts2;
+    float *v2 = static_cast<float *>(pinned_get(c, v2_bytes + sizeof(float) * 12));
+    if (!v2) return fail();
+    float *Rt = v2 + (size_t)nVerts2 * 3;
+    if (hipMemcpyAsync(v2, c.d_v2.p, v2_bytes, hipMemcpyDeviceToHost, c.icp_stream) != hipSuccess ||
         hipMemcpyAsync(Rt, c.d_Rt.p, sizeof(float) * 12, hipMemcpyDeviceToHost, c.icp_stream) != hipSuccess ||
         hipStreamSynchronize(c.icp_stream) != hipSuccess) {
         lsn::set_error("ICP: download failed: %s", hipGetErrorString(hipGetLastError()));
+        (void)hipStreamSynchronize(c.icp_stream);
+        pinned_put(c, v2);
         return fail();
     }
-    memcpy(verts2, v2.data(), sizeof(float) * 3 * (size_t)nVerts2);
+    memcpy(verts2, v2, v2_bytes);
     memcpy(R, Rt, sizeof(float) * 9);
     memcpy(t, Rt + 9, sizeof(float) * 3);
+    pinned_put(c, v2);
     return error;
+}
+
+extern "C" float ICP(Point3f *verts1, Point3f *verts2, int nVerts1, int nVerts2, float *R, float *t, int maxIter)
+{
+    return lsn::guarded<float>("ICP", 1.0f, [&]() { return ICP_impl(verts1, verts2, nVerts1, nVerts2, R, t, maxIter); });
 }
 
 // ---- the outbound formats of the mesh the last merge call left in HBM (include/NativeUtils.h part 3) ----------------------------
@@ -1139,7 +1207,7 @@ long long last_mesh_bytes(Ctx &c, Lane &l, int kind, unsigned char *out, long lo
 }
 }  // namespace
 
-extern "C" long long lsnLastMeshTransferFrame(unsigned char *out, long long out_cap)
+static long long lsnLastMeshTransferFrame_impl(unsigned char *out, long long out_cap)
 {
     lsn::clear_error();
     Ctx &c = ctx();
@@ -1149,7 +1217,12 @@ extern "C" long long lsnLastMeshTransferFrame(unsigned char *out, long long out_
     return last_mesh_bytes(c, *l, 0, out, out_cap);
 }
 
-extern "C" long long lsnLastMeshPly(unsigned char *out, long long out_cap)
+extern "C" long long lsnLastMeshTransferFrame(unsigned char *out, long long out_cap)
+{
+    return lsn::guarded<long long>("lsnLastMeshTransferFrame", static_cast<long long>(-1), [&]() { return lsnLastMeshTransferFrame_impl(out, out_cap); });
+}
+
+static long long lsnLastMeshPly_impl(unsigned char *out, long long out_cap)
 {
     lsn::clear_error();
     Ctx &c = ctx();
@@ -1157,4 +1230,9 @@ extern "C" long long lsnLastMeshPly(unsigned char *out, long long out_cap)
     if (!l) l = &c.merge;
     std::lock_guard<std::mutex> g(l->mu);
     return last_mesh_bytes(c, *l, 1, out, out_cap);
+}
+
+extern "C" long long lsnLastMeshPly(unsigned char *out, long long out_cap)
+{
+    return lsn::guarded<long long>("lsnLastMeshPly", static_cast<long long>(-1), [&]() { return lsnLastMeshPly_impl(out, out_cap); });
 }

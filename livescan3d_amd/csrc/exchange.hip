@@ -291,11 +291,17 @@ __global__ __launch_bounds__(kThreads, 8) void recon_kernel(const FuseArgs a, co
 
 extern "C" int lsnFusionTilesPerTick(const LsnFusion *p) { return p ? p->tiles_per_tick : 0; }
 
-extern "C" int lsnFusionPackSurvivors(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
+static int lsnFusionPackSurvivors_impl(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
                                       int *d_tile_prefix, int *d_offsets, void *stream)
 {
     lsn::clear_error();
     return lsn::pack_survivors(p, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, nullptr, stream);
+}
+
+extern "C" int lsnFusionPackSurvivors(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
+                                      int *d_tile_prefix, int *d_offsets, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionPackSurvivors", static_cast<int>(-1), [&]() { return lsnFusionPackSurvivors_impl(p, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, stream); });
 }
 
 // Survivor exchange, sender side: count + scan as in lsnFusionRun, then the compact streams instead of vertices.
@@ -323,7 +329,7 @@ int lsn::pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors,
     FuseArgs a;
     fill_args(p, a, d_depth, d_colors, nullptr, d_offsets);
     launch_count(p, true, s, a);
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames, a.offsets, nullptr, nullptr);
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames, a.offsets, nullptr);
     PackArgs pk;
     pk.mask = static_cast<unsigned char *>(d_mask);
     pk.depth_c = static_cast<unsigned short *>(d_depth_c);
@@ -340,7 +346,7 @@ int lsn::pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors,
 
 // Survivor exchange, receiver side: `all` is a plan over the WHOLE rig (every sensor, lsnFusionSetParams called with all
 // parameters, same n_ticks); the gathered arrays hold n_shards equally shaped shards of maps_per_shard sensors each.
-extern "C" int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
+static int lsnFusionReconstruct_impl(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
                                     const void *d_rgb_c, long long slab, const int *d_tile_prefix, const int *d_shard_offsets,
                                     void *d_merged, int *d_merged_offsets, void *stream)
 {
@@ -349,7 +355,14 @@ extern "C" int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_s
                             d_merged_offsets, nullptr, stream);
 }
 
-extern "C" int lsnFusionPackSurvivorsRun(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
+extern "C" int lsnFusionReconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
+                                    const void *d_rgb_c, long long slab, const int *d_tile_prefix, const int *d_shard_offsets,
+                                    void *d_merged, int *d_merged_offsets, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionReconstruct", static_cast<int>(-1), [&]() { return lsnFusionReconstruct_impl(all, n_shards, maps_per_shard, d_masks, d_depth_c, d_rgb_c, slab, d_tile_prefix, d_shard_offsets, d_merged, d_merged_offsets, stream); });
+}
+
+static int lsnFusionPackSurvivorsRun_impl(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
                                          int *d_tile_prefix, int *d_offsets, int *d_tick_base, void *stream)
 {
     lsn::clear_error();
@@ -360,7 +373,13 @@ extern "C" int lsnFusionPackSurvivorsRun(LsnFusion *p, const void *d_depth, cons
     return lsn::pack_survivors(p, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, d_tick_base, stream);
 }
 
-extern "C" int lsnFusionReconstructRun(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
+extern "C" int lsnFusionPackSurvivorsRun(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c,
+                                         int *d_tile_prefix, int *d_offsets, int *d_tick_base, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionPackSurvivorsRun", static_cast<int>(-1), [&]() { return lsnFusionPackSurvivorsRun_impl(p, d_depth, d_colors, d_mask, d_depth_c, d_rgb_c, d_tile_prefix, d_offsets, d_tick_base, stream); });
+}
+
+static int lsnFusionReconstructRun_impl(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
                                        const void *d_rgb_c, long long run_len, const int *d_tile_prefix, const int *d_shard_offsets,
                                        void *d_merged, int *d_merged_offsets, int *d_tick_base_scratch, void *stream)
 {
@@ -371,6 +390,13 @@ extern "C" int lsnFusionReconstructRun(LsnFusion *all, int n_shards, int maps_pe
     }
     return lsn::reconstruct(all, n_shards, maps_per_shard, d_masks, d_depth_c, d_rgb_c, run_len, d_tile_prefix, d_shard_offsets, d_merged,
                             d_merged_offsets, d_tick_base_scratch, stream);
+}
+
+extern "C" int lsnFusionReconstructRun(LsnFusion *all, int n_shards, int maps_per_shard, const void *d_masks, const void *d_depth_c,
+                                       const void *d_rgb_c, long long run_len, const int *d_tile_prefix, const int *d_shard_offsets,
+                                       void *d_merged, int *d_merged_offsets, int *d_tick_base_scratch, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionReconstructRun", static_cast<int>(-1), [&]() { return lsnFusionReconstructRun_impl(all, n_shards, maps_per_shard, d_masks, d_depth_c, d_rgb_c, run_len, d_tile_prefix, d_shard_offsets, d_merged, d_merged_offsets, d_tick_base_scratch, stream); });
 }
 
 // d_tick_base (nullable, scratch [n_shards][n_ticks]): the gathered streams are one back-to-back run of `slab` entries per shard
@@ -439,12 +465,18 @@ int lsn::reconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const voi
     return 0;
 }
 
-extern "C" int lsnMergeShards(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap,
+static int lsnMergeShards_impl(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap,
                               const int *d_shard_offsets, void *d_merged, long long merged_cap, int *d_merged_offsets, void *stream)
 {
     lsn::clear_error();
     return lsn::merge_shards(device, n_shards, n_ticks, maps_per_shard, d_shards, shard_cap, d_shard_offsets, d_merged, merged_cap, d_merged_offsets,
                              false, stream);
+}
+
+extern "C" int lsnMergeShards(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap,
+                              const int *d_shard_offsets, void *d_merged, long long merged_cap, int *d_merged_offsets, void *stream)
+{
+    return lsn::guarded<int>("lsnMergeShards", static_cast<int>(-1), [&]() { return lsnMergeShards_impl(device, n_shards, n_ticks, maps_per_shard, d_shards, shard_cap, d_shard_offsets, d_merged, merged_cap, d_merged_offsets, stream); });
 }
 
 int lsn::merge_shards(int device, int n_shards, int n_ticks, int maps_per_shard, const void *d_shards, long long shard_cap,
@@ -626,7 +658,7 @@ struct LsnShard {
     std::mutex mu;
 };
 
-extern "C" int lsnShardUniqueId(unsigned char *id128)
+static int lsnShardUniqueId_impl(unsigned char *id128)
 {
     lsn::clear_error();
     if (!id128) return -1;
@@ -639,7 +671,12 @@ extern "C" int lsnShardUniqueId(unsigned char *id128)
     return 0;
 }
 
-extern "C" void lsnShardDestroy(LsnShard *sh)
+extern "C" int lsnShardUniqueId(unsigned char *id128)
+{
+    return lsn::guarded<int>("lsnShardUniqueId", static_cast<int>(-1), [&]() { return lsnShardUniqueId_impl(id128); });
+}
+
+static void lsnShardDestroy_impl(LsnShard *sh)
 {
     if (!sh) return;
     (void)hipSetDevice(sh->device);
@@ -654,7 +691,12 @@ extern "C" void lsnShardDestroy(LsnShard *sh)
     delete sh;
 }
 
-extern "C" LsnShard *lsnShardPrepare(int device, int rank, int world, int n_ticks, int n_maps, const int *widths, const int *heights)
+extern "C" void lsnShardDestroy(LsnShard *sh)
+{
+    lsn::guarded_void("lsnShardDestroy", [&]() { lsnShardDestroy_impl(sh); });
+}
+
+static LsnShard * lsnShardPrepare_impl(int device, int rank, int world, int n_ticks, int n_maps, const int *widths, const int *heights)
 {
     lsn::clear_error();
     if (world <= 0 || rank < 0 || rank >= world || n_ticks <= 0 || n_maps <= 0 || !widths || !heights || n_maps % world != 0) {
@@ -741,7 +783,12 @@ extern "C" LsnShard *lsnShardPrepare(int device, int rank, int world, int n_tick
     return sh;
 }
 
-extern "C" int lsnShardConnect(LsnShard *sh, const unsigned char *id128)
+extern "C" LsnShard * lsnShardPrepare(int device, int rank, int world, int n_ticks, int n_maps, const int *widths, const int *heights)
+{
+    return lsn::guarded<LsnShard *>("lsnShardPrepare", static_cast<LsnShard *>(nullptr), [&]() { return lsnShardPrepare_impl(device, rank, world, n_ticks, n_maps, widths, heights); });
+}
+
+static int lsnShardConnect_impl(LsnShard *sh, const unsigned char *id128)
 {
     lsn::clear_error();
     if (!sh || !id128) {
@@ -767,7 +814,12 @@ extern "C" int lsnShardConnect(LsnShard *sh, const unsigned char *id128)
     return 0;
 }
 
-extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsigned char *id128, int n_ticks, int n_maps, const int *widths,
+extern "C" int lsnShardConnect(LsnShard *sh, const unsigned char *id128)
+{
+    return lsn::guarded<int>("lsnShardConnect", static_cast<int>(-1), [&]() { return lsnShardConnect_impl(sh, id128); });
+}
+
+static LsnShard * lsnShardCreate_impl(int device, int rank, int world, const unsigned char *id128, int n_ticks, int n_maps, const int *widths,
                                     const int *heights)
 {
     if (!id128) {
@@ -786,7 +838,13 @@ extern "C" LsnShard *lsnShardCreate(int device, int rank, int world, const unsig
     return sh;
 }
 
-extern "C" int lsnShardRcclPath(char *buf, int len)
+extern "C" LsnShard * lsnShardCreate(int device, int rank, int world, const unsigned char *id128, int n_ticks, int n_maps, const int *widths,
+                                    const int *heights)
+{
+    return lsn::guarded<LsnShard *>("lsnShardCreate", static_cast<LsnShard *>(nullptr), [&]() { return lsnShardCreate_impl(device, rank, world, id128, n_ticks, n_maps, widths, heights); });
+}
+
+static int lsnShardRcclPath_impl(char *buf, int len)
 {
     Rccl *r = rccl();
     if (!r) return -1;
@@ -794,11 +852,16 @@ extern "C" int lsnShardRcclPath(char *buf, int len)
     return (int)r->path.size();
 }
 
+extern "C" int lsnShardRcclPath(char *buf, int len)
+{
+    return lsn::guarded<int>("lsnShardRcclPath", static_cast<int>(-1), [&]() { return lsnShardRcclPath_impl(buf, len); });
+}
+
 extern "C" LsnFusion *lsnShardPlan(LsnShard *sh, int whole) { return sh ? (whole ? sh->whole : sh->local) : nullptr; }
 extern "C" long long lsnShardMergedCapacity(const LsnShard *sh) { return sh && sh->whole ? sh->whole->cap : 0; }
 extern "C" long long lsnShardLastBytesSent(const LsnShard *sh) { return sh ? sh->last_bytes_per_rank : 0; }
 
-extern "C" int lsnShardSetParams(LsnShard *sh, const float *intr_all, const float *wt_all, const float *bounds6, void *stream)
+static int lsnShardSetParams_impl(LsnShard *sh, const float *intr_all, const float *wt_all, const float *bounds6, void *stream)
 {
     lsn::clear_error();
     if (!sh || !intr_all || !wt_all || !bounds6) {
@@ -809,9 +872,14 @@ extern "C" int lsnShardSetParams(LsnShard *sh, const float *intr_all, const floa
     return lsnFusionSetParams(sh->local, intr_all + 7 * (size_t)sh->rank * sh->mpr, wt_all + 12 * (size_t)sh->rank * sh->mpr, bounds6, stream);
 }
 
+extern "C" int lsnShardSetParams(LsnShard *sh, const float *intr_all, const float *wt_all, const float *bounds6, void *stream)
+{
+    return lsn::guarded<int>("lsnShardSetParams", static_cast<int>(-1), [&]() { return lsnShardSetParams_impl(sh, intr_all, wt_all, bounds6, stream); });
+}
+
 static int shard_step(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets, void *stream);
 
-extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets,
+static int lsnShardStep_impl(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets,
                             void *stream)
 {
     lsn::clear_error();
@@ -835,6 +903,12 @@ extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void 
         sh->failure = lsn::error_buffer();
     }
     return rc;
+}
+
+extern "C" int lsnShardStep(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets,
+                            void *stream)
+{
+    return lsn::guarded<int>("lsnShardStep", static_cast<int>(-1), [&]() { return lsnShardStep_impl(sh, d_depth_local, d_colors_local, d_merged, d_merged_offsets, stream); });
 }
 
 static int shard_step(LsnShard *sh, const void *d_depth_local, const void *d_colors_local, void **d_merged, int **d_merged_offsets, void *stream)

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kThreads) void table_kernel(const FrameDesc *frames
 // host side
 // -------------------------------------------------------------------------------------------------------------
 
-extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const int *widths, const int *heights)
+static LsnFusion * lsnFusionCreate_impl(int device, int n_ticks, int n_maps, const int *widths, const int *heights)
 {
     lsn::clear_error();
     if (n_ticks <= 0 || n_maps <= 0 || !widths || !heights) {
@@ -721,7 +721,12 @@ extern "C" LsnFusion *lsnFusionCreate(int device, int n_ticks, int n_maps, const
     return p;
 }
 
-extern "C" void lsnFusionDestroy(LsnFusion *p)
+extern "C" LsnFusion * lsnFusionCreate(int device, int n_ticks, int n_maps, const int *widths, const int *heights)
+{
+    return lsn::guarded<LsnFusion *>("lsnFusionCreate", static_cast<LsnFusion *>(nullptr), [&]() { return lsnFusionCreate_impl(device, n_ticks, n_maps, widths, heights); });
+}
+
+static void lsnFusionDestroy_impl(LsnFusion *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
@@ -739,6 +744,11 @@ extern "C" void lsnFusionDestroy(LsnFusion *p)
     delete p;
 }
 
+extern "C" void lsnFusionDestroy(LsnFusion *p)
+{
+    lsn::guarded_void("lsnFusionDestroy", [&]() { lsnFusionDestroy_impl(p); });
+}
+
 extern "C" long long lsnFusionTickCapacity(const LsnFusion *p) { return p ? p->cap : 0; }
 
 // IntrinsicCameraParameters(float*) / WorldTranformation(float*), include/NativeUtils/depthprocessing.h:56-63,96-97: the caller's 7 and 12
@@ -753,7 +763,7 @@ static void pack_sensor_params(const float *ip, const float *tp, SensorParams &s
     s.r20 = tp[9]; s.r21 = tp[10]; s.r22 = tp[11];
 }
 
-extern "C" int lsnPackSensorParams(const float *intr7, const float *wt12, float *out16)
+static int lsnPackSensorParams_impl(const float *intr7, const float *wt12, float *out16)
 {
     lsn::clear_error();
     if (!intr7 || !wt12 || !out16) {
@@ -767,7 +777,12 @@ extern "C" int lsnPackSensorParams(const float *intr7, const float *wt12, float 
     return 0;
 }
 
-extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *wt, const float *bounds6, void *stream)
+extern "C" int lsnPackSensorParams(const float *intr7, const float *wt12, float *out16)
+{
+    return lsn::guarded<int>("lsnPackSensorParams", static_cast<int>(-1), [&]() { return lsnPackSensorParams_impl(intr7, wt12, out16); });
+}
+
+static int lsnFusionSetParams_impl(LsnFusion *p, const float *intr, const float *wt, const float *bounds6, void *stream)
 {
     lsn::clear_error();
     if (!p || !intr || !wt || !bounds6) {
@@ -803,7 +818,12 @@ extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *
     return 0;
 }
 
-extern "C" int lsnFusionSetMode(LsnFusion *p, int mode)
+extern "C" int lsnFusionSetParams(LsnFusion *p, const float *intr, const float *wt, const float *bounds6, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionSetParams", static_cast<int>(-1), [&]() { return lsnFusionSetParams_impl(p, intr, wt, bounds6, stream); });
+}
+
+static int lsnFusionSetMode_impl(LsnFusion *p, int mode)
 {
     if (!p || mode < 0 || mode > 2) {
         lsn::set_error("lsnFusionSetMode: mode must be 0 (count/scan/write launches), 1 (single launch, runs + look-back) or 2 (single pass, look-back per tile)");
@@ -813,7 +833,12 @@ extern "C" int lsnFusionSetMode(LsnFusion *p, int mode)
     return 0;
 }
 
-extern "C" int lsnFusionSetPipelined(LsnFusion *p, int enable)
+extern "C" int lsnFusionSetMode(LsnFusion *p, int mode)
+{
+    return lsn::guarded<int>("lsnFusionSetMode", static_cast<int>(-1), [&]() { return lsnFusionSetMode_impl(p, mode); });
+}
+
+static int lsnFusionSetPipelined_impl(LsnFusion *p, int enable)
 {
     lsn::clear_error();
     if (!p) return -1;
@@ -834,11 +859,21 @@ extern "C" int lsnFusionSetPipelined(LsnFusion *p, int enable)
     return 0;
 }
 
-extern "C" int lsnFusionProfile(LsnFusion *p, int enable)
+extern "C" int lsnFusionSetPipelined(LsnFusion *p, int enable)
+{
+    return lsn::guarded<int>("lsnFusionSetPipelined", static_cast<int>(-1), [&]() { return lsnFusionSetPipelined_impl(p, enable); });
+}
+
+static int lsnFusionProfile_impl(LsnFusion *p, int enable)
 {
     if (!p) return -1;
     p->profile = enable != 0;
     return 0;
+}
+
+extern "C" int lsnFusionProfile(LsnFusion *p, int enable)
+{
+    return lsn::guarded<int>("lsnFusionProfile", static_cast<int>(-1), [&]() { return lsnFusionProfile_impl(p, enable); });
 }
 
 static int drain_events(LsnFusion *p)
@@ -854,7 +889,7 @@ static int drain_events(LsnFusion *p)
     return 0;
 }
 
-extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *launches, char *name, int name_len, int reset)
+static int lsnFusionKernelStats_impl(LsnFusion *p, double *avg_ms, long long *launches, char *name, int name_len, int reset)
 {
     lsn::clear_error();
     if (!p) return -1;
@@ -870,6 +905,11 @@ extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *lau
         p->launches = 0;
     }
     return 0;
+}
+
+extern "C" int lsnFusionKernelStats(LsnFusion *p, double *avg_ms, long long *launches, char *name, int name_len, int reset)
+{
+    return lsn::guarded<int>("lsnFusionKernelStats", static_cast<int>(-1), [&]() { return lsnFusionKernelStats_impl(p, avg_ms, launches, name, name_len, reset); });
 }
 
 // Kernel arguments of one call (everything but the per-mode scratch selection).
@@ -1003,7 +1043,7 @@ static void launch(bool vec, int grid, hipStream_t s, const FuseArgs &a, bool la
     else     hipLaunchKernelGGL((fuse_kernel<MODE, false>), dim3(grid), dim3(kThreads), 0, s, a);
 }
 
-extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+static int lsnFusionRun_impl(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
                             void *stream)
 {
     lsn::clear_error();
@@ -1013,6 +1053,12 @@ extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_col
     }
     std::lock_guard<std::mutex> g(p->mu);
     return lsn::run_locked(p, d_depth, d_colors, d_vertices, d_offsets, lsn::as_stream(stream), false, nullptr);
+}
+
+extern "C" int lsnFusionRun(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+                            void *stream)
+{
+    return lsn::guarded<int>("lsnFusionRun", static_cast<int>(-1), [&]() { return lsnFusionRun_impl(p, d_depth, d_colors, d_vertices, d_offsets, stream); });
 }
 
 int lsn::run_hooked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, hipStream_t s, const RunHooks *hooks)
@@ -1071,7 +1117,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         ac.offsets = off_int;
         launch_count(p, vec, p->side, ac);
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, p->side, ac.tile_counts, ac.tiles_per_tick, ac.frames,
-                           ac.n_frames, off_int, nullptr, nullptr);
+                           ac.n_frames, off_int, nullptr);
         LSN_HIP(hipEventRecord(p->ev_counted, p->side));
         LSN_HIP(hipStreamWaitEvent(s, p->ev_counted, 0));
         LSN_HIP(hipMemcpyAsync(d_offsets, off_int, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
@@ -1082,12 +1128,9 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         p->calls++;
     } else if (p->mode == 0 || with_pixmap || hooks) {
         launch_count(p, vec, s, a);
-        const bool mirror = hooks && hooks->mirror && hooks->h_offsets;
-        if (hooks && hooks->carry_wait) LSN_HIP(hipStreamWaitEvent(s, hooks->carry_wait, 0));
         hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
-                           a.offsets, hooks ? hooks->carry : nullptr, mirror ? hooks->h_offsets : nullptr);
-        if (hooks && hooks->carry_record) LSN_HIP(hipEventRecord(hooks->carry_record, s));
-        if (hooks && hooks->h_offsets && !mirror) LSN_HIP(hipMemcpyAsync(hooks->h_offsets, d_offsets, off_bytes, hipMemcpyDeviceToHost, s));
+                           a.offsets, nullptr);
+        if (hooks && hooks->h_offsets) LSN_HIP(hipMemcpyAsync(hooks->h_offsets, d_offsets, off_bytes, hipMemcpyDeviceToHost, s));
         if (hooks && hooks->counted) LSN_HIP(hipEventRecord(hooks->counted, s));
         if (hooks && hooks->colours_ready) LSN_HIP(hipStreamWaitEvent(s, hooks->colours_ready, 0));
         if (e0) LSN_HIP(hipEventRecord(e0, s));
@@ -1175,7 +1218,7 @@ int lsn::run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, voi
 }
 
 // Streamed calls: this batch is written while the NEXT batch (already resident) is counted by the same kernel.
-extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+static int lsnFusionRunStreamed_impl(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
                                     const void *d_next_depth, void *stream)
 {
     lsn::clear_error();
@@ -1209,7 +1252,7 @@ extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const voi
         // nothing (valid) was counted ahead for this batch: do it now, like mode 0
         a.offsets = off_cur;
         launch_count(p, vec, s, a);
-        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, cur, a.tiles_per_tick, a.frames, a.n_frames, off_cur, nullptr, nullptr);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, cur, a.tiles_per_tick, a.frames, a.n_frames, off_cur, nullptr);
     }
     LSN_HIP(hipMemcpyAsync(d_offsets, off_cur, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
     a.offsets = d_offsets;
@@ -1225,7 +1268,7 @@ extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const voi
     }
     if (e1) LSN_HIP(hipEventRecord(e1, s));
     if (d_next_depth) {
-        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, nxt, a.tiles_per_tick, a.frames, a.n_frames, off_nxt, nullptr, nullptr);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, nxt, a.tiles_per_tick, a.frames, a.n_frames, off_nxt, nullptr);
         p->counted_for = d_next_depth;
         p->counted_gen = p->params_gen;
         p->stream_half ^= 1;
@@ -1236,8 +1279,14 @@ extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const voi
     return 0;
 }
 
+extern "C" int lsnFusionRunStreamed(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+                                    const void *d_next_depth, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionRunStreamed", static_cast<int>(-1), [&]() { return lsnFusionRunStreamed_impl(p, d_depth, d_colors, d_vertices, d_offsets, d_next_depth, stream); });
+}
+
 // Diagnostics / tests: builds the per-pixel depth thresholds now (if the plan uses them) and copies them out.
-extern "C" int lsnFusionThresholds(LsnFusion *p, unsigned int *out_host, float *build_ms, void *stream)
+static int lsnFusionThresholds_impl(LsnFusion *p, unsigned int *out_host, float *build_ms, void *stream)
 {
     lsn::clear_error();
     if (!p || !p->params_set) {
@@ -1260,10 +1309,15 @@ extern "C" int lsnFusionThresholds(LsnFusion *p, unsigned int *out_host, float *
     return 0;
 }
 
+extern "C" int lsnFusionThresholds(LsnFusion *p, unsigned int *out_host, float *build_ms, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionThresholds", static_cast<int>(-1), [&]() { return lsnFusionThresholds_impl(p, out_host, build_ms, stream); });
+}
+
 // Reads back the look-back error flag (diagnostics for tests); synchronises the stream.
 extern "C" int lsnFusionCheck(LsnFusion *p, void *stream) { return lsnFusionLookbackFailed(p, stream); }
 
-extern "C" int lsnFusionLookbackFailed(LsnFusion *p, void *stream)
+static int lsnFusionLookbackFailed_impl(LsnFusion *p, void *stream)
 {
     if (!p) return -1;
     int flag = 0;
@@ -1272,5 +1326,10 @@ extern "C" int lsnFusionLookbackFailed(LsnFusion *p, void *stream)
     LSN_HIP(hipMemcpy(&flag, p->misc.p, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) LSN_HIP(hipMemset(p->misc.p, 0, sizeof(int)));
     return flag;
+}
+
+extern "C" int lsnFusionLookbackFailed(LsnFusion *p, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionLookbackFailed", static_cast<int>(-1), [&]() { return lsnFusionLookbackFailed_impl(p, stream); });
 }
 

@@ -409,13 +409,10 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
 
 // Mode 0, between the count and the write launch: one workgroup per tick turns that tick's tile counts into exclusive
 // prefixes in place and fills the per-sensor offset table (offsets[tick][f] = first vertex of sensor f, [n_frames] = total).
-// carry_in (optional, single-tick plans): the prefixes start at *carry_in instead of 0 -- the host exports fuse a tick as several
-// groups of sensors, each with a plan of its own, and a group's vertices / triangles follow the previous group's in the same
-// output block (abi.hip); carry_in then points at the previous group's total, offsets[n_frames] of its table.
 // mirror (optional): the offset table is also stored there -- pinned host memory, so the host has the counts when the stream
 // is idle without a copy of its own.
 __attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(int *tile_counts, int tiles_per_tick, const FrameDesc *frames, int n_frames,
-                                                        int *offsets, const int *carry_in, int *mirror)
+                                                        int *offsets, int *mirror)
 {
     __shared__ int s_wave[4];
     __shared__ int s_carry;
@@ -423,7 +420,7 @@ __attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(
     int *tc = tile_counts + (long long)tick * tiles_per_tick;
     int *off = offsets + (long long)tick * (n_frames + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = carry_in ? *carry_in : 0;
+    if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (int c0 = 0; c0 < tiles_per_tick; c0 += kThreads) {
         const int i = c0 + threadIdx.x;

@@ -1375,7 +1375,7 @@ struct LsnIcp {
 
 static constexpr int kTraceCap = 1024;
 
-extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
+static LsnIcp * lsnIcpCreate_impl(int device, int max_n1, int max_n2)
 {
     lsn::clear_error();
     if (max_n1 <= 0 || max_n2 <= 0) {
@@ -1427,7 +1427,12 @@ extern "C" LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2)
     return w;
 }
 
-extern "C" void lsnIcpDestroy(LsnIcp *w)
+extern "C" LsnIcp * lsnIcpCreate(int device, int max_n1, int max_n2)
+{
+    return lsn::guarded<LsnIcp *>("lsnIcpCreate", static_cast<LsnIcp *>(nullptr), [&]() { return lsnIcpCreate_impl(device, max_n1, max_n2); });
+}
+
+static void lsnIcpDestroy_impl(LsnIcp *w)
 {
     if (!w) return;
     (void)hipSetDevice(w->device);
@@ -1435,7 +1440,12 @@ extern "C" void lsnIcpDestroy(LsnIcp *w)
     delete w;
 }
 
-extern "C" int lsnIcpSetProfiling(LsnIcp *w, int on)
+extern "C" void lsnIcpDestroy(LsnIcp *w)
+{
+    lsn::guarded_void("lsnIcpDestroy", [&]() { lsnIcpDestroy_impl(w); });
+}
+
+static int lsnIcpSetProfiling_impl(LsnIcp *w, int on)
 {
     lsn::clear_error();
     if (!w) return -1;
@@ -1443,6 +1453,11 @@ extern "C" int lsnIcpSetProfiling(LsnIcp *w, int on)
     w->profiling = on != 0;
     w->n_events = 0;
     return 0;
+}
+
+extern "C" int lsnIcpSetProfiling(LsnIcp *w, int on)
+{
+    return lsn::guarded<int>("lsnIcpSetProfiling", static_cast<int>(-1), [&]() { return lsnIcpSetProfiling_impl(w, on); });
 }
 
 // records the end of `phase` on the stream (profiling only)
@@ -1459,7 +1474,7 @@ static void mark(LsnIcp *w, int phase, hipStream_t s)
     (void)hipEventRecord(w->events[w->n_events++], s);
 }
 
-extern "C" int lsnIcpProfile(LsnIcp *w, float *ms4, void *stream)
+static int lsnIcpProfile_impl(LsnIcp *w, float *ms4, void *stream)
 {
     lsn::clear_error();
     if (!w || !ms4) return -1;
@@ -1473,6 +1488,11 @@ extern "C" int lsnIcpProfile(LsnIcp *w, float *ms4, void *stream)
         ms4[w->event_phase[k] & 3] += ms;
     }
     return (int)w->n_events;
+}
+
+extern "C" int lsnIcpProfile(LsnIcp *w, float *ms4, void *stream)
+{
+    return lsn::guarded<int>("lsnIcpProfile", static_cast<int>(-1), [&]() { return lsnIcpProfile_impl(w, ms4, stream); });
 }
 
 static inline int blocks_for(int n) { return (n + kThreads - 1) / kThreads; }
@@ -1607,7 +1627,7 @@ static int check_sizes(LsnIcp *w, int n1, int n2, const char *who)
     return 0;
 }
 
-extern "C" int lsnIcpNearest(LsnIcp *w, const float *d_verts1, int n1, const float *d_verts2, int n2, int *d_idx, float *d_dist2,
+static int lsnIcpNearest_impl(LsnIcp *w, const float *d_verts1, int n1, const float *d_verts2, int n2, int *d_idx, float *d_dist2,
                              int nn_mode, void *stream)
 {
     lsn::clear_error();
@@ -1625,7 +1645,13 @@ extern "C" int lsnIcpNearest(LsnIcp *w, const float *d_verts1, int n1, const flo
     return run_nn(w, d_verts1, n1, nullptr, n2, d_idx, d_dist2, nullptr, nn_mode, s, false, nullptr, 0);
 }
 
-extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int n2, float *d_R, float *d_t, int maxIter,
+extern "C" int lsnIcpNearest(LsnIcp *w, const float *d_verts1, int n1, const float *d_verts2, int n2, int *d_idx, float *d_dist2,
+                             int nn_mode, void *stream)
+{
+    return lsn::guarded<int>("lsnIcpNearest", static_cast<int>(-1), [&]() { return lsnIcpNearest_impl(w, d_verts1, n1, d_verts2, n2, d_idx, d_dist2, nn_mode, stream); });
+}
+
+static int lsnIcpRun_impl(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int n2, float *d_R, float *d_t, int maxIter,
                          int nn_mode, void *stream)
 {
     lsn::clear_error();
@@ -1677,7 +1703,13 @@ extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_vert
     return 0;
 }
 
-extern "C" int lsnIcpTrace(LsnIcp *w, float *out, int max_iters, void *stream)
+extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int n2, float *d_R, float *d_t, int maxIter,
+                         int nn_mode, void *stream)
+{
+    return lsn::guarded<int>("lsnIcpRun", static_cast<int>(-1), [&]() { return lsnIcpRun_impl(w, d_verts1, n1, d_verts2, n2, d_R, d_t, maxIter, nn_mode, stream); });
+}
+
+static int lsnIcpTrace_impl(LsnIcp *w, float *out, int max_iters, void *stream)
 {
     lsn::clear_error();
     if (!w || !out) return -1;
@@ -1688,12 +1720,17 @@ extern "C" int lsnIcpTrace(LsnIcp *w, float *out, int max_iters, void *stream)
     return n;
 }
 
+extern "C" int lsnIcpTrace(LsnIcp *w, float *out, int max_iters, void *stream)
+{
+    return lsn::guarded<int>("lsnIcpTrace", static_cast<int>(-1), [&]() { return lsnIcpTrace_impl(w, out, max_iters, stream); });
+}
+
 // refineWorker_DoWork (LiveScanServer/MainWindowForm.cs:330-410) with every cloud resident in HBM for the whole
 // Gauss-Seidel loop: the reference re-uploads "all other sensors" and the sensor's own cloud for each of the
 // n_sensors x n_refine_iters ICP calls; here each cloud goes up once and comes back once.  The pose composition at the
 // end repeats the C# loops literally, including their in-place update of worldTransforms[i].R while later rows still
 // read it (:398-406).
-extern "C" int lsnRefine(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
+static int lsnRefine_impl(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
                          float *world_R, float *world_t, float *Rs_out, float *Ts_out)
 {
     lsn::clear_error();
@@ -1780,4 +1817,10 @@ extern "C" int lsnRefine(int device, int n_sensors, float *const *clouds, const 
         if (Ts_out) memcpy(Ts_out + 3 * i, Rt.data() + 12 * (size_t)i + 9, 3 * sizeof(float));
     }
     return 0;
+}
+
+extern "C" int lsnRefine(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
+                         float *world_R, float *world_t, float *Rs_out, float *Ts_out)
+{
+    return lsn::guarded<int>("lsnRefine", static_cast<int>(-1), [&]() { return lsnRefine_impl(device, n_sensors, clouds, counts, n_refine_iters, n_icp_iters, world_R, world_t, Rs_out, Ts_out); });
 }

@@ -106,13 +106,8 @@ struct RunHooks {
     hipEvent_t written = nullptr;         // recorded after the write pass (the vertices may leave while the triangulation runs)
     int *h_tri_offsets = nullptr;         // lsnFusionRunMesh: pinned host copy of the triangle offset table ...
     hipEvent_t tri_counted = nullptr;     // ... and the event behind it
-    // a tick fused as several groups of sensors into ONE output block (abi.hip): this group's vertex / triangle prefixes start at
-    // *carry / *tri_carry (device memory: the previous group's total), and its vertex indices (pixel -> vertex map, triangles) with them
-    const int *carry = nullptr;
-    const int *tri_carry = nullptr;
-    bool mirror = false;                  // h_offsets / h_tri_offsets are stored by the scan kernels themselves (pinned, device-visible memory): no copy
-    // ... and the groups run on different streams: the scan that reads *carry waits for carry_wait, and records carry_record behind itself
-    hipEvent_t carry_wait = nullptr, carry_record = nullptr, tri_carry_wait = nullptr, tri_carry_record = nullptr;
+    bool mirror = false;                  // h_tri_offsets is pinned, device-visible memory and the scan kernel stores the table there itself: no copy,
+                                          // and the triangle write pass treats its output as host memory too (abi.hip's direct path)
 };
 // lsnFusionRun with the plan's mutex already held; with_pixmap also fills the pixel -> vertex map the triangulation reads.
 int run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, hipStream_t s, bool with_pixmap,

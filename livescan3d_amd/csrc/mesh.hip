@@ -417,10 +417,8 @@ static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles,
     if (vec) hipLaunchKernelGGL((tri_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, t);
     else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
     const bool mirror = hooks && hooks->mirror && hooks->h_tri_offsets;
-    if (hooks && hooks->tri_carry_wait) LSN_HIP(hipStreamWaitEvent(s, hooks->tri_carry_wait, 0));
     hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, t.tile_counts, t.tiles_per_tick, t.frames, p->n_maps,
-                       d_tri_offsets, hooks ? hooks->tri_carry : nullptr, mirror ? hooks->h_tri_offsets : nullptr);
-    if (hooks && hooks->tri_carry_record) LSN_HIP(hipEventRecord(hooks->tri_carry_record, s));
+                       d_tri_offsets, mirror ? hooks->h_tri_offsets : nullptr);
     if (hooks && hooks->h_tri_offsets && !mirror)
         LSN_HIP(hipMemcpyAsync(hooks->h_tri_offsets, d_tri_offsets, sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1), hipMemcpyDeviceToHost, s));
     if (hooks && hooks->tri_counted) LSN_HIP(hipEventRecord(hooks->tri_counted, s));
@@ -432,11 +430,17 @@ static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles,
 
 extern "C" long long lsnFusionTickTriangleCapacity(const LsnFusion *p) { return p ? 2 * p->cap : 0; }
 
-extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+static int lsnFusionRunMesh_impl(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
                                 void *d_triangles, int *d_tri_offsets, void *stream)
 {
     lsn::clear_error();
     return lsn::run_mesh(p, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, lsn::as_stream(stream), nullptr);
+}
+
+extern "C" int lsnFusionRunMesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets,
+                                void *d_triangles, int *d_tri_offsets, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionRunMesh", static_cast<int>(-1), [&]() { return lsnFusionRunMesh_impl(p, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream); });
 }
 
 int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, void *d_triangles,

@@ -1266,7 +1266,7 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
     return 0;
 }
 
-extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, void *d_depth, void *d_colors, void *stream)
+static int lsnFusionRadialCorrect_impl(LsnFusion *p, const float *intr_params, void *d_depth, void *d_colors, void *stream)
 {
     lsn::clear_error();
     if (!p || !intr_params || !d_depth || !d_colors) {
@@ -1277,7 +1277,12 @@ extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, vo
     return radial_correct(p, intr_params, d_depth, d_colors, d_depth, d_colors, lsn::as_stream(stream));
 }
 
-extern "C" int lsnFusionRadialCorrectTo(LsnFusion *p, const float *intr_params, const void *d_depth_in, const void *d_colors_in, void *d_depth_out,
+extern "C" int lsnFusionRadialCorrect(LsnFusion *p, const float *intr_params, void *d_depth, void *d_colors, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionRadialCorrect", static_cast<int>(-1), [&]() { return lsnFusionRadialCorrect_impl(p, intr_params, d_depth, d_colors, stream); });
+}
+
+static int lsnFusionRadialCorrectTo_impl(LsnFusion *p, const float *intr_params, const void *d_depth_in, const void *d_colors_in, void *d_depth_out,
                                         void *d_colors_out, void *stream)
 {
     lsn::clear_error();
@@ -1287,4 +1292,10 @@ extern "C" int lsnFusionRadialCorrectTo(LsnFusion *p, const float *intr_params, 
     }
     std::lock_guard<std::mutex> g(p->mu);
     return radial_correct(p, intr_params, d_depth_in, d_colors_in, d_depth_out, d_colors_out, lsn::as_stream(stream));
+}
+
+extern "C" int lsnFusionRadialCorrectTo(LsnFusion *p, const float *intr_params, const void *d_depth_in, const void *d_colors_in, void *d_depth_out,
+                                        void *d_colors_out, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionRadialCorrectTo", static_cast<int>(-1), [&]() { return lsnFusionRadialCorrectTo_impl(p, intr_params, d_depth_in, d_colors_in, d_depth_out, d_colors_out, stream); });
 }

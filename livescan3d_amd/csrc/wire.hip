@@ -846,7 +846,7 @@ struct LsnTransfer {
 
 extern "C" {
 
-LsnTransfer *lsnTransferCreate(int device, int max_vertices, int max_triangles)
+static LsnTransfer *lsnTransferCreate_impl(int device, int max_vertices, int max_triangles)
 {
     lsn::clear_error();
     if (max_vertices < 0 || max_triangles < 0) { lsn::set_error("lsnTransferCreate: negative capacity"); return nullptr; }
@@ -884,21 +884,36 @@ LsnTransfer *lsnTransferCreate(int device, int max_vertices, int max_triangles)
     return t;
 }
 
-void lsnTransferDestroy(LsnTransfer *t)
+LsnTransfer *lsnTransferCreate(int device, int max_vertices, int max_triangles)
+{
+    return lsn::guarded<LsnTransfer *>("lsnTransferCreate", static_cast<LsnTransfer *>(nullptr), [&]() { return lsnTransferCreate_impl(device, max_vertices, max_triangles); });
+}
+
+static void lsnTransferDestroy_impl(LsnTransfer *t)
 {
     if (!t) return;
     (void)hipSetDevice(t->device);
     delete t;
 }
 
-int lsnTransferLastPath(LsnTransfer *t)
+void lsnTransferDestroy(LsnTransfer *t)
+{
+    lsn::guarded_void("lsnTransferDestroy", [&]() { lsnTransferDestroy_impl(t); });
+}
+
+static int lsnTransferLastPath_impl(LsnTransfer *t)
 {
     if (!t) return -1;
     std::lock_guard<std::mutex> guard(t->mu);
     return t->last_path;
 }
 
-long long lsnTransferFrameBound(int n_vertices, int n_triangles)
+int lsnTransferLastPath(LsnTransfer *t)
+{
+    return lsn::guarded<int>("lsnTransferLastPath", static_cast<int>(-1), [&]() { return lsnTransferLastPath_impl(t); });
+}
+
+static long long lsnTransferFrameBound_impl(int n_vertices, int n_triangles)
 {
     const long long nt = n_triangles > 0 ? n_triangles : 0, nv = n_vertices > 0 ? n_vertices : 0;
     const long long send = nt > 0 ? 3 * nt : nv;
@@ -906,7 +921,12 @@ long long lsnTransferFrameBound(int n_vertices, int n_triangles)
     return 12 + 8 * chunks + 15 * send + 12 * nt;
 }
 
-long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles,
+long long lsnTransferFrameBound(int n_vertices, int n_triangles)
+{
+    return lsn::guarded<long long>("lsnTransferFrameBound", static_cast<long long>(-1), [&]() { return lsnTransferFrameBound_impl(n_vertices, n_triangles); });
+}
+
+static long long lsnTransferPack_impl(LsnTransfer *t, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles,
                           void *d_out, long long out_cap, void *stream)
 {
     lsn::clear_error();
@@ -1024,6 +1044,12 @@ long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices
     return need;
 }
 
+long long lsnTransferPack(LsnTransfer *t, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles,
+                          void *d_out, long long out_cap, void *stream)
+{
+    return lsn::guarded<long long>("lsnTransferPack", static_cast<long long>(-1), [&]() { return lsnTransferPack_impl(t, d_vertices, n_vertices, d_triangles, n_triangles, d_out, out_cap, stream); });
+}
+
 static int ply_header(PlyHeader *h, int nV, int nT)
 {
     h->len = snprintf(h->text, sizeof h->text,
@@ -1036,14 +1062,19 @@ static int ply_header(PlyHeader *h, int nV, int nT)
     return h->len > 0 && h->len < (int)sizeof h->text ? 0 : -1;
 }
 
-long long lsnPlyBinaryBytes(int n_vertices, int n_triangles)
+static long long lsnPlyBinaryBytes_impl(int n_vertices, int n_triangles)
 {
     PlyHeader h;
     if (n_vertices < 0 || n_triangles < 0 || ply_header(&h, n_vertices, n_triangles)) return -1;
     return h.len + 15ll * n_vertices + 13ll * n_triangles;
 }
 
-long long lsnPlyPack(int device, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles, void *d_out,
+long long lsnPlyBinaryBytes(int n_vertices, int n_triangles)
+{
+    return lsn::guarded<long long>("lsnPlyBinaryBytes", static_cast<long long>(-1), [&]() { return lsnPlyBinaryBytes_impl(n_vertices, n_triangles); });
+}
+
+static long long lsnPlyPack_impl(int device, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles, void *d_out,
                      long long out_cap, void *stream)
 {
     lsn::clear_error();
@@ -1063,6 +1094,12 @@ long long lsnPlyPack(int device, const void *d_vertices, int n_vertices, const i
                                                                      static_cast<unsigned char *>(d_out), h, vb, fb);
     LSN_HIP(hipGetLastError());
     return need;
+}
+
+long long lsnPlyPack(int device, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles, void *d_out,
+                     long long out_cap, void *stream)
+{
+    return lsn::guarded<long long>("lsnPlyPack", static_cast<long long>(-1), [&]() { return lsnPlyPack_impl(device, d_vertices, n_vertices, d_triangles, n_triangles, d_out, out_cap, stream); });
 }
 
 }  // extern "C"
@@ -1129,7 +1166,7 @@ extern "C" {
 
 int lsnZstdAvailable(void) { return zstd().ok ? 1 : 0; }
 
-int lsnFrameParseHeader(const unsigned char *header16, LsnFrameInfo *info)
+static int lsnFrameParseHeader_impl(const unsigned char *header16, LsnFrameInfo *info)
 {
     lsn::clear_error();
     if (!header16 || !info) { lsn::set_error("lsnFrameParseHeader: null argument"); return -1; }
@@ -1145,7 +1182,12 @@ int lsnFrameParseHeader(const unsigned char *header16, LsnFrameInfo *info)
     return 0;
 }
 
-long long lsnFrameDecode(const unsigned char *payload, int payload_bytes, int compressed, int width, int height,
+int lsnFrameParseHeader(const unsigned char *header16, LsnFrameInfo *info)
+{
+    return lsn::guarded<int>("lsnFrameParseHeader", static_cast<int>(-1), [&]() { return lsnFrameParseHeader_impl(header16, info); });
+}
+
+static long long lsnFrameDecode_impl(const unsigned char *payload, int payload_bytes, int compressed, int width, int height,
                          unsigned char *depth_out, unsigned char *rgb_out, unsigned char *bodies_out, int bodies_cap,
                          int *n_bodies)
 {
@@ -1184,7 +1226,14 @@ long long lsnFrameDecode(const unsigned char *payload, int payload_bytes, int co
     return bl;
 }
 
-long long lsnFrameEncode(const unsigned char *depth, const unsigned char *rgb, int width, int height, const unsigned char *bodies,
+long long lsnFrameDecode(const unsigned char *payload, int payload_bytes, int compressed, int width, int height,
+                         unsigned char *depth_out, unsigned char *rgb_out, unsigned char *bodies_out, int bodies_cap,
+                         int *n_bodies)
+{
+    return lsn::guarded<long long>("lsnFrameDecode", static_cast<long long>(-1), [&]() { return lsnFrameDecode_impl(payload, payload_bytes, compressed, width, height, depth_out, rgb_out, bodies_out, bodies_cap, n_bodies); });
+}
+
+static long long lsnFrameEncode_impl(const unsigned char *depth, const unsigned char *rgb, int width, int height, const unsigned char *bodies,
                          int bodies_bytes, int compression_level, unsigned char *out, long long out_cap)
 {
     lsn::clear_error();
@@ -1220,7 +1269,13 @@ long long lsnFrameEncode(const unsigned char *depth, const unsigned char *rgb, i
     return 16 + (long long)isize;
 }
 
-long long lsnRecordingAppend(unsigned char *out, long long cap, const unsigned char *frame, int len, int timestamp_ms)
+long long lsnFrameEncode(const unsigned char *depth, const unsigned char *rgb, int width, int height, const unsigned char *bodies,
+                         int bodies_bytes, int compression_level, unsigned char *out, long long out_cap)
+{
+    return lsn::guarded<long long>("lsnFrameEncode", static_cast<long long>(-1), [&]() { return lsnFrameEncode_impl(depth, rgb, width, height, bodies, bodies_bytes, compression_level, out, out_cap); });
+}
+
+static long long lsnRecordingAppend_impl(unsigned char *out, long long cap, const unsigned char *frame, int len, int timestamp_ms)
 {
     lsn::clear_error();
     char hdr[96];
@@ -1231,6 +1286,11 @@ long long lsnRecordingAppend(unsigned char *out, long long cap, const unsigned c
     if (len > 0) memcpy(out + hl, frame, (size_t)len);
     out[hl + len] = '\n';                                       // :127
     return need;
+}
+
+long long lsnRecordingAppend(unsigned char *out, long long cap, const unsigned char *frame, int len, int timestamp_ms)
+{
+    return lsn::guarded<long long>("lsnRecordingAppend", static_cast<long long>(-1), [&]() { return lsnRecordingAppend_impl(out, cap, frame, len, timestamp_ms); });
 }
 
 }  // extern "C"
@@ -1268,7 +1328,7 @@ bool next_int(const unsigned char *f, long long len, long long *pos, int *out)
 
 extern "C" {
 
-long long lsnRecordingNext(const unsigned char *file, long long len, long long pos, long long *frame_off, int *frame_len,
+static long long lsnRecordingNext_impl(const unsigned char *file, long long len, long long pos, long long *frame_off, int *frame_len,
                            int *timestamp_ms)
 {
     lsn::clear_error();
@@ -1289,6 +1349,12 @@ long long lsnRecordingNext(const unsigned char *file, long long len, long long p
     pos += size;
     if (pos < len) pos += 1;                                    // fgetc '\n' (:78)
     return pos;
+}
+
+long long lsnRecordingNext(const unsigned char *file, long long len, long long pos, long long *frame_off, int *frame_len,
+                           int *timestamp_ms)
+{
+    return lsn::guarded<long long>("lsnRecordingNext", static_cast<long long>(-1), [&]() { return lsnRecordingNext_impl(file, len, pos, frame_off, frame_len, timestamp_ms); });
 }
 
 }  // extern "C"

@@ -191,3 +191,102 @@ def test_merge_and_single_sensor_calls_from_two_threads(gpu, orc, n_sensors):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+# ---- nothing throws across the C-ABI (the reference itself lets nanoflann throw, include/nanoflann.h:904) ----------------------
+
+_THROW_SCRIPT = r"""
+import ctypes as C, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from livescan3d_amd import native, synth
+L = native.lib()
+vp = C.c_void_p
+rig = synth.make_rig("noise", 1, 16, 8)
+w = np.array([16], np.int32); h = np.array([8], np.int32)
+out = {{}}
+mesh = native.Mesh()
+mesh.nVertices = 77
+L.generateMeshFromDepthMaps(1, rig.depth_maps.ctypes.data_as(vp), rig.depth_colors.ctypes.data_as(vp), w.ctypes.data_as(vp), h.ctypes.data_as(vp),
+                            rig.intr.ctypes.data_as(vp), rig.wt.ctypes.data_as(vp), C.byref(mesh), False, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, False)
+out["merge"] = [mesh.nVertices, mesh.nTriangles, bool(mesh.triangles), native.last_error()]
+L.deleteMesh(C.byref(mesh))
+L.generateVerticesFromDepthMap(rig.depth_maps.ctypes.data_as(vp), rig.depth_colors.ctypes.data_as(vp), w.ctypes.data_as(vp), h.ctypes.data_as(vp),
+                               rig.intr.ctypes.data_as(vp), rig.wt.ctypes.data_as(vp), C.byref(mesh), -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, 0)
+out["single"] = [mesh.nVertices, mesh.nTriangles, bool(mesh.triangles), native.last_error()]
+L.deleteMesh(C.byref(mesh))
+R = np.eye(3, dtype=np.float32).ravel().copy(); t = np.array([1, 2, 3], np.float32)
+v1 = np.zeros((4, 3), np.float32); v2 = np.ones((4, 3), np.float32)
+L.ICP.restype = C.c_float
+r = L.ICP(v1.ctypes.data_as(vp), v2.ctypes.data_as(vp), 4, 4, R.ctypes.data_as(vp), t.ctypes.data_as(vp), 3)
+out["icp"] = [float(r), R.tolist(), t.tolist(), v2.ravel().tolist(), native.last_error()]
+plan = L.lsnFusionCreate(0, 1, 1, w.ctypes.data_as(vp), h.ctypes.data_as(vp))
+out["create"] = [bool(plan), native.last_error()]
+L.depthMapAndColorSetRadialCorrection(1, rig.depth_maps.ctypes.data_as(vp), rig.depth_colors.ctypes.data_as(vp), w.ctypes.data_as(vp), h.ctypes.data_as(vp),
+                                      rig.intr.ctypes.data_as(vp))
+out["radial"] = [native.last_error()]
+print(json.dumps(out))
+"""
+
+
+def _run_with_env(script, **env):
+    import json
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, f"the process died (rc {r.returncode}): an exception crossed the boundary?\n{r.stderr[-2000:]}"
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("nth", [1, 2, 3, 4, 5])
+def test_an_exception_inside_an_export_never_crosses_the_boundary(nth):
+    """LSN_TEST_THROW=n makes the n-th guarded entry of the process throw std::bad_alloc from inside the export's body (what a
+    growing std::vector / std::map would do under memory pressure).  The caller must see an empty mesh / untouched R, t / a null
+    handle and a message -- never std::terminate.  Runs without a GPU: the trampoline sits in front of everything."""
+    script = _THROW_SCRIPT.format(root=ROOT)
+    base = _run_with_env(script, LSN_TEST_THROW="0")
+    got = _run_with_env(script, LSN_TEST_THROW=str(nth))
+    # every mesh export leaves an empty mesh with a valid, never-dereferenced triangle pointer, whatever happened inside
+    for k in ("merge", "single"):
+        assert got[k][:3] == [0, 0, True] and got[k][3], got[k]
+    assert got["icp"][0] == 1.0 and got["icp"][1] == base["icp"][1] and got["icp"][2] == [1.0, 2.0, 3.0] and got["icp"][3] == [1.0] * 12
+    assert got["create"][0] is False and got["create"][1]
+    if nth == 1:   # the first guarded entry of the script is the merge call: it says what hit it
+        assert "generateMeshFromDepthMaps: std::bad_alloc" in got["merge"][3], got["merge"]
+
+
+_ALLOC_SCRIPT = r"""
+import ctypes as C, hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from livescan3d_amd import native, synth
+rig = synth.make_rig("scene", 4, 256, 212, seed=41, bounds=synth.CROP_BOUNDS)
+out = []
+for _ in range(3):
+    try:
+        v, t = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        out.append([len(v), len(t), hashlib.sha256(v.tobytes() + t.tobytes()).hexdigest(), ""])
+    except native.NativeUtilsError as ex:
+        out.append([0, 0, "", str(ex)])
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nth", [1, 2, 4, 7, 11])
+def test_a_failed_allocation_leaves_an_empty_mesh_and_the_next_call_works(gpu, orc, nth):
+    """LSN_TEST_FAIL_ALLOC=n: the n-th device / pinned allocation of the process throws std::bad_alloc in the middle of a real merge call.
+    That call ends in an empty mesh and a message (never std::terminate, nothing left in flight that could store into a recycled block);
+    the calls after it return the oracle's mesh."""
+    import hashlib
+    from livescan3d_amd import synth
+    rig = synth.make_rig("scene", 4, 256, 212, seed=41, bounds=synth.CROP_BOUNDS)
+    want_v, _, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    want = [len(want_v), len(want_t), hashlib.sha256(want_v.tobytes() + want_t.tobytes()).hexdigest(), ""]
+    got = _run_with_env(_ALLOC_SCRIPT.format(root=ROOT), LSN_TEST_FAIL_ALLOC=str(nth))
+    failed = [g for g in got if g[3]]
+    assert len(failed) <= 1 and all("bad_alloc" in g[3] for g in failed), got
+    assert [g for g in got if not g[3]] == [want] * (3 - len(failed)), got
+    assert got[-1] == want
