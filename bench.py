@@ -132,7 +132,8 @@ def main():
     native.require_gpu()
 
     S, B, w, h = args.sensors, args.ticks, args.width, args.height
-    from livescan3d_amd.sharding import MergedCloudExchange, sensor_block
+    from livescan3d_amd.sharding import sensor_block
+    from tests.exchange_rehearsal import MergedCloudExchange   # comparison legs only (the product path is ShardedFusion / lsnShard*)
     try:
         s0, s1 = sensor_block(S, world, rank)   # contiguous sensor block: rank order = formMesh sensor order
     except ValueError as e:
@@ -168,7 +169,8 @@ def main():
     use_shard = survivors_ok and args.exchange == "survivors" and (not share or fake_rccl)
     use_sx = survivors_ok and not use_shard and args.exchange in ("survivors", "survivors-python")
     if multi:
-        from livescan3d_amd.sharding import ShardedFusion, SurvivorExchange
+        from livescan3d_amd.sharding import ShardedFusion
+        from tests.exchange_rehearsal import SurvivorExchange
         shard_preflight = None
         if use_shard:
             # The library's own RCCL step.  ShardedFusion prepares every rank locally, lets the ranks agree that all are ready and only

@@ -1,8 +1,10 @@
-"""The N > 1 path on CPU: two gloo ranks, one block of sensors each, all-gather + merged-cloud assembly.
+"""The N > 1 path on CPU: gloo ranks (world 2, and world 8 x 1 sensor = BASELINE configs[3]'s split), one block of sensors each,
+all-gathers + merged-cloud assembly, both exchange protocols.
 
-The per-rank fusion is done by the CPU oracle here (tests may use it); what is under test is the product's sharding
-logic (livescan3d_amd/sharding.py): contiguous sensor blocks, the two all-gathers, and the packing contract of
-lsnMergeShards (restated in numpy below, because the HIP kernel needs a GPU).  The merged cloud on every rank must
+The per-rank fusion is done by the CPU oracle here (tests may use it); what is under test is the sharding logic: contiguous sensor
+blocks (livescan3d_amd/sharding.py), ownership and offsets of every rank's shard, the all-gathers (tests/exchange_rehearsal.py, the
+same protocol lsnShard* runs over RCCL), and the packing contracts of lsnMergeShards / lsnFusionPackSurvivors / lsnFusionReconstruct
+(restated in numpy below, because the HIP kernels need a GPU).  The merged cloud on every rank must
 equal the single-process merged cloud byte for byte, in formMesh's sensor order."""
 import os
 import socket
@@ -38,7 +40,8 @@ def _worker(rank, world, port, S, T, w, h, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from livescan3d_amd import synth
-    from livescan3d_amd.sharding import MergedCloudExchange, sensor_block
+    from livescan3d_amd.sharding import sensor_block
+    from tests.exchange_rehearsal import MergedCloudExchange
     from oracle import orc
     s0, s1 = sensor_block(S, world, rank)
     mpr = s1 - s0
@@ -69,21 +72,28 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("S", [2, 4])
-def test_two_rank_allgather_equals_single_process_merge(tmp_path, orc, S):
+def _check_every_rank(tmp_path, orc, world, S, T, w, h):
+    """Every rank's merged cloud and offset table equal the single-process merge of all S sensors, byte for byte."""
     from livescan3d_amd import synth
-    world, T, w, h = 2, 3, 64, 48
-    mp.spawn(_worker, args=(world, _free_port(), S, T, w, h, str(tmp_path)), nprocs=world, join=True)
-    m0, m1 = np.load(tmp_path / "merged_0.npy"), np.load(tmp_path / "merged_1.npy")
-    o0, o1 = np.load(tmp_path / "off_0.npy"), np.load(tmp_path / "off_1.npy")
-    assert np.array_equal(o0, o1)
+    merged = [np.load(tmp_path / f"merged_{r}.npy") for r in range(world)]
+    offs = [np.load(tmp_path / f"off_{r}.npy") for r in range(world)]
+    for o in offs[1:]:
+        assert np.array_equal(offs[0], o)
     for k in range(T):
         rig = synth.make_rig("scene" if k % 2 == 0 else "noise", S, w, h, seed=13, tick=k, bounds=synth.CROP_BOUNDS)
         want, counts = orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
-        n = int(o0[k, -1])
-        assert n == len(want) and list(np.diff(o0[k])) == list(counts)
-        for m in (m0, m1):                                  # every rank holds the whole merged cloud
+        n = int(offs[0][k, -1])
+        assert n == len(want) and list(np.diff(offs[0][k])) == list(counts)
+        for m in merged:                                    # every rank holds the whole merged cloud
             assert m[k, :n].tobytes() == want.tobytes()
+
+
+# (8, 8): BASELINE configs[3] -- 8 sensors sharded one per rank -- as a CPU rehearsal of ownership and offsets
+@pytest.mark.parametrize("world,S", [(2, 2), (2, 4), (8, 8)])
+def test_allgather_of_vertex_shards_equals_single_process_merge(tmp_path, orc, world, S):
+    T, w, h = (3, 64, 48) if world == 2 else (2, 64, 48)
+    mp.spawn(_worker, args=(world, _free_port(), S, T, w, h, str(tmp_path)), nprocs=world, join=True)
+    _check_every_rank(tmp_path, orc, world, S, T, w, h)
 
 
 def test_sensor_blocks():
@@ -105,7 +115,8 @@ def _survivor_worker(rank, world, port, S, T, w, h, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from types import SimpleNamespace
     from livescan3d_amd import synth
-    from livescan3d_amd.sharding import SurvivorExchange, sensor_block
+    from livescan3d_amd.sharding import sensor_block
+    from tests.exchange_rehearsal import SurvivorExchange
     from oracle import orc
     s0, s1 = sensor_block(S, world, rank)
     mpr, P = s1 - s0, w * h
@@ -172,17 +183,8 @@ def _survivor_worker(rank, world, port, S, T, w, h, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_survivor_exchange_equals_single_process_merge(tmp_path, orc):
-    from livescan3d_amd import synth
-    world, S, T, w, h = 2, 4, 2, 64, 48
+@pytest.mark.parametrize("world,S", [(2, 4), (8, 8)])
+def test_survivor_exchange_equals_single_process_merge(tmp_path, orc, world, S):
+    T, w, h = 2, 64, 48
     mp.spawn(_survivor_worker, args=(world, _free_port(), S, T, w, h, str(tmp_path)), nprocs=world, join=True)
-    m0, m1 = np.load(tmp_path / "merged_0.npy"), np.load(tmp_path / "merged_1.npy")
-    o0, o1 = np.load(tmp_path / "off_0.npy"), np.load(tmp_path / "off_1.npy")
-    assert np.array_equal(o0, o1)
-    for k in range(T):
-        rig = synth.make_rig("scene" if k % 2 == 0 else "noise", S, w, h, seed=13, tick=k, bounds=synth.CROP_BOUNDS)
-        want, counts = orc.generate_mesh_vertices(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
-        n = int(o0[k, -1])
-        assert n == len(want) and list(np.diff(o0[k])) == list(counts)
-        for m in (m0, m1):
-            assert m[k, :n].tobytes() == want.tobytes()
+    _check_every_rank(tmp_path, orc, world, S, T, w, h)
