@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--padded-exchange", action="store_true", help="N > 1: all-gather full-capacity slabs (no host sync)")
     ap.add_argument("--no-tick-parallel", action="store_true", help="N > 1: skip the extra tick-parallel (no-exchange) leg")
     ap.add_argument("--icp-reps", type=int, default=5)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--settle-seconds", type=float, default=0.5,
                     help="untimed steps run for this long before the --warmup steps so that the timed region reads settled clocks (reported as settle_ms)")
     args = ap.parse_args()
@@ -590,6 +590,21 @@ def main():
         with leg(result, "wire"):
             result["wire"] = bench_wire(args, torch, native, synth, dev, stream, S, w, h, bounds, with_cpu=not args.no_cpu)
 
+    # ---- the other BASELINE shapes, device resident (extra field): configs[4]'s 1-GPU share and one tick per call ----------------
+    if rank == 0 and not multi and args.mode == 0 and not args.core_only:
+        with leg(result, "shapes"):
+            result["shapes"] = bench_shapes(args, torch, synth, DeviceFusion, dev, dev_index)
+
+    # ---- the CPU side of the reference's tick (extra field): port timings for radial / mesh / whole tick, the reference's own triangulation ---
+    if rank == 0 and world == 1 and not args.no_cpu and not args.no_mesh:
+        with leg(result, "cpu_tick"):
+            result["cpu_tick"] = cpu_tick(synth, S, w, h)
+            for k_leg, k_cpu in (("mesh", "mesh_ms"), ("radial_correction", "radial_ms"), ("full_tick", "full_tick_ms")):
+                if isinstance(result.get(k_leg), dict):
+                    result[k_leg]["cpu_port_ms_per_tick"] = result["cpu_tick"][k_cpu]
+            if isinstance(result.get("mesh"), dict) and "reference_triangulation_ms" in result["cpu_tick"]:
+                result["mesh"]["cpu_reference_tri_ms_per_tick"] = result["cpu_tick"]["reference_triangulation_ms"]
+
     # ---- drop-in export on host buffers (PCIe-inclusive; never `value`) -----------------------------------------
     if rank == 0 and not args.no_host_path:
         with leg(result, "host_path"):
@@ -601,6 +616,9 @@ def main():
         with leg(result, "icp"):
             result["icp"] = bench_icp(args, torch, native, synth, dev, stream, with_cpu=(world == 1 and not args.no_cpu))
             result["icp_config2"] = result["icp"].pop("config2")
+            # the second half of BASELINE.json's metric ("... + ICP iter ms") as top-level scalars
+            result["icp_iter_ms"] = result["icp"]["iter_ms"]
+            result["icp_iter_ms_config2"] = result["icp_config2"]["iter_ms_grid"]
 
     # ---- the whole pose-refinement pass (H2 / f-3): N sensors x 2 refine passes x 10 ICP iterations in one call ---------
     if rank == 0 and not multi and not args.no_icp:
@@ -621,6 +639,84 @@ def main():
 
 
 PCIE_GBS = 63.0   # MI355X_MICROARCH.md: PCIe 5.0 x16, per direction
+
+
+def bench_shapes(args, torch, synth, DeviceFusion, dev, dev_index):
+    """BASELINE.json's other shapes on one GPU, device resident like the headline: configs[4]'s 1-GPU forms (16 x 1024x1024 = the whole
+    rig on one GPU, 2 x 1024x1024 = its per-GPU share at 8 GPUs) and the latency case (8 x 512x424, ONE tick per call).  Per shape:
+    ms per step, the write kernel's HBM fraction (HIP events inside the library) and the whole step's."""
+    out = {"note": "hash-noise frames, two-pass fusion; frac = (2 P + 19 V) bytes / write-kernel time / 8 TB/s, step_frac = the same bytes / step time"}
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, S, w, h, T in (("16x1024x1024_x8ticks", 16, 1024, 1024, 8), ("2x1024x1024_x32ticks", 2, 1024, 1024, 32), ("8x512x424_x1tick", 8, 512, 424, 1)):
+        P = w * h
+        rig = synth.make_rig("noise", S, w, h, seed=1, bounds=synth.CROP_BOUNDS)
+        fus = DeviceFusion(T, [w] * S, [h] * S, device=dev_index, mode=0)
+        fus.set_params(rig.intr, rig.wt, rig.bounds)
+        d, c = synth.noise_frames_torch(dev, 1, T, S, w, h)
+        d, c = d.view(T, S * P), c.view(T, S * P * 3)
+        for _ in range(4):
+            fus.run(d, c)
+        torch.cuda.synchronize()
+        n = max(20, min(400, int(0.25 / max(1e-5, 2e-9 * T * S * P))))      # ~0.25 s of steps
+        fus.plan.profile(True)
+        fus.plan.kernel_stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fus.run(d, c)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        ks = fus.plan.kernel_stats(reset=True)
+        fus.plan.profile(False)
+        V = int(fus.offsets[:, -1].sum().item())
+        alg = 2 * P * S * T + 19 * V
+        out[name] = {"sensors": S, "width": w, "height": h, "ticks_per_step": T, "ms_per_step": 1e3 * dt, "frames_per_s": T / dt,
+                     "kernel": ks["kernel"], "kernel_avg_ms": ks["avg_ms"], "algorithmic_bytes_per_step": alg,
+                     "frac": alg / (ks["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if ks["avg_ms"] > 0 else None,
+                     "step_frac": alg / dt / 1e9 / HBM_PEAK_GBS}
+        del fus, d, c
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_tick(synth, S, w, h):
+    """One tick of the reference's real work on the host CPU, per stage, on scene frames (the same generator the GPU legs use):
+    the port (oracle/lsn_oracle.c, single thread unless stated) and, where it can be built, the reference's own code."""
+    from oracle import orc
+    rig = synth.make_rig("scene", S, w, h, seed=4, tick=0)
+
+    def best_of(fn, reps=3):
+        best, val = float("inf"), None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            val = fn()
+            best = min(best, time.perf_counter() - t0)
+        return 1e3 * best, val
+
+    threads = min(S, os.cpu_count() or 1)
+    radial_ms, corrected = best_of(lambda: orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, n_threads=threads))
+    cd = np.ascontiguousarray(np.asarray(corrected[0])).view(np.uint8).ravel()
+    cc = np.ascontiguousarray(np.asarray(corrected[1])).ravel()
+    mesh_ms, mesh = best_of(lambda: orc.generate_mesh(cd, cc, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds))
+    out = {"workload": f"one tick of {S} x {w}x{h} scene frames", "kind": "port",
+           "radial_ms": radial_ms, "radial_threads": threads, "mesh_ms": mesh_ms, "mesh_threads": 1, "full_tick_ms": radial_ms + mesh_ms,
+           "vertices": int(len(mesh[0])), "triangles": int(len(mesh[2])),
+           "note": "radial: depthMapAndColorSetRadialCorrection's port, one thread per sensor like depthprocessing.cpp:1794-1815; mesh: "
+                   "createVertices + generateTrianglesGradients + formMesh, sensors one after the other; best of 3"}
+    if orc.have_ref_tri():
+        # the REFERENCE's own triangulation (src/NativeUtils/meshGenerator.cpp compiled in place, 4 row-band threads inside like the
+        # reference runs it) on the same corrected frames, sensor after sensor -- what cpu_reference_tri_ms reports
+        P = w * h
+        maps = []
+        for i in range(S):
+            d = cd.view(np.uint16)[i * P:(i + 1) * P].reshape(h, w)
+            c = cc[3 * i * P:3 * (i + 1) * P].reshape(h, w, 3)
+            _, _, p2v = orc.create_vertices(d, c, rig.intr[7 * i:7 * i + 7], rig.wt[12 * i:12 * i + 12], rig.bounds, want_maps=True)
+            maps.append((np.ascontiguousarray(d), np.ascontiguousarray(p2v.reshape(h, w))))
+        ref_ms, n_tri = best_of(lambda: sum(len(orc.ref_triangles(d, m)) for d, m in maps))
+        out["reference_triangulation_ms"] = ref_ms
+        out["reference_triangulation_kind"] = "reference (meshGenerator.cpp:147-181 compiled in place, its own 4 threads), all sensors of the tick one after the other"
+        out["reference_triangles"] = int(n_tri)
+    return out
 
 
 def bench_host_path(native, synth, S, w, h, bounds):
@@ -1170,7 +1266,9 @@ def cpu_baseline(args, synth, S, w, h, bounds):
     config0 = {"workload": "configs[0]: 1 x 512x424, CPU port, 1 thread", "ms_per_frame": ms0, "frames_per_s": 1e3 / ms0,
                "algorithmic_GBps": (2 * 512 * 424 + 19 * len(v0)) / (ms0 * 1e-3) / 1e9}
     return {"config0": config0, "value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} merge calls of {S} x {w}x{h} (same generator, tick 0) in {dt:.1f} s, {threads} threads (one per sensor), host has {cores} cores",
+            "sample": f"{n} merge calls of {S} x {w}x{h} (same generator, tick 0) in {dt:.1f} s, {threads} threads (one per sensor), host has {cores} cores; "
+                      "the threaded figure is allocation- and concatenation-bound like the reference it mirrors (a 28 MB scratch malloc'ed and page-faulted "
+                      "per call, the per-sensor clouds concatenated serially: oracle/lsn_oracle.c:98-111 = depthprocessing.cpp:128-136,1578-1608), not compute-bound",
             "single_thread_value": n1 / dt1, "host": host_description()}
 
 

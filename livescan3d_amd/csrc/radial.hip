@@ -1083,6 +1083,19 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
         return -1;
     }
     const size_t npix = (size_t)p->cap * p->n_ticks;
+    if (!in_place) {
+        // out of place the bands warp straight from the input (no scratch copy): an output range that overlaps an input range in part
+        // would be overwritten by one band while another still reads it as a warp source
+        auto overlap = [](const void *a, size_t na, const void *b, size_t nb) {
+            const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+            return x < y + nb && y < x + na;
+        };
+        if (overlap(d_depth_in, 2 * npix, d_depth, 2 * npix) || overlap(d_colors_in, 3 * npix, d_colors, 3 * npix) ||
+            overlap(d_depth_in, 2 * npix, d_colors, 3 * npix) || overlap(d_colors_in, 3 * npix, d_depth, 2 * npix)) {
+            lsn::set_error("lsnFusionRadialCorrectTo: the output buffers overlap the input buffers in part (pass the same pointers for an in-place correction)");
+            return -1;
+        }
+    }
     if (p->radial.reserve(sizeof(RadialParams) * p->n_maps)) return -1;
     std::vector<RadialParams> rp(p->n_maps);
     for (int i = 0; i < p->n_maps; i++) {
@@ -1199,10 +1212,15 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
     const long long holes_tick_bytes = (((p->cap + 64ll * (p->n_maps + 1)) / 8) + 31) & ~15ll;
     const size_t cnt_bytes = 3 * sizeof(int) * kCntStride * (size_t)n_tf;
     if (p->holes.reserve((size_t)holes_tick_bytes * p->n_ticks + 64) || p->work.reserve(8 * npix + 64) || p->work2.reserve(4 * npix + 64)) return -1;
+    // The second pass leaves every counter cleared -- when it has run to its end.  A call that failed between the band kernel and the
+    // per-frame kernel (a launch error), or one that took another closing route after the band kernel, leaves counts behind: the
+    // counters are cleared here unless the previous chain is known to have been enqueued completely.
     if (p->work_cnt.bytes < cnt_bytes) {
         if (p->work_cnt.reserve(cnt_bytes)) return -1;
-        LSN_HIP(hipMemsetAsync(p->work_cnt.p, 0, cnt_bytes, s));   // the second pass leaves every counter cleared
+        p->work_cnt_clean = false;
     }
+    if (!p->work_cnt_clean) LSN_HIP(hipMemsetAsync(p->work_cnt.p, 0, p->work_cnt.bytes, s));
+    p->work_cnt_clean = false;
     if (!vec) LSN_HIP(hipMemsetAsync(p->holes.p, 0, (size_t)holes_tick_bytes * p->n_ticks, s));   // the pixel-by-pixel pass only sets bits
     BandArgs ba;
     ba.frames = p->frames.as<FrameDesc>();
@@ -1263,6 +1281,7 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
     }
     hipLaunchKernelGGL(close_fix_kernel, dim3((unsigned)n_tf), dim3(kFixThreads), 0, s, fa);
     LSN_HIP(hipGetLastError());
+    p->work_cnt_clean = true;
     return 0;
 }
 

@@ -184,3 +184,39 @@ def test_one_call_per_tick_equals_the_two_exports(gpu, orc):
         want_d, want_c = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
         want_v, _, want_t = orc.generate_mesh(want_d, want_c, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
         assert np.array_equal(d2, np.asarray(want_d).view(np.uint8).ravel()) and v2.tobytes() == want_v.tobytes() and np.array_equal(t2, want_t)
+
+
+def test_partly_overlapping_buffers_are_refused_and_route_switches_leave_no_stale_counts(gpu, orc, monkeypatch):
+    """Out of place the bands warp straight from the input: an output that overlaps the input IN PART would be overwritten by one band
+    while another still reads it, so the entry point refuses it (identical pointers = in place, disjoint = out of place).  And a call that
+    takes the wavefront closing after the band kernel must not leave work-list counts behind for the next two-pass call."""
+    import torch
+    T, N, w, h = 2, 2, 256, 212
+    rigs = [synth.make_rig("scene", N, w, h, seed=31, tick=k) for k in range(T)]
+    plan = native.FusionPlan(0, T, rigs[0].widths, rigs[0].heights)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    npix = T * N * w * h
+    big_d = torch.zeros(2 * npix, dtype=torch.int16, device="cuda")
+    big_c = torch.zeros(6 * npix, dtype=torch.uint8, device="cuda")
+    big_d[:npix] = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs]).ravel()).cuda()
+    big_c[:3 * npix] = torch.from_numpy(np.stack([r.depth_colors for r in rigs]).ravel()).cuda()
+    with pytest.raises(native.NativeUtilsError, match="overlap"):
+        plan.radial_correct_to(rigs[0].intr, big_d.data_ptr(), big_c.data_ptr(), big_d.data_ptr() + 2 * (npix // 2), big_c.data_ptr() + 3 * npix, st)
+    with pytest.raises(native.NativeUtilsError, match="overlap"):
+        plan.radial_correct_to(rigs[0].intr, big_d.data_ptr(), big_c.data_ptr(), big_d.data_ptr() + 2 * npix, big_c.data_ptr() + 16, st)
+    want = [orc.radial_correction(r.depth_maps, r.depth_colors, r.widths, r.heights, rigs[0].intr) for r in rigs]
+
+    def run_and_check(tag):
+        plan.radial_correct_to(rigs[0].intr, big_d.data_ptr(), big_c.data_ptr(), big_d.data_ptr() + 2 * npix, big_c.data_ptr() + 3 * npix, st)
+        torch.cuda.synchronize()
+        got_d = big_d[npix:].cpu().numpy().view(np.uint8).reshape(T, -1)
+        got_c = big_c[3 * npix:].cpu().numpy().reshape(T, -1)
+        for k in range(T):
+            assert np.array_equal(got_d[k], np.asarray(want[k][0]).view(np.uint8).ravel()), f"{tag}: tick {k} depth"
+            assert np.array_equal(got_c[k], np.asarray(want[k][1]).ravel()), f"{tag}: tick {k} colours"
+
+    run_and_check("two-pass")
+    monkeypatch.setenv("LSN_RADIAL_CLOSE", "wavefront")
+    run_and_check("wavefront")
+    monkeypatch.delenv("LSN_RADIAL_CLOSE")
+    run_and_check("two-pass after the wavefront route")
