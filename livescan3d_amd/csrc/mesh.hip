@@ -25,7 +25,7 @@ struct TriArgs {
     unsigned int *codes; // [n_ticks * tiles_per_tick * 256] per-lane 4-bit-per-pixel triangle codes: count pass -> write pass
     int tiles_per_tick;
     int win;                    // triangles staged per LDS round of the write pass
-    int host_out;               // `tri` is pinned host memory: plain stores, rounds aligned to the destination (stage_and_store's note)
+    int host_out;               // `tri` is pinned host memory: the launch picks the HOST form of the write pass
     long long tick_pix_stride;  // pixels per tick
     long long tick_tri_stride;  // triangles per tick (capacity)
 };
@@ -155,7 +155,10 @@ __device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerL
 }
 
 // MODE 0 = count triangles per tile, 1 = write them at the scanned offsets.
-template <int MODE, bool VEC>
+// HOST (write pass): `tri` is pinned host memory -- plain stores, rounds aligned to the destination (stage_and_store's note).  A template
+// parameter, not a run-time flag: a run-time choice between a streaming and a plain store of the same value to the same address is
+// folded into ONE plain store by the compiler, and the device-resident path loses its streaming stores (65.8 against 71.7 k ticks/s).
+template <int MODE, bool VEC, bool HOST = false>
 __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const TriArgs a)
 {
     extern __shared__ int stage[];   // write pass: stage_ints(a.win) + 3 * 64 ints
@@ -361,9 +364,9 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
             const int end = lead + n;                      // in ints, relative to the aligned start of the first chunk
             const int c0 = lead ? 1 : 0, c1 = end >> 2;     // chunks [c0, c1) are whole
             int4 *g16 = reinterpret_cast<int4 *>(out - lead);
-            const int mis = a.host_out ? (int)((reinterpret_cast<uintptr_t>(g16 + c0) >> 4) & 63) : 0;
+            const int mis = HOST ? (int)((reinterpret_cast<uintptr_t>(g16 + c0) >> 4) & 63) : 0;
             for (int j = c0 + (int)threadIdx.x - mis; j < c1; j += kThreads) {
-                if (j < c0) continue;
+                if (HOST && j < c0) continue;
                 int4 v;                                     // written once, never read again by this launch sequence
                 const unsigned int o = (unsigned int)(4 * j - lead), q = o / 48u, rem = o - 48u * q;   // one division per chunk: a pad may fall inside it
                 const int ph = 4 * j + (int)q;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
                 v.y = stage[ph + 1 + (rem + 1 >= 48u)];
                 v.z = stage[ph + 2 + (rem + 2 >= 48u)];
                 v.w = stage[ph + 3 + (rem + 3 >= 48u)];
-                if (a.host_out) {
+                if (HOST) {
                     g16[j] = v;
                 } else {
                     __builtin_nontemporal_store(v.x, &g16[j].x);
@@ -422,8 +425,13 @@ static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles,
     if (hooks && hooks->h_tri_offsets && !mirror)
         LSN_HIP(hipMemcpyAsync(hooks->h_tri_offsets, d_tri_offsets, sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1), hipMemcpyDeviceToHost, s));
     if (hooks && hooks->tri_counted) LSN_HIP(hipEventRecord(hooks->tri_counted, s));
-    if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
-    else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
+    if (t.host_out) {
+        if (vec) hipLaunchKernelGGL((tri_kernel<1, true, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
+        else     hipLaunchKernelGGL((tri_kernel<1, false, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
+    } else {
+        if (vec) hipLaunchKernelGGL((tri_kernel<1, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
+        else     hipLaunchKernelGGL((tri_kernel<1, false>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
+    }
     LSN_HIP(hipGetLastError());
     return 0;
 }
