@@ -22,12 +22,13 @@
 //     crosses the link.  So a group is ONE launch: the single-pass form of the fusion (fuse_kernel<4>: a tile keeps its vertices
 //     in registers, publishes its count, finds its offset by look-back -- over the tiles of the earlier groups too), no count
 //     kernel, no scan; the triangle passes run once, behind the last group, over the whole tick;
-//   * calls that START WITH THE RADIAL CORRECTION (lsnCorrectAndGenerateMesh) keep round 3's flow -- output in HBM, copy engine
-//     home behind the count: ~100 us of latency-bound closing rounds per group cannot hide behind the previous group's stores
-//     (same probe), measured 1.32 against 1.17 ms;
-//   * registering the caller's arrays (hipHostRegister) was measured again: 1.4 ms to register 8.7 MB, copies from registered
-//     memory 43 GB/s, kernel loads from it 40 GB/s -- slower than the pageable copy.  The cache stays OFF unless $LSN_HOST_REGISTER=1.
-// $LSN_HOST_PATH=copy selects round 3's flow for every call (A/B runs); $LSN_HOST_GROUP=n fixes the sensors per group.
+//   * so kernel stores are the form for ONE small group (a single-sensor call: one launch, no count round trip).  Calls of several
+//     groups, and calls that start with the radial correction (~100 us of latency-bound closing rounds per group), build the mesh
+//     in HBM and let the COPY ENGINE take it home group by group (fuse_host_grouped): the engine runs beside the kernels, and the
+//     length a DMA needs comes from a pinned word the group's last tile writes, read behind the launch's event;
+//   * registering the caller's arrays (hipHostRegister) was measured in rounds 2 and 4: 1.4 ms to register 8.7 MB, copies from
+//     registered memory 43 GB/s, kernel loads from it 40 GB/s -- slower than the pageable copy; the opt-in cache of round 2 is gone.
+// $LSN_HOST_PATH=direct / grouped forces one flow for every call (A/B runs); $LSN_HOST_GROUP=n fixes the sensors per group.
 #include "lsn_common.hpp"
 
 #include <atomic>
@@ -228,9 +229,9 @@ constexpr int kMaxGroups = 16;
 
 struct Lane {
     std::mutex mu;
-    hipStream_t stream = nullptr, up = nullptr, down = nullptr;
-    hipEvent_t ev_depth = nullptr, ev_col = nullptr, ev_counted = nullptr, ev_written = nullptr, ev_tri_counted = nullptr, ev_down = nullptr;
-    hipEvent_t ev_group[kMaxGroups] = {};    // "group g's corrected maps are final" (the write-back of the one-call tick waits for it)
+    hipStream_t stream = nullptr, up = nullptr, down = nullptr, back = nullptr;   // kernels; uploads; mesh downloads; write-backs of corrected maps
+    hipEvent_t ev_group[kMaxGroups] = {};    // "group g's vertices are in HBM (and its corrected maps final)"
+    hipEvent_t ev_tri = nullptr;             // "the triangle counts are known"
     int *h_off = nullptr, *h_toff = nullptr;   // pinned: the offset tables of the call in progress
     int h_off_cap = 0;
     lsn::DevBuf d_depth, d_colors, d_depth2, d_colors2, d_out, d_off, d_tri, d_tri_off;
@@ -255,7 +256,7 @@ struct Ctx {
     std::atomic<Lane *> last_lane{nullptr};   // the lane whose call finished last: lsnLastMesh* read the mesh it left in HBM
     bool ready = false;
     int device = 0;
-    bool direct = true;       // $LSN_HOST_PATH=copy: round 3's flow (output in HBM, copy engine home) for A/B runs
+    int host_path = 0;        // $LSN_HOST_PATH: 0 = by call (default), 1 = "direct" (kernel stores) always, 2 = "grouped" (copy engine) always
     int group_override = 0;   // $LSN_HOST_GROUP: sensors per group (0 = by size)
     hipStream_t icp_stream = nullptr;
     lsn::DevBuf d_v1, d_v2, d_Rt;
@@ -268,17 +269,6 @@ struct Ctx {
     LsnTransfer *xfer = nullptr;
     int xfer_v = 0, xfer_t = 0;
     lsn::DevBuf d_wire;
-    // caller ranges registered with the runtime (opt-in, see the file comment)
-    struct Reg {
-        const char *base;
-        size_t bytes;
-        unsigned long long last_use;
-    };
-    std::vector<Reg> regs;
-    std::vector<std::pair<const void *, size_t>> seen;   // ranges of the last calls that are not registered (yet)
-    std::vector<std::pair<const void *, size_t>> refused; // ranges the runtime would not register: not tried again
-    unsigned long long use_clock = 0;
-    bool reg_enabled = false;   // $LSN_HOST_REGISTER=1
     bool warned_flags = false;
 };
 
@@ -308,79 +298,14 @@ int ensure_ready(Ctx &c)
     LSN_HIP(hipSetDevice(c.device));
     LSN_HIP(hipStreamCreateWithFlags(&c.icp_stream, hipStreamNonBlocking));
     for (Lane *l : {&c.merge, &c.single}) {
-        for (hipStream_t *s : {&l->stream, &l->up, &l->down}) LSN_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-        for (hipEvent_t *e : {&l->ev_depth, &l->ev_col, &l->ev_counted, &l->ev_written, &l->ev_tri_counted, &l->ev_down})
-            LSN_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipStream_t *s : {&l->stream, &l->up, &l->down, &l->back}) LSN_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+        LSN_HIP(hipEventCreateWithFlags(&l->ev_tri, hipEventDisableTiming));
         for (int i = 0; i < kMaxGroups; i++) LSN_HIP(hipEventCreateWithFlags(&l->ev_group[i], hipEventDisableTiming));
     }
-    if (const char *e = getenv("LSN_HOST_REGISTER")) c.reg_enabled = atoi(e) != 0;
-    if (const char *e = getenv("LSN_HOST_PATH")) c.direct = strcmp(e, "copy") != 0;
+    if (const char *e = getenv("LSN_HOST_PATH")) c.host_path = !strcmp(e, "direct") ? 1 : (!strcmp(e, "grouped") || !strcmp(e, "copy")) ? 2 : 0;
     if (const char *e = getenv("LSN_HOST_GROUP")) c.group_override = atoi(e);
     c.ready = true;
     return 0;
-}
-
-constexpr size_t kPage = 4096;
-constexpr size_t kRegMaxRanges = 16;
-constexpr size_t kRegMaxBytes = (size_t)1 << 30;
-
-void reg_drop(Ctx &c, size_t i)
-{
-    (void)hipHostUnregister(const_cast<char *>(c.regs[i].base));  // fails when the caller has freed the memory meanwhile: nothing to undo then
-    (void)hipGetLastError();
-    c.regs.erase(c.regs.begin() + (long)i);
-}
-
-// True when [p, p + bytes) lies inside a range registered with the runtime (copies from it then run as DMA out of the
-// caller's pages).  A range is registered on its second sighting -- one-off buffers are not worth the ~millisecond the
-// registration costs.  may_register = false only looks the range up.
-bool host_range_pinned(Ctx &c, const void *p, size_t bytes, bool may_register)
-{
-    if (!c.reg_enabled || !p || bytes < 65536) return false;
-    std::lock_guard<std::mutex> tg(c.tab_mu);
-    const char *b = static_cast<const char *>(p);
-    c.use_clock++;
-    for (auto &r : c.regs)
-        if (b >= r.base && b + bytes <= r.base + r.bytes) {
-            r.last_use = c.use_clock;
-            return true;
-        }
-    if (!may_register) return false;
-    for (auto &r : c.refused)
-        if (r.first == p && r.second == bytes) return false;
-    bool second = false;
-    for (auto &r : c.seen)
-        if (r.first == p && r.second == bytes) second = true;
-    if (!second) {
-        if (c.seen.size() >= 16) c.seen.erase(c.seen.begin());
-        c.seen.emplace_back(p, bytes);
-        return false;
-    }
-    // registered ranges may not overlap (page granularity): whatever the new range touches goes first
-    const uintptr_t lo = (uintptr_t)b & ~(kPage - 1), hi = ((uintptr_t)b + bytes + kPage - 1) & ~(kPage - 1);
-    for (size_t i = c.regs.size(); i-- > 0;) {
-        const uintptr_t rl = (uintptr_t)c.regs[i].base & ~(kPage - 1), rh = ((uintptr_t)c.regs[i].base + c.regs[i].bytes + kPage - 1) & ~(kPage - 1);
-        if (rl < hi && lo < rh) reg_drop(c, i);
-    }
-    size_t total = bytes;
-    for (auto &r : c.regs) total += r.bytes;
-    while (!c.regs.empty() && (c.regs.size() >= kRegMaxRanges || total > kRegMaxBytes)) {
-        size_t lru = 0;
-        for (size_t i = 1; i < c.regs.size(); i++)
-            if (c.regs[i].last_use < c.regs[lru].last_use) lru = i;
-        total -= c.regs[lru].bytes;
-        reg_drop(c, lru);
-    }
-    for (size_t i = c.seen.size(); i-- > 0;)
-        if (c.seen[i].first == p && c.seen[i].second == bytes) c.seen.erase(c.seen.begin() + (long)i);
-    if (hipHostRegister(const_cast<char *>(b), bytes, hipHostRegisterDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        if (c.refused.size() >= 16) c.refused.erase(c.refused.begin());
-        c.refused.emplace_back(p, bytes);
-        return false;
-    }
-    c.regs.push_back({b, bytes, c.use_clock});
-    return true;
 }
 
 // waits for everything the context has in flight on the merge streams (error paths: no copy may touch the caller's arrays
@@ -390,6 +315,7 @@ void drain(Lane &l)
     (void)hipStreamSynchronize(l.up);
     (void)hipStreamSynchronize(l.stream);
     (void)hipStreamSynchronize(l.down);
+    (void)hipStreamSynchronize(l.back);
     (void)hipGetLastError();
 }
 
@@ -491,143 +417,6 @@ int ensure_tables(Lane &l, int n)
     LSN_HIP(hipHostMalloc((void **)&l.h_off, sizeof(int) * (size_t)(n + 64), hipHostMallocDefault));
     LSN_HIP(hipHostMalloc((void **)&l.h_toff, sizeof(int) * (size_t)(n + 64), hipHostMallocDefault));
     l.h_off_cap = n + 64;
-    return 0;
-}
-
-// Fuses `count` sensors of one tick from host buffers into out_mesh.  first/count select the sensors
-// (generateVerticesFromDepthMap uses one); total_d / total_c are the bytes of the caller's whole arrays as far as the call
-// knows them (what gets registered).  c.mu held.
-// radial (optional): the call starts with the radial correction of the frames (depthMapAndColorSetRadialCorrection) on the device;
-// radial_back_d / radial_back_c (optional): the corrected maps are also copied to these host arrays, like the separate export does.
-int fuse_host_copy(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, size_t total_d, size_t total_c,
-                   const int *widths, const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first,
-                   int count, bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr,
-                   unsigned char *radial_back_c = nullptr)
-{
-    l.groups.clear();
-    l.last_plan = nullptr;
-    LsnFusion *plan = get_plan(c, l, widths, heights, first, count);
-    if (!plan) return -1;
-    l.last_plan = plan;
-    // sensor `first` starts after the frames before it (depthprocessing.cpp:1646-1650)
-    size_t dskip = 0, cskip = 0, dbytes = 0, cbytes = 0;
-    for (int i = 0; i < first; i++) {
-        dskip += (size_t)widths[i] * heights[i] * 2;
-        cskip += (size_t)widths[i] * heights[i] * 3;
-    }
-    for (int i = 0; i < count; i++) {
-        dbytes += (size_t)widths[first + i] * heights[first + i] * 2;
-        cbytes += (size_t)widths[first + i] * heights[first + i] * 3;
-    }
-    l.last_nv = -1;                                   // d_out / d_tri are about to be overwritten (or reallocated)
-    const long long cap = lsnFusionTickCapacity(plan);
-    if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_out.reserve((size_t)cap * 16) ||
-        l.d_off.reserve(sizeof(int) * (count + 1)))
-        return -1;
-    if (ensure_tables(l, count + 1)) return -1;
-    // the merge call sees the whole arrays the caller keeps from tick to tick: those get registered; a single-sensor call
-    // (which only knows a prefix of them) profits when its slice lies inside
-    (void)host_range_pinned(c, depth_maps, total_d, with_triangles);
-    (void)host_range_pinned(c, depth_colors, total_c, with_triangles);
-
-    // A small call (one sensor: ~1 MB up, ~2 MB down) is all fixed latency: every hand-over between streams costs more than the
-    // overlap could win, so it runs on ONE stream.  A big call goes depth first (the count pass needs nothing else), colours
-    // behind it on the upload stream, kernels on the main stream, vertices home on the download stream.
-    const bool small = dbytes + cbytes < ((size_t)4 << 20);
-    hipStream_t up = small ? l.stream : l.up, down = small ? l.stream : l.down;
-    LSN_HIP(hipMemcpyAsync(l.d_depth.p, depth_maps + dskip, dbytes, hipMemcpyHostToDevice, up));
-    if (!small) LSN_HIP(hipEventRecord(l.ev_depth, up));
-    LSN_HIP(hipMemcpyAsync(l.d_colors.p, depth_colors + cskip, cbytes, hipMemcpyHostToDevice, up));
-    if (!small) LSN_HIP(hipEventRecord(l.ev_col, up));
-    if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, l.stream)) return -1;
-    if (!small) LSN_HIP(hipStreamWaitEvent(l.stream, l.ev_depth, 0));
-    const void *run_d = l.d_depth.p, *run_c = l.d_colors.p;
-    if (radial) {
-        // the correction reads depth and colours of the raw frames and leaves the corrected ones in a second pair of buffers, which
-        // the passes below then read; the corrected maps go home on the download stream while the fusion kernels run
-        if (l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16)) return -1;
-        if (!small) LSN_HIP(hipStreamWaitEvent(l.stream, l.ev_col, 0));
-        if (lsnFusionRadialCorrectTo(plan, intr + 7 * first, l.d_depth.p, l.d_colors.p, l.d_depth2.p, l.d_colors2.p, l.stream)) return -1;
-        run_d = l.d_depth2.p;
-        run_c = l.d_colors2.p;
-        if (radial_back_d && radial_back_c) {
-            LSN_HIP(hipEventRecord(l.ev_down, l.stream));
-            if (!small) LSN_HIP(hipStreamWaitEvent(down, l.ev_down, 0));
-            LSN_HIP(hipMemcpyAsync(radial_back_d + dskip, l.d_depth2.p, dbytes, hipMemcpyDeviceToHost, down));
-            LSN_HIP(hipMemcpyAsync(radial_back_c + cskip, l.d_colors2.p, cbytes, hipMemcpyDeviceToHost, down));
-        }
-    }
-    lsn::RunHooks hooks;
-    hooks.colours_ready = (small || radial) ? nullptr : l.ev_col;
-    hooks.h_offsets = l.h_off;
-    hooks.counted = l.ev_counted;
-    hooks.written = l.ev_written;
-    l.h_toff[count] = 0;
-    if (with_triangles) {
-        const long long tcap = lsnFusionTickTriangleCapacity(plan);
-        if (l.d_tri.reserve((size_t)tcap * 12) || l.d_tri_off.reserve(sizeof(int) * (count + 1))) return -1;
-        hooks.h_tri_offsets = l.h_toff;
-        hooks.tri_counted = l.ev_tri_counted;
-        if (lsn::run_mesh(plan, run_d, run_c, l.d_out.p, l.d_off.as<int>(), l.d_tri.p, l.d_tri_off.as<int>(), l.stream, &hooks))
-            return -1;
-    } else {
-        if (lsn::run_hooked(plan, run_d, run_c, l.d_out.p, l.d_off.as<int>(), l.stream, &hooks)) return -1;
-    }
-    // the vertex count arrives while the write pass (and the triangulation) are still running
-    LSN_HIP(hipEventSynchronize(l.ev_counted));
-    const int nv = l.h_off[count];
-    if (nv < 0 || nv > cap) {
-        lsn::set_error("NativeUtils: device returned an impossible vertex count %d", nv);
-        return -1;
-    }
-    void *host = pinned_get(c, (size_t)nv * sizeof(VertexC4ubV3f));
-    if (!host) return -1;
-    if (nv > 0) {
-        // the vertices leave on their own stream as soon as the write pass is done
-        if ((!small && hipStreamWaitEvent(down, l.ev_written, 0) != hipSuccess) ||
-            hipMemcpyAsync(host, l.d_out.p, (size_t)nv * sizeof(VertexC4ubV3f), hipMemcpyDeviceToHost, down) != hipSuccess) {
-            lsn::set_error("NativeUtils: vertex download failed: %s", hipGetErrorString(hipGetLastError()));
-            drain(l);
-            pinned_put(c, host);
-            return -1;
-        }
-    }
-    int nt = 0;
-    void *host_tri = nullptr;
-    if (with_triangles) {
-        bool bad = hipEventSynchronize(l.ev_tri_counted) != hipSuccess;
-        nt = bad ? 0 : l.h_toff[count];
-        if (!bad && (nt < 0 || nt > 2 * cap)) {
-            lsn::set_error("NativeUtils: device returned an impossible triangle count %d", nt);
-            bad = true;
-        }
-        if (!bad && nt > 0) {
-            host_tri = pinned_get(c, (size_t)nt * 12);
-            bad = !host_tri || hipMemcpyAsync(host_tri, l.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, l.stream) != hipSuccess;
-        }
-        if (bad) {
-            if (!lsn::has_error()) lsn::set_error("NativeUtils: triangle download failed: %s", hipGetErrorString(hipGetLastError()));
-            drain(l);
-            pinned_put(c, host);
-            if (host_tri) pinned_put(c, host_tri);
-            return -1;
-        }
-    }
-    if (hipStreamSynchronize(l.stream) != hipSuccess || hipStreamSynchronize(l.down) != hipSuccess) {
-        lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
-        drain(l);
-        pinned_put(c, host);
-        if (host_tri) pinned_put(c, host_tri);
-        return -1;
-    }
-    l.last_nv = nv;
-    l.last_nt = nt;
-    l.last_in_hbm = true;
-    out->nVertices = nv;
-    out->vertices = static_cast<VertexC4ubV3f *>(host);
-    out->nTriangles = nt;
-    out->triangles = nt > 0 ? static_cast<int *>(host_tri) : g_no_triangles;
-    c.last_lane.store(&l);
     return 0;
 }
 
@@ -830,12 +619,12 @@ int fuse_host_direct(Ctx &c, Lane &l, const unsigned char *depth_maps, const uns
                 if (back && hipEventRecord(l.ev_group[next_group], l.stream) != hipSuccess) return fail();
             }
             if (lsn::run_frames(plan, run_d, run_c, host, l.d_off.as<int>(), g.first - first, g.first - first + g.count, next_group == 0, with_triangles,
-                                l.h_off, l.stream))
+                                l.h_off, nullptr, true, l.stream))
                 return fail();
             tr.mark("launch");
         }
     }
-    if (with_triangles && lsn::run_triangles(plan, run_d, host_tri, l.d_tri_off.as<int>(), l.h_toff, l.stream)) return fail();
+    if (with_triangles && lsn::run_triangles(plan, run_d, host_tri, l.d_tri_off.as<int>(), l.h_toff, true, l.stream)) return fail();
     if (back) {
         // the corrected maps go home group by group (copy engine, pageable destination: each copy blocks) while the launches run
         for (size_t k = 0; k < G; k++) {
@@ -885,6 +674,179 @@ int fuse_host_direct(Ctx &c, Lane &l, const unsigned char *depth_maps, const uns
     return 0;
 }
 
+// The same call with the mesh built in HBM and the copy engine taking it home -- the form for calls of several groups and for calls
+// that start with the radial correction.  While a kernel streams to host memory no other kernel completes (file comment), so with
+// several groups the storing launches serialise with everything else; the copy engine does not have that problem: group g's
+// vertices leave (pinned destination, asynchronous) while group g+1 uploads, is corrected and fused.  What a DMA needs and a
+// storing kernel does not is a LENGTH: the last tile of a group's launch leaves the group's end offset in a pinned word, and the
+// host reads it once the launch's event has fired -- by then it has uploaded the next group, so the wait is short or none.
+int fuse_host_grouped(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths, const int *heights,
+                      const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count, bool with_triangles, bool radial,
+                      unsigned char *radial_back_d, unsigned char *radial_back_c)
+{
+    l.last_nv = -1;
+    l.last_plan = nullptr;
+    static const bool trace_env = getenv("LSN_HOST_TRACE") && atoi(getenv("LSN_HOST_TRACE")) != 0;
+    static std::atomic<int> trace_calls{0};
+    PhaseTrace tr;
+    if (trace_env) {
+        const int k = trace_calls++;
+        tr.on = k >= 10 && k < 13;
+    }
+    tr.mark("enter");
+    l.groups.clear();
+    LsnFusion *plan = get_plan(c, l, widths, heights, first, count);
+    if (!plan) return -1;
+    l.last_plan = plan;
+    if (make_schedule(c, l, widths, heights, first, count, radial)) return -1;
+    const size_t G = l.groups.size();
+    size_t dbytes = 0, cbytes = 0;
+    for (const Group &g : l.groups) {
+        dbytes += g.dbytes;
+        cbytes += g.cbytes;
+    }
+    const long long cap = lsnFusionTickCapacity(plan);
+    const int n_tab = count + 2 + (int)G;   // offsets [count + 1], give-up flag, then the groups' end offsets
+    if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_out.reserve((size_t)cap * 16) ||
+        l.d_off.reserve(sizeof(int) * (size_t)(count + 1)) || l.d_tri_off.reserve(sizeof(int) * (size_t)(count + 1)) || ensure_tables(l, n_tab))
+        return -1;
+    if (radial && (l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16))) return -1;
+    if (with_triangles && l.d_tri.reserve((size_t)cap * 2 * 12)) return -1;
+    const bool back = radial && radial_back_d && radial_back_c;
+    void *host = pinned_get(c, (size_t)cap * sizeof(VertexC4ubV3f));   // capacity-sized: the first vertices leave before the count is known
+    void *host_tri = nullptr;
+    auto fail = [&]() {
+        drain(l);   // nothing of a failed call stays in flight: no copy may land in a block that goes back to the pool
+        if (host) pinned_put(c, host);
+        if (host_tri) pinned_put(c, host_tri);
+        return -1;
+    };
+    if (!host) return fail();
+    int *h_end = l.h_off + count + 2;
+    l.h_off[count + 1] = 0;    // the look-back's give-up flag
+    if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, l.stream)) return fail();
+    tr.mark("setup");
+
+    const char *run_d = radial ? l.d_depth2.as<char>() : l.d_depth.as<char>();
+    const char *run_c = radial ? l.d_colors2.as<char>() : l.d_colors.as<char>();
+    int sent = 0;   // vertices already on their way home
+    // group k's launches have been enqueued: when its event has fired, its vertices (and corrected maps) go home
+    auto service = [&](size_t k) -> int {
+        const Group &g = l.groups[k];
+        LSN_HIP(hipEventSynchronize(l.ev_group[k]));
+        const int end = h_end[k];
+        if (l.h_off[count + 1] != 0 || end < sent || end > cap) {
+            lsn::set_error("NativeUtils: the fusion of sensors %d..%d failed on the device (end offset %d, flag %d)", g.first, g.first + g.count - 1, end,
+                           l.h_off[count + 1]);
+            return -1;
+        }
+        if (end > sent)
+            LSN_HIP(hipMemcpyAsync(static_cast<char *>(host) + (size_t)sent * 16, l.d_out.as<char>() + (size_t)sent * 16, (size_t)(end - sent) * 16,
+                                   hipMemcpyDeviceToHost, l.down));
+        sent = end;
+        tr.mark("down");
+        return 0;
+    };
+    // The corrected maps go home in the runs of the upload schedule (>= 1 MiB each: a smaller pageable copy is staged through a bounce
+    // buffer), a run as soon as the last group it covers is final.  Pageable destination: these copies keep the thread, so they only
+    // start once every upload and launch of the call has been issued; on their own stream, not behind the mesh.
+    auto write_back = [&](size_t k) -> int {
+        for (const Copy &cp : l.copies) {
+            size_t last = 0;   // the last group this run covers
+            for (size_t q = 0; q < G; q++)
+                if ((cp.colours ? l.groups[q].c_off : l.groups[q].d_off) < cp.dev_off + cp.bytes) last = q;
+            if (last != k) continue;
+            unsigned char *dst = (cp.colours ? radial_back_c : radial_back_d) + cp.src_off;
+            const char *src = (cp.colours ? l.d_colors2.as<char>() : l.d_depth2.as<char>()) + cp.dev_off;
+            LSN_HIP(hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyDeviceToHost, l.back));
+            tr.mark("back");
+        }
+        return 0;
+    };
+    size_t next_group = 0;
+    for (size_t i = 0; i < l.copies.size(); i++) {
+        const Copy &cp = l.copies[i];
+        char *dst = (cp.colours ? l.d_colors.as<char>() : l.d_depth.as<char>()) + cp.dev_off;
+        const unsigned char *src = (cp.colours ? depth_colors : depth_maps) + cp.src_off;
+        const hipError_t e = G == 1 ? hipMemcpyAsync(dst, src, cp.bytes, hipMemcpyHostToDevice, l.stream)
+                                    : hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyHostToDevice, l.up);
+        if (e != hipSuccess) {
+            lsn::set_error("NativeUtils: upload failed: %s", hipGetErrorString(e));
+            return fail();
+        }
+        tr.mark(cp.colours ? "upC" : "upD");
+        for (; next_group < G && l.groups[next_group].ready_after == (int)i + 1; next_group++) {
+            const Group &g = l.groups[next_group];
+            if (radial && lsnFusionRadialCorrectTo(g.radial_plan, intr + 7 * g.first, l.d_depth.as<char>() + g.d_off, l.d_colors.as<char>() + g.c_off,
+                                                   l.d_depth2.as<char>() + g.d_off, l.d_colors2.as<char>() + g.c_off, l.stream))
+                return fail();
+            h_end[next_group] = -1;
+            if (lsn::run_frames(plan, run_d, run_c, l.d_out.p, l.d_off.as<int>(), g.first - first, g.first - first + g.count, next_group == 0,
+                                with_triangles, l.h_off, h_end + next_group, false, l.stream) ||
+                hipEventRecord(l.ev_group[next_group], l.stream) != hipSuccess)
+                return fail();
+            tr.mark("launch");
+            if (next_group > 0 && service(next_group - 1)) return fail();   // the group before: done while this one was uploading
+        }
+    }
+    if (with_triangles) {
+        // the triangle passes over the whole tick, behind the last group (they only read what the groups left in HBM)
+        if (lsn::run_triangles(plan, run_d, l.d_tri.p, l.d_tri_off.as<int>(), l.h_toff, false, l.stream) || hipEventRecord(l.ev_tri, l.stream) != hipSuccess)
+            return fail();
+    }
+    // the corrected maps of all groups but the last (their events fired long ago), the last group's vertices, then the triangles
+    // (asynchronous) BEFORE the last group's maps, so that the thread-keeping copies share the link with the triangle download
+    if (back)
+        for (size_t k = 0; k + 1 < G; k++)
+            if (hipEventSynchronize(l.ev_group[k]) != hipSuccess || write_back(k)) return fail();
+    if (service(G - 1)) return fail();
+    const int nv = sent;
+    int nt = 0;
+    if (with_triangles) {
+        if (hipEventSynchronize(l.ev_tri) != hipSuccess) {
+            lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
+            return fail();
+        }
+        nt = l.h_toff[count];
+        if (nt < 0 || nt > 2 * cap) {
+            lsn::set_error("NativeUtils: device returned an impossible triangle count %d", nt);
+            return fail();
+        }
+        if (nt > 0) {
+            // the triangle write pass is still running: the copy waits for it on the kernels' stream
+            host_tri = pinned_get(c, (size_t)nt * 12);
+            if (!host_tri || hipMemcpyAsync(host_tri, l.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, l.stream) != hipSuccess) {
+                if (!lsn::has_error()) lsn::set_error("NativeUtils: triangle download failed: %s", hipGetErrorString(hipGetLastError()));
+                return fail();
+            }
+        }
+        tr.mark("tri");
+    }
+    if (back && write_back(G - 1)) return fail();
+    if (hipStreamSynchronize(l.down) != hipSuccess || hipStreamSynchronize(l.stream) != hipSuccess) {
+        lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
+        return fail();
+    }
+    tr.mark("sync");
+    if (nv != l.h_off[count]) {
+        lsn::set_error("NativeUtils: the groups' end offsets (%d) and the tick's total (%d) disagree", nv, l.h_off[count]);
+        return fail();
+    }
+    l.last_nv = nv;
+    l.last_nt = nt;
+    l.last_in_hbm = true;
+    l.last_radial = radial;
+    l.last_tri = with_triangles;
+    out->nVertices = nv;
+    out->vertices = static_cast<VertexC4ubV3f *>(host);
+    out->nTriangles = nt;
+    out->triangles = nt > 0 ? static_cast<int *>(host_tri) : g_no_triangles;
+    c.last_lane.store(&l);
+    tr.mark("done");
+    tr.print();
+    return 0;
+}
+
 // lsnLastMesh*: the mesh of the lane's last call in d_out / d_tri.  The direct path left it in host memory only; its inputs are
 // still resident, so the plan's ordinary launches rebuild it in HBM (bit-identical: same arithmetic, same frames).  Lane lock held.
 int materialize(Lane &l)
@@ -903,26 +865,22 @@ int materialize(Lane &l)
     return 0;
 }
 
-int fuse_host(Ctx &c, Lane &l, int n_maps_known, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths,
-              const int *heights, const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count,
-              bool with_triangles, bool radial = false, unsigned char *radial_back_d = nullptr, unsigned char *radial_back_c = nullptr)
+// Which flow a call takes (measured on one box, 8 x 512x424, gpurun_out/r04/host_ab5.txt):
+//   merge / single-sensor calls: the kernels store straight into the mesh's host blocks (0.43 / 0.75 ms against 0.55 / 0.84 ms for the
+//       copy-engine form: a pageable upload and an asynchronous download do not run side by side -- the third and fourth upload
+//       run of a call take 103 instead of 37 us while the previous group's vertices are on their way down);
+//   calls that start with the radial correction: mesh in HBM, copy engine home group by group (1.1 against 1.26 ms: the ~100 us
+//       of latency-bound closing rounds per group cannot hide behind a storing kernel, but they do hide behind a DMA).
+// $LSN_HOST_PATH=direct / grouped forces one of them for every call (A/B runs).
+int fuse_host(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths, const int *heights,
+              const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count, bool with_triangles, bool radial = false,
+              unsigned char *radial_back_d = nullptr, unsigned char *radial_back_c = nullptr)
 {
-    // Calls that start with the radial correction keep the device-resident output + copy engine: while a kernel streams to host
-    // memory no other kernel completes (tools/link_probe.hip, F), so the correction of the next group -- ~100 us of latency-bound
-    // closing rounds per launch -- cannot hide behind the previous group's stores, and the grouped form loses (1.32 against 1.17 ms)
-    static const bool radial_direct = getenv("LSN_HOST_RADIAL_DIRECT") && atoi(getenv("LSN_HOST_RADIAL_DIRECT")) != 0;
-    if (c.direct && (!radial || radial_direct))
-        return fuse_host_direct(c, l, depth_maps, depth_colors, widths, heights, intr, wt, out, bounds6, first, count, with_triangles, radial,
-                                radial_back_d, radial_back_c);
-    size_t total_d = 0, total_c = 0;
-    for (int i = 0; i < n_maps_known; i++) {
-        total_d += (size_t)widths[i] * heights[i] * 2;
-        total_c += (size_t)widths[i] * heights[i] * 3;
-    }
-    const int rc = fuse_host_copy(c, l, depth_maps, depth_colors, total_d, total_c, widths, heights, intr, wt, out, bounds6, first, count,
-                                  with_triangles, radial, radial_back_d, radial_back_c);
-    if (rc) drain(l);   // nothing of a failed call stays in flight
-    return rc;
+    const bool direct = c.host_path == 1 || (c.host_path == 0 && !radial);
+    return direct ? fuse_host_direct(c, l, depth_maps, depth_colors, widths, heights, intr, wt, out, bounds6, first, count, with_triangles, radial,
+                                     radial_back_d, radial_back_c)
+                  : fuse_host_grouped(c, l, depth_maps, depth_colors, widths, heights, intr, wt, out, bounds6, first, count, with_triangles, radial,
+                                      radial_back_d, radial_back_c);
 }
 
 }  // namespace
@@ -942,7 +900,7 @@ static void generateVerticesFromDepthMap_impl(unsigned char *depth_maps, unsigne
         return;
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
-    if (ensure_ready(c) || fuse_host(c, l, depth_map_index + 1, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params,
+    if (ensure_ready(c) || fuse_host(c, l, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params,
                                      out_mesh, b, depth_map_index, 1, false))
         empty_mesh(out_mesh);
 }
@@ -971,7 +929,7 @@ static void generateMeshFromDepthMaps_impl(int n_maps, unsigned char *depth_maps
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
     if (ensure_ready(c) ||
-        fuse_host(c, l, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps, true)) {
+        fuse_host(c, l, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps, true)) {
         empty_mesh(out_mesh);
         return;
     }
@@ -1013,7 +971,7 @@ static void lsnCorrectAndGenerateMesh_impl(int n_maps, unsigned char *depth_maps
         return;
     }
     const float b[6] = {minX, minY, minZ, maxX, maxY, maxZ};
-    if (ensure_ready(c) || fuse_host(c, l, n_maps, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps,
+    if (ensure_ready(c) || fuse_host(c, l, depth_maps, depth_colors, widths, heights, intr_params, wtransform_params, out_mesh, b, 0, n_maps,
                                      true, true, write_back_corrected ? depth_maps : nullptr, write_back_corrected ? depth_colors : nullptr))
         empty_mesh(out_mesh);
 }

@@ -303,7 +303,7 @@ template <int MODE, bool VEC, bool LAZY = false>
 __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
 {
     constexpr bool kWrite = MODE != 0;
-    __shared__ uint4 stage[kWrite ? (kWin + kWin / 8) : 1];
+    __shared__ uint4 stage[kWrite ? kStageSlots : 1];
     __shared__ int s_wave_tot[4];
     __shared__ int s_wave_next[4];
     __shared__ int s_base;
@@ -412,6 +412,7 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
                 if (t.frame_start) a.offsets_mirror[t.f] = base;
                 if (tile == a.tiles_per_tick - 1) a.offsets_mirror[a.n_frames] = base + tile_tot;
             }
+            if (a.group_end_mirror && blockIdx.x == gridDim.x - 1) *a.group_end_mirror = base + tile_tot;
         }
     }
     if (MODE != 4 && tile_tot != counted) {
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void run_kernel(const FuseArgs a)
 {
-    __shared__ uint4 stage[kWin + kWin / 8];
+    __shared__ uint4 stage[kStageSlots];
     __shared__ int s_wave_tot[4];
     __shared__ int s_run;
     __shared__ int s_base;
@@ -960,6 +961,7 @@ void lsn::fill_args(LsnFusion *p, FuseArgs &a, const void *d_depth, const void *
     a.tile0 = 0;
     a.host_out = 0;
     a.offsets_mirror = nullptr;
+    a.group_end_mirror = nullptr;
 }
 
 // Called at the top of every run (p->mu held): from the second run with the same parameters on, the count pass uses the
@@ -1172,9 +1174,10 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
 // a later launch find the inclusive prefixes of the earlier launches' tiles in place (same epoch).  This is the form the host
 // exports use (abi.hip): their output block is pinned host memory, the launch is bound by the PCIe link, and any further kernel
 // boundary -- a separate count, a scan -- is time in which nothing crosses it.  first_of_tick starts a tick (new epoch).
-// offsets_mirror (optional, pinned host memory, n_maps + 2 ints): the offset table as the tiles resolve it, then a give-up flag.
+// offsets_mirror (optional, pinned host memory, n_maps + 2 ints): the offset table as the tiles resolve it, then a give-up flag;
+// group_end_mirror (optional, pinned): where this launch's vertices end inside the tick; host_out: d_vertices is pinned host memory.
 int lsn::run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, int f0, int f1, bool first_of_tick,
-                    bool with_pixmap, int *offsets_mirror, hipStream_t s)
+                    bool with_pixmap, int *offsets_mirror, int *group_end_mirror, bool host_out, hipStream_t s)
 {
     if (!p || !d_depth || !d_colors || !d_vertices || !d_offsets || f0 < 0 || f1 > p->n_maps || f0 >= f1 || p->n_ticks != 1) {
         lsn::set_error("run_frames: bad arguments");
@@ -1211,7 +1214,8 @@ int lsn::run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, voi
     a.chunk = 0;
     a.tile0 = p->tile_start[f0];
     a.offsets_mirror = offsets_mirror;
-    a.host_out = offsets_mirror != nullptr;   // the hosts that mirror the counts are the ones whose output block is host memory
+    a.group_end_mirror = group_end_mirror;
+    a.host_out = host_out ? 1 : 0;
     launch<4>(vec, p->tile_start[f1] - p->tile_start[f0], s, a, p->lazy_rgb);
     LSN_HIP(hipGetLastError());
     return 0;

@@ -59,6 +59,7 @@ struct FuseArgs {
     int chunk;                       // write pass block order: 0 = tick-major; C > 0 = chunks of C consecutive tiles, all ticks of a chunk before the next chunk
     int tile0;                       // one-tick plans only: the launch covers tiles [tile0, tile0 + gridDim.x) of the tick (a group of sensors, run_frames)
     int host_out;                    // mode 2: `out` is pinned host memory (plain, destination-aligned stores; see stage_and_store)
+    int *group_end_mirror;           // mode 2, optional (pinned host memory): where this launch's vertices end inside the tick, stored by its last tile
     int *offsets_mirror;             // mode 2, optional: the offset table entries are also stored here (pinned host memory), [n_frames + 1] = give-up flag
     int runs_per_tick;               // mode 1
     long long tick_depth_stride;  // u16 elements
@@ -364,6 +365,14 @@ __device__ __forceinline__ void compute_tile(const FuseArgs &a, const Tile &t, c
     compute_pixels<WRITE>(a, P, in, xf, yf, keep, vert);
 }
 
+// Where rank q of a staged window lives: q + q / 8 (one 16-byte pad per 8 ranks).  LSN_STAGE_PAD_SHIFT (build-time, A/B only):
+// 4 = one pad per 16 ranks, 31 = no padding.
+#ifndef LSN_STAGE_PAD_SHIFT
+#define LSN_STAGE_PAD_SHIFT 3
+#endif
+__device__ __forceinline__ int stage_slot16(int q) { return q + (q >> LSN_STAGE_PAD_SHIFT); }
+constexpr int kStageSlots = kWin + (kWin >> LSN_STAGE_PAD_SHIFT) + 1;
+
 // Stages a tile's survivors in LDS in rank order, window by window, and copies them out with consecutive lanes writing
 // consecutive 16-B vertices.  Rank q of a window lives at slot q + q/8: a lane's 8 consecutive ranks then start 9 slots
 // (144 B) apart, which keeps the 16-B LDS writes of neighbouring lanes on different bank groups (stride 128 B is an
@@ -381,7 +390,7 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
 #pragma unroll
         for (int k = 0; k < kPxPerLane; k++) {
             if (keep[k]) {
-                if ((unsigned int)r < (unsigned int)kWin) stage[r + (r >> 3)] = vert[k];
+                if ((unsigned int)r < (unsigned int)kWin) stage[stage_slot16(r)] = vert[k];
                 r++;
             }
         }
@@ -390,10 +399,10 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
         if (host_dst) {
             const int mis = (int)((reinterpret_cast<uintptr_t>(dst + w0) >> 4) & 63);
             for (int i = (int)threadIdx.x - mis; i < n; i += kThreads)
-                if (i >= 0) dst[w0 + i] = stage[i + (i >> 3)];
+                if (i >= 0) dst[w0 + i] = stage[stage_slot16(i)];
         } else
         for (int i = threadIdx.x; i < n; i += kThreads) {
-            const uint4 v = stage[i + (i >> 3)];
+            const uint4 v = stage[stage_slot16(i)];
             if (kNontemporalStores) {   // written once, never read again by this launch sequence
                 __builtin_nontemporal_store(v.x, &dst[w0 + i].x);
                 __builtin_nontemporal_store(v.y, &dst[w0 + i].y);
@@ -411,20 +420,16 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
 // prefixes in place and fills the per-sensor offset table (offsets[tick][f] = first vertex of sensor f, [n_frames] = total).
 // mirror (optional): the offset table is also stored there -- pinned host memory, so the host has the counts when the stream
 // is idle without a copy of its own.
-__attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(int *tile_counts, int tiles_per_tick, const FrameDesc *frames, int n_frames,
-                                                        int *offsets, int *mirror)
+__device__ __forceinline__ void scan_tick(int *tc, int tiles_per_tick, const FrameDesc *frames, int n_frames, int *off, int *mirror_row,
+                                          int (&s_wave)[4], int &s_carry)
 {
-    __shared__ int s_wave[4];
-    __shared__ int s_carry;
-    const int tick = blockIdx.x;
-    int *tc = tile_counts + (long long)tick * tiles_per_tick;
-    int *off = offsets + (long long)tick * (n_frames + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (int c0 = 0; c0 < tiles_per_tick; c0 += kThreads) {
         const int i = c0 + threadIdx.x;
-        const int v = i < tiles_per_tick ? tc[i] : 0;
+        int v = 0;
+        if (i < tiles_per_tick) v = tc[i];
         const int incl = wave_inclusive_scan(v, lane);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
@@ -439,8 +444,18 @@ __attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(
     for (int f = threadIdx.x; f <= n_frames; f += kThreads) {
         const int v = f < n_frames ? tc[frames[f].tile_start] : s_carry;
         off[f] = v;
-        if (mirror) mirror[(long long)tick * (n_frames + 1) + f] = v;
+        if (mirror_row) mirror_row[f] = v;
     }
+}
+
+__attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(int *tile_counts, int tiles_per_tick, const FrameDesc *frames, int n_frames,
+                                                        int *offsets, int *mirror)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_carry;
+    const int tick = blockIdx.x;
+    scan_tick(tile_counts + (long long)tick * tiles_per_tick, tiles_per_tick, frames, n_frames, offsets + (long long)tick * (n_frames + 1),
+                     mirror ? mirror + (long long)tick * (n_frames + 1) : nullptr, s_wave, s_carry);
 }
 
 

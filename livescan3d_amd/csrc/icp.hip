@@ -1575,7 +1575,12 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
     const dim3 per_group((n_groups + kThreads / 64 - 1) / (kThreads / 64));
     // consumer launches (one wave per workgroup, a multiple of 64 of them): a seeded group needs ~3-5 super-blocks and ~5-8
     // point ranges; longer lists are served by looping.  Waves without an item leave after one load.
-    const dim3 blocks_grid(64 * ((6 * n_groups + 63) / 64)), scan_grid(64 * ((8 * n_groups + 63) / 64));
+    // waves per query group of the two list consumers.  The scan list of a seeded step holds ~6 (configs[1]) to ~11 (configs[2]) items
+    // per group, unevenly over the 64 segments: with fewer waves than the fullest segment has items, some waves serve a second item
+    // behind their first -- a second chain of dependent round trips that sets the launch time ($LSN_ICP_SCAN_WAVES, A/B in EXPERIMENTS.md)
+    static const int scan_waves = getenv("LSN_ICP_SCAN_WAVES") ? std::max(1, atoi(getenv("LSN_ICP_SCAN_WAVES"))) : 12;
+    static const int block_waves = getenv("LSN_ICP_BLOCK_WAVES") ? std::max(1, atoi(getenv("LSN_ICP_BLOCK_WAVES"))) : 8;
+    const dim3 blocks_grid(64 * ((block_waves * n_groups + 63) / 64)), scan_grid(64 * ((scan_waves * n_groups + 63) / 64));
     if (seeded) {
         hipLaunchKernelGGL(nn_cull_kernel<true>, per_group, dim3(kThreads), 0, s, src, d_verts2, n2, st, keys, n1, gp, supers, d_verts1, n1,
                            (const int *)w->idx_sorted.as<int>(), best_key, groups, wk, bank);

@@ -106,8 +106,8 @@ struct RunHooks {
     hipEvent_t written = nullptr;         // recorded after the write pass (the vertices may leave while the triangulation runs)
     int *h_tri_offsets = nullptr;         // lsnFusionRunMesh: pinned host copy of the triangle offset table ...
     hipEvent_t tri_counted = nullptr;     // ... and the event behind it
-    bool mirror = false;                  // h_tri_offsets is pinned, device-visible memory and the scan kernel stores the table there itself: no copy,
-                                          // and the triangle write pass treats its output as host memory too (abi.hip's direct path)
+    bool mirror = false;                  // h_tri_offsets is pinned, device-visible memory and the scan kernel stores the table there itself: no copy
+    bool host_out = false;                // the triangle write pass's output is pinned host memory (its HOST form)
 };
 // lsnFusionRun with the plan's mutex already held; with_pixmap also fills the pixel -> vertex map the triangulation reads.
 int run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, hipStream_t s, bool with_pixmap,
@@ -121,8 +121,8 @@ int run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_ve
 // One launch, single pass, over frames [f0, f1) of a one-tick plan (fusion.hip); and the triangle passes alone over the whole tick, for
 // a pixel -> vertex map that run_frames(with_pixmap) launches have filled (mesh.hip).  tri_mirror: optional pinned copy of the table.
 int run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, int f0, int f1, bool first_of_tick,
-               bool with_pixmap, int *offsets_mirror, hipStream_t s);
-int run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, hipStream_t s);
+               bool with_pixmap, int *offsets_mirror, int *group_end_mirror, bool host_out, hipStream_t s);
+int run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, bool host_out, hipStream_t s);
 
 // The survivor exchange's two ends with the back-to-back stream layout (exchange.hip; see their definitions).
 int pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c, int *d_tile_prefix,

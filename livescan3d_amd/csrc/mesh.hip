@@ -412,7 +412,7 @@ static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles,
     static const int win_env = getenv("LSN_TRI_WINDOW") ? atoi(getenv("LSN_TRI_WINDOW")) : kTriWinDefault;
     t.win = std::min(4096, std::max(256, win_env)) & ~15;
     const size_t stage_bytes = sizeof(int) * (size_t)(stage_ints(t.win) + 3 * 64);
-    t.host_out = hooks && hooks->mirror;   // the hosts that mirror the counts are the ones whose output block is host memory
+    t.host_out = hooks && hooks->host_out;
     t.tick_pix_stride = p->cap;
     t.tick_tri_stride = 2 * p->cap;
     const bool vec = p->pixmap_compact && ((uintptr_t)d_depth & 15) == 0;   // the vertex pass above wrote the compact map iff it ran its wide-load form
@@ -475,7 +475,7 @@ int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void 
     return triangle_passes(p, d_depth, d_triangles, d_tri_offsets, s, hooks);
 }
 
-int lsn::run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, hipStream_t s)
+int lsn::run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, bool host_out, hipStream_t s)
 {
     if (!p || !d_depth || !d_triangles || !d_tri_offsets) {
         lsn::set_error("run_triangles: null argument");
@@ -488,6 +488,7 @@ int lsn::run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int
         return -1;
     lsn::RunHooks hooks;
     hooks.mirror = tri_mirror != nullptr;
+    hooks.host_out = host_out;
     hooks.h_tri_offsets = tri_mirror;
     return triangle_passes(p, d_depth, d_triangles, d_tri_offsets, s, &hooks);
 }
