@@ -3,12 +3,15 @@
 Bar: bit-exact -- vertex counts, per-sensor offsets, order, RGBA bytes and XYZ bit patterns
 (the reference's own correctness check is a bit-for-bit mesh compare, src/NativeUtils/main.cpp:211-245).
 All calls go through the C-ABI (ctypes)."""
+import os
+
 import numpy as np
 import pytest
 
 from livescan3d_amd import native, synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _oracle_cloud(orc, rig):
@@ -455,3 +458,62 @@ def test_soak_of_mixed_export_calls(gpu, orc):
             rigs[j].wt = (rigs[j].wt + rng.normal(scale=0.01, size=rigs[j].wt.shape)).astype(np.float32)
             for k in [k for k in expect if k[0] == j and k[1] != "radial"]:
                 del expect[k]
+
+
+# ---- the host flows of the exports (abi.hip): upload schedule, groups, kernel stores / copy engine ------------------------------------
+
+_FLOW_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from livescan3d_amd import native, synth
+out = {{}}
+for name, kind, n, w, h in {cases!r}:
+    rig = synth.make_rig(kind, n, w, h, seed=17, bounds=synth.CROP_BOUNDS)
+    v, t = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    v2, t2 = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    assert v.tobytes() == v2.tobytes() and t.tobytes() == t2.tobytes(), name + ": the second call differs from the first"
+    v1, t1, d1, c1 = native.correct_and_generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, write_back=True)
+    frame = native.last_mesh_transfer_frame()      # the mesh of the last call, rebuilt in / read from HBM
+    out[name] = [len(v), len(t), hashlib.sha256(v.tobytes() + t.tobytes()).hexdigest(),
+                 len(v1), len(t1), hashlib.sha256(v1.tobytes() + t1.tobytes() + np.asarray(d1).tobytes() + np.asarray(c1).tobytes()).hexdigest(),
+                 hashlib.sha256(frame).hexdigest()]
+print(json.dumps(out))
+"""
+
+_FLOW_CASES = [("two_groups", "scene", 3, 512, 424),      # D[0-2] C[0-1] | C[2]: a short tail joins its predecessor or stands alone
+               ("four_groups", "scene", 8, 256, 424),     # colour runs of 5 sensors: 8 sensors -> 2 groups, depth in one run
+               ("big_frames", "noise", 3, 1024, 768),     # every sensor its own group (2.4 MB of colours each)
+               ("many_sensors", "noise", 20, 640, 560),   # more sensors with >= 1 MiB of colours than group events: regrouped
+               ("odd_sizes", "scene", 5, 250, 121)]       # slices that break the wide-load alignment: one group
+
+
+@pytest.mark.parametrize("env", [{}, {"LSN_HOST_PATH": "direct"}, {"LSN_HOST_PATH": "grouped"}, {"LSN_HOST_GROUP": "1"},
+                                 {"LSN_HOST_GROUP": "3", "LSN_HOST_PATH": "grouped"}])
+def test_every_host_flow_returns_the_oracles_mesh(gpu, orc, env):
+    """generateMeshFromDepthMaps and lsnCorrectAndGenerateMesh through every flow of the library (kernel stores into the pinned mesh
+    blocks / mesh in HBM + copy engine; sensors per upload group by size, forced to 1 and to 3) on rigs that exercise the schedule's
+    corners: the meshes, the written-back corrected maps and the TransferServer stream of the call's mesh must be the oracle's."""
+    import hashlib
+    import subprocess
+    import sys as _sys
+    import json
+    from livescan3d_amd import synth
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([_sys.executable, "-c", _FLOW_SCRIPT.format(root=ROOT, cases=_FLOW_CASES)], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    for name, kind, n, w, h in _FLOW_CASES:
+        rig = synth.make_rig(kind, n, w, h, seed=17, bounds=synth.CROP_BOUNDS)
+        want_v, _, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        cd, cc = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+        cd = np.ascontiguousarray(np.asarray(cd)).view(np.uint8).ravel()
+        cc = np.ascontiguousarray(np.asarray(cc)).ravel()
+        v1, _, t1 = orc.generate_mesh(cd, cc, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        g = got[name]
+        assert g[:2] == [len(want_v), len(want_t)], (name, env, g[:2])
+        assert g[2] == hashlib.sha256(want_v.tobytes() + want_t.tobytes()).hexdigest(), (name, env, "merge call")
+        assert g[3:5] == [len(v1), len(t1)], (name, env, g[3:5])
+        assert g[5] == hashlib.sha256(v1.tobytes() + t1.tobytes() + cd.tobytes() + cc.tobytes()).hexdigest(), (name, env, "tick as one call")
+        assert g[6] == hashlib.sha256(orc.transfer_frame(v1, t1)).hexdigest(), (name, env, "stream of the last mesh")

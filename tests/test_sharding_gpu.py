@@ -362,6 +362,15 @@ def _shard_worker_multi(rank, world, port, sizes, chunks, padded, out):
             ok = ok and n > 0 and bool(torch.equal(merged[k, :n], want_v[k, :n]))
     sent = sf.shard.last_bytes_sent()
     ok = ok and sent > 0
+    if rank == 0:
+        # ... and straight against the CPU oracle, not only against the single-plan HIP fusion: the merged cloud a rank ends up with
+        # is the oracle's merge of ALL sensors, byte for byte
+        from oracle import orc
+        mv, mo = merged.cpu().numpy(), moff.cpu().numpy()
+        for k in range(T):
+            want, counts = orc.generate_mesh_vertices(rigs[k].depth_maps, rigs[k].depth_colors, widths, heights, rigs[0].intr, rigs[0].wt, rigs[0].bounds)
+            n = int(mo[k, -1])
+            ok = ok and n == len(want) and list(np.diff(mo[k])) == list(counts) and mv[k, :n].tobytes() == want.tobytes()
     sf.close()
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))
@@ -385,7 +394,7 @@ def test_shard_step_several_ranks_on_one_gpu(gpu, tmp_path, world, sizes, chunks
     tests/fake_rccl -- the seven nccl* entry points over a shared-memory segment -- and `world` processes share this GPU:
     rank offsets, the grouped all-gathers, the chunked second-stream pipeline, the reconstruction of every rank's sensors
     (or the vertex exchange on the ragged rig) all run as they would on `world` GPUs, and every rank must end up with the
-    single-plan merged cloud.  World 8 (configs[3] itself) cannot be rehearsed here: a GPU box admits at most 6 processes on its
+    single-plan merged cloud; rank 0 also holds its result against the CPU oracle's merge of all sensors.  World 8 (configs[3] itself) cannot be rehearsed here: a GPU box admits at most 6 processes on its
     card, so 4 ranks x 1 sensor is the largest one-sensor-per-rank case."""
     if not os.path.exists(FAKE_RCCL):
         pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
