@@ -206,9 +206,6 @@ extern "C" int lsnStreamSynchronize(int device, void *stream)
 
 namespace {
 
-// What one call in flight needs: streams, events, device buffers.  LiveScanServer runs its merge calls (updateWorker: radial correction,
-// generateMeshFromDepthMaps) and its refine calls (refineWorker: generateVerticesFromDepthMap per sensor, then ICP) on two threads
-// (MainWindowForm.cs:238,304); each of the three families has its own lane, so they only meet at the short shared tables below.
 // One group of consecutive sensors of a call: fused by one launch as soon as its frames are on the device (file comment).
 struct Group {
     int first = 0, count = 0;        // sensors [first, first + count) of the caller's arrays
@@ -227,6 +224,9 @@ struct Copy {
 
 constexpr int kMaxGroups = 16;
 
+// What one call in flight needs: streams, events, device buffers, plans.  LiveScanServer runs its merge calls (updateWorker: radial
+// correction, generateMeshFromDepthMaps) and its refine calls (refineWorker: generateVerticesFromDepthMap per sensor, then ICP) on two
+// threads (MainWindowForm.cs:238,304); each of the three families has its own lane, so they only meet at the pool of pinned blocks.
 struct Lane {
     std::mutex mu;
     hipStream_t stream = nullptr, up = nullptr, down = nullptr, back = nullptr;   // kernels; uploads; mesh downloads; write-backs of corrected maps
@@ -252,7 +252,7 @@ struct Ctx {
     Lane merge, single;       // lane of the merge / radial / last-mesh calls; lane of the single-sensor calls
     std::mutex icp_mu;        // ICP: own buffers, own stream
     std::mutex init_mu;
-    std::mutex tab_mu;        // the shared tables: the pinned-block pool, the registered host ranges
+    std::mutex tab_mu;        // the pool of pinned blocks
     std::atomic<Lane *> last_lane{nullptr};   // the lane whose call finished last: lsnLastMesh* read the mesh it left in HBM
     bool ready = false;
     int device = 0;
