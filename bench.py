@@ -125,10 +125,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # A rank that raises INSIDE a collective (of torch's group here, or of the library's own RCCL communicator in lsnShardStep) leaves
+        # its peers waiting in it: that cannot be repaired from inside the run.  The group's timeout turns it into a non-zero exit of the
+        # job instead of a hang (torch's watchdog for its own collectives; the driver's clock for the library's).
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("LSN_BENCH_PG_TIMEOUT_S", "300")))
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
     native.require_gpu()
 
     S, B, w, h = args.sensors, args.ticks, args.width, args.height
@@ -325,7 +330,9 @@ def main():
                 "parallelism": f"sensor-shard{world}" + (("+allgather(survivors; lsnShard* = C++ host glue + RCCL inside the library)" if use_shard else
                                                           "+allgather(survivors; Python over torch.distributed)" if use_sx else "+allgather(vertices)") if multi else ""),
                 "bounds": [float(x) for x in bounds],
-                **({"shard_preflight": shard_preflight, "rccl_library": native.shard_rccl_path() if (use_shard or shard_preflight) else None} if multi else {}),
+                **({"shard_preflight": shard_preflight, "rccl_library": native.shard_rccl_path() if (use_shard or shard_preflight) else None,
+                    "collective_failure": "not recoverable mid-collective: the process group's timeout (LSN_BENCH_PG_TIMEOUT_S, 300 s) ends the job non-zero"}
+                   if multi else {}),
                 "parity": "outputs bit-identical to the CPU restatement of the reference (tests/, -m gpu); that restatement is PARITY UNPINNED for "
                           "the depth -> cloud path, the radial correction and the non-NN part of ICP (the reference ships no fixtures and "
                           "depthprocessing.cpp / icp.cpp cannot be built here without stand-ins); nearest neighbour and triangulation are "
