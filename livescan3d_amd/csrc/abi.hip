@@ -421,10 +421,14 @@ int ensure_tables(Lane &l, int n)
 }
 
 // The upload schedule of a call.  A pageable copy of >= 1 MiB is pinned in place by the runtime (~52 GB/s, ~10 us of fixed cost),
-// a smaller one is staged through a bounce buffer at a quarter of the rate, so frames go up in runs of at least 1 MiB.  The groups
-// are the runs of the COLOUR array (two 512x424 sensors); the depth array is cut independently (three sensors), a run going up
-// just before the first group that needs it -- a group is launched as soon as its frames are there, i.e. after `ready_after`
-// copies.  8 x 512x424:  D[0-2] C[0-1] | D[3-7] C[2-3] | C[4-5] | C[6-7].
+// a smaller one is staged through a bounce buffer at a quarter of the rate, so frames go up in runs of at least 1 MiB, and a group
+// of sensors is launched as soon as its frames are there, i.e. after `ready_after` copies.  How many sensors make a group
+// (measured, 8 x 512x424, gpurun_out/r04/host_ab8.txt):
+//   * merge calls (kernel stores): every storing launch costs ~8 us of ramp and drain, every group one depth and one colour copy --
+//     groups are the >= 1 MiB runs of the DEPTH array (three sensors): 0.417-0.420 / 0.740 ms against 0.429-0.432 / 0.753 for
+//     groups of two (the runs of the colour array) and 0.427 / 0.752 for groups of four.  D[0-2] C[0-2] | D[3-7] C[3-5] | C[6-7];
+//   * calls that start with the radial correction: a group pays ~100 us of latency-bound closing rounds whatever its size --
+//     groups of >= 2.5 MiB of colours (four sensors): 1.05 ms against 1.10 (three) and 1.16 (two).  D[0-3] C[0-3] | D[4-7] C[4-7].
 int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int first, int count, bool radial)
 {
     l.groups.clear();
@@ -442,7 +446,7 @@ int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int fi
     if (per == 0 && count > kMaxGroups) {
         size_t cb = 0;
         for (int i = first; i < end; i++) cb += csz(i);
-        if (cb / kMaxGroups >= kPinnedCopy) per = (count + kMaxGroups - 1) / kMaxGroups;   // many big sensors: at most kMaxGroups groups
+        if (cb / kMaxGroups >= ((size_t)5 << 19)) per = (count + kMaxGroups - 1) / kMaxGroups;   // many big sensors: at most kMaxGroups groups
     }
     size_t d_off = 0, c_off = 0;
     for (int i = first; i < end;) {
@@ -450,7 +454,9 @@ int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int fi
         g.first = i;
         g.d_off = d_off; g.c_off = c_off;
         g.d_src = d_src0 + d_off; g.c_src = c_src0 + c_off;
-        while (i < end && (per > 0 ? g.count < per : (g.count == 0 || g.cbytes < kPinnedCopy))) {
+        auto weight = [&](const Group &q) { return radial ? q.cbytes : q.dbytes; };   // what a group is sized by
+        const size_t full = radial ? (size_t)5 << 19 : kPinnedCopy;
+        while (i < end && (per > 0 ? g.count < per : (g.count == 0 || weight(g) < full))) {
             g.dbytes += dsz(i);
             g.cbytes += csz(i);
             g.count++;
@@ -458,7 +464,7 @@ int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int fi
         }
         d_off += g.dbytes;
         c_off += g.cbytes;
-        if (per == 0 && !l.groups.empty() && i == end && g.cbytes * 2 < kPinnedCopy) {
+        if (per == 0 && !l.groups.empty() && i == end && weight(g) * 2 < full) {
             Group &b = l.groups.back();   // a short tail: one more bounce-buffer copy would cost more than the overlap wins
             b.count += g.count;
             b.dbytes += g.dbytes;
