@@ -680,6 +680,23 @@ int fuse_host_direct(Ctx &c, Lane &l, const unsigned char *depth_maps, const uns
     return 0;
 }
 
+// The corrected maps of group k go home in the runs of the upload schedule (>= 1 MiB each: a smaller pageable copy is staged through
+// a bounce buffer): every run whose last group is k.  Pageable destination: these copies keep the thread; on their own stream.
+int write_back_runs(Lane &l, size_t k, unsigned char *back_d, unsigned char *back_c)
+{
+    const size_t G = l.groups.size();
+    for (const Copy &cp : l.copies) {
+        size_t last = 0;   // the last group this run covers
+        for (size_t q = 0; q < G; q++)
+            if ((cp.colours ? l.groups[q].c_off : l.groups[q].d_off) < cp.dev_off + cp.bytes) last = q;
+        if (last != k) continue;
+        unsigned char *dst = (cp.colours ? back_c : back_d) + cp.src_off;
+        const char *src = (cp.colours ? l.d_colors2.as<char>() : l.d_depth2.as<char>()) + cp.dev_off;
+        LSN_HIP(hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyDeviceToHost, l.back));
+    }
+    return 0;
+}
+
 // The same call with the mesh built in HBM and the copy engine taking it home -- the form for calls of several groups and for calls
 // that start with the radial correction.  While a kernel streams to host memory no other kernel completes (file comment), so with
 // several groups the storing launches serialise with everything else; the copy engine does not have that problem: group g's
@@ -753,21 +770,11 @@ int fuse_host_grouped(Ctx &c, Lane &l, const unsigned char *depth_maps, const un
         tr.mark("down");
         return 0;
     };
-    // The corrected maps go home in the runs of the upload schedule (>= 1 MiB each: a smaller pageable copy is staged through a bounce
-    // buffer), a run as soon as the last group it covers is final.  Pageable destination: these copies keep the thread, so they only
-    // start once every upload and launch of the call has been issued; on their own stream, not behind the mesh.
+    // the corrected maps only start home once every upload and launch of the call has been issued (their copies keep the thread)
     auto write_back = [&](size_t k) -> int {
-        for (const Copy &cp : l.copies) {
-            size_t last = 0;   // the last group this run covers
-            for (size_t q = 0; q < G; q++)
-                if ((cp.colours ? l.groups[q].c_off : l.groups[q].d_off) < cp.dev_off + cp.bytes) last = q;
-            if (last != k) continue;
-            unsigned char *dst = (cp.colours ? radial_back_c : radial_back_d) + cp.src_off;
-            const char *src = (cp.colours ? l.d_colors2.as<char>() : l.d_depth2.as<char>()) + cp.dev_off;
-            LSN_HIP(hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyDeviceToHost, l.back));
-            tr.mark("back");
-        }
-        return 0;
+        const int rc = write_back_runs(l, k, radial_back_d, radial_back_c);
+        tr.mark("back");
+        return rc;
     };
     size_t next_group = 0;
     for (size_t i = 0; i < l.copies.size(); i++) {
@@ -1003,32 +1010,54 @@ static void depthMapAndColorSetRadialCorrection_impl(int n_maps, unsigned char *
     std::lock_guard<std::mutex> g(l.mu);
     if (ensure_ready(c)) return;
     l.last_nv = -1;   // the lane's buffers are about to be reused
-    LsnFusion *plan = get_plan(c, l, widths, heights, 0, n_maps);
-    if (!plan) return;
+    l.last_plan = nullptr;
+    l.groups.clear();
+    // the upload schedule of a call that starts with the correction: groups of >= 2.5 MiB of colours, each with a plan for its warp tables
+    if (make_schedule(c, l, widths, heights, 0, n_maps, true)) return;
+    const size_t G = l.groups.size();
     size_t dbytes = 0, cbytes = 0;
-    for (int i = 0; i < n_maps; i++) {
-        dbytes += (size_t)widths[i] * heights[i] * 2;
-        cbytes += (size_t)widths[i] * heights[i] * 3;
+    for (const Group &q : l.groups) {
+        dbytes += q.dbytes;
+        cbytes += q.cbytes;
     }
     if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16)) return;
-    if (hipMemcpyAsync(l.d_depth.p, depth_maps, dbytes, hipMemcpyHostToDevice, l.stream) != hipSuccess ||
-        hipMemcpyAsync(l.d_colors.p, depth_colors, cbytes, hipMemcpyHostToDevice, l.stream) != hipSuccess) {
-        lsn::set_error("depthMapAndColorSetRadialCorrection: upload failed: %s", hipGetErrorString(hipGetLastError()));
-        return;
+    // Both directions are pageable copies that keep the thread; what overlaps is the correction itself (~100 us per group, latency
+    // bound) with the next group's upload and the previous group's way home.  Out of place on the device (the warped, un-closed
+    // maps stay in LDS); a group's slice of the caller's arrays is overwritten once ITS kernels have run -- a call that fails
+    // later leaves the earlier groups corrected and the rest untouched.
+    size_t next_group = 0, written = 0;
+    auto finish = [&](size_t k) -> int {   // group k's corrected maps into the caller's arrays
+        if (hipEventSynchronize(l.ev_group[k]) != hipSuccess) {
+            lsn::set_error("depthMapAndColorSetRadialCorrection: the correction failed: %s", hipGetErrorString(hipGetLastError()));
+            return -1;
+        }
+        return write_back_runs(l, k, depth_maps, depth_colors);
+    };
+    bool ok = true;
+    for (size_t i = 0; ok && i < l.copies.size(); i++) {
+        const Copy &cp = l.copies[i];
+        char *dst = (cp.colours ? l.d_colors.as<char>() : l.d_depth.as<char>()) + cp.dev_off;
+        const unsigned char *src = (cp.colours ? depth_colors : depth_maps) + cp.src_off;
+        if (hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyHostToDevice, l.up) != hipSuccess) {
+            lsn::set_error("depthMapAndColorSetRadialCorrection: upload failed: %s", hipGetErrorString(hipGetLastError()));
+            ok = false;
+            break;
+        }
+        for (; ok && next_group < G && l.groups[next_group].ready_after == (int)i + 1; next_group++) {
+            const Group &q = l.groups[next_group];
+            ok = lsnFusionRadialCorrectTo(q.radial_plan, intr_params + 7 * q.first, l.d_depth.as<char>() + q.d_off, l.d_colors.as<char>() + q.c_off,
+                                          l.d_depth2.as<char>() + q.d_off, l.d_colors2.as<char>() + q.c_off, l.stream) == 0 &&
+                 hipEventRecord(l.ev_group[next_group], l.stream) == hipSuccess;
+            // the group before goes home while this one is being corrected -- but never before every upload run it shares with a later
+            // group has been read (a depth run may cover sensors of the next group: write_back_runs only takes runs that END in k)
+            if (ok && next_group > 0 && written < next_group) {
+                ok = finish(written) == 0;
+                written++;
+            }
+        }
     }
-    // out of place on the device (the warped, un-closed maps then stay in LDS); the caller's arrays are only overwritten once
-    // the kernels have run
-    if (lsnFusionRadialCorrectTo(plan, intr_params, l.d_depth.p, l.d_colors.p, l.d_depth2.p, l.d_colors2.p, l.stream)) return;
-    if (hipStreamSynchronize(l.stream) != hipSuccess) {
-        lsn::set_error("depthMapAndColorSetRadialCorrection: the correction failed: %s", hipGetErrorString(hipGetLastError()));
-        return;
-    }
-    if (hipMemcpyAsync(depth_maps, l.d_depth2.p, dbytes, hipMemcpyDeviceToHost, l.stream) != hipSuccess ||
-        hipMemcpyAsync(depth_colors, l.d_colors2.p, cbytes, hipMemcpyDeviceToHost, l.stream) != hipSuccess ||
-        hipStreamSynchronize(l.stream) != hipSuccess) {
-        lsn::set_error("depthMapAndColorSetRadialCorrection: download failed: %s", hipGetErrorString(hipGetLastError()));
-        return;
-    }
+    for (; ok && written < G; written++) ok = finish(written) == 0;
+    if (!ok) drain(l);
 }
 
 extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, int *widths,
