@@ -428,12 +428,14 @@ int ensure_tables(Lane &l, int n)
 //     groups are the >= 1 MiB runs of the DEPTH array (three sensors): 0.417-0.420 / 0.740 ms against 0.429-0.432 / 0.753 for
 //     groups of two (the runs of the colour array) and 0.427 / 0.752 for groups of four.  D[0-2] C[0-2] | D[3-7] C[3-5] | C[6-7];
 //   * calls that start with the radial correction: a group pays ~100 us of latency-bound closing rounds whatever its size --
-//     groups of >= 2.5 MiB of colours (four sensors): 1.05 ms against 1.10 (three) and 1.16 (two).  D[0-3] C[0-3] | D[4-7] C[4-7].
-int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int first, int count, bool radial)
+//     groups of >= 2.5 MB of colours (four sensors): 1.05 ms against 1.10 (three) and 1.16 (two).  D[0-3] C[0-3] | D[4-7] C[4-7].
+void plan_schedule(std::vector<Group> &groups, std::vector<Copy> &copies, const int *widths, const int *heights, int first, int count, bool radial,
+                   int group_override)
 {
-    l.groups.clear();
-    l.copies.clear();
+    groups.clear();
+    copies.clear();
     constexpr size_t kPinnedCopy = (size_t)1 << 20;
+    constexpr size_t kRadialGroup = 2500000;   // colours per group of a call that starts with the radial correction: four 512x424 sensors
     const int end = first + count;
     auto dsz = [&](int i) { return (size_t)widths[i] * heights[i] * 2; };
     auto csz = [&](int i) { return (size_t)widths[i] * heights[i] * 3; };
@@ -442,11 +444,11 @@ int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int fi
         d_src0 += dsz(i);
         c_src0 += csz(i);
     }
-    int per = c.group_override > 0 ? c.group_override : 0;
+    int per = group_override > 0 ? group_override : 0;
     if (per == 0 && count > kMaxGroups) {
         size_t cb = 0;
         for (int i = first; i < end; i++) cb += csz(i);
-        if (cb / kMaxGroups >= ((size_t)5 << 19)) per = (count + kMaxGroups - 1) / kMaxGroups;   // many big sensors: at most kMaxGroups groups
+        if (cb / kMaxGroups >= kRadialGroup) per = (count + kMaxGroups - 1) / kMaxGroups;   // many big sensors: at most kMaxGroups groups
     }
     size_t d_off = 0, c_off = 0;
     for (int i = first; i < end;) {
@@ -455,7 +457,7 @@ int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int fi
         g.d_off = d_off; g.c_off = c_off;
         g.d_src = d_src0 + d_off; g.c_src = c_src0 + c_off;
         auto weight = [&](const Group &q) { return radial ? q.cbytes : q.dbytes; };   // what a group is sized by
-        const size_t full = radial ? (size_t)5 << 19 : kPinnedCopy;
+        const size_t full = radial ? kRadialGroup : kPinnedCopy;
         while (i < end && (per > 0 ? g.count < per : (g.count == 0 || weight(g) < full))) {
             g.dbytes += dsz(i);
             g.cbytes += csz(i);
@@ -464,33 +466,33 @@ int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int fi
         }
         d_off += g.dbytes;
         c_off += g.cbytes;
-        if (per == 0 && !l.groups.empty() && i == end && weight(g) * 2 < full) {
-            Group &b = l.groups.back();   // a short tail: one more bounce-buffer copy would cost more than the overlap wins
+        if (per == 0 && !groups.empty() && i == end && weight(g) * 2 < full) {
+            Group &b = groups.back();   // a short tail: one more bounce-buffer copy would cost more than the overlap wins
             b.count += g.count;
             b.dbytes += g.dbytes;
             b.cbytes += g.cbytes;
         } else {
-            l.groups.push_back(g);
+            groups.push_back(g);
         }
     }
     // a group's radial correction works on its slice of the buffers through a plan of its own: the slices must keep the alignment
     // the wide-load kernels ask for (16 B depth, 8 B colours); and there are kMaxGroups events.  A rig that breaks either goes as
     // one group
-    bool ok = l.groups.size() <= (size_t)kMaxGroups;
-    for (const Group &g : l.groups) ok &= (g.d_off % 16) == 0 && (g.c_off % 8) == 0;
-    if (!ok && l.groups.size() > 1) {
-        Group all = l.groups.front();
-        for (size_t k = 1; k < l.groups.size(); k++) {
-            all.count += l.groups[k].count;
-            all.dbytes += l.groups[k].dbytes;
-            all.cbytes += l.groups[k].cbytes;
+    bool ok = groups.size() <= (size_t)kMaxGroups;
+    for (const Group &g : groups) ok &= (g.d_off % 16) == 0 && (g.c_off % 8) == 0;
+    if (!ok && groups.size() > 1) {
+        Group all = groups.front();
+        for (size_t k = 1; k < groups.size(); k++) {
+            all.count += groups[k].count;
+            all.dbytes += groups[k].dbytes;
+            all.cbytes += groups[k].cbytes;
         }
-        l.groups.assign(1, all);
+        groups.assign(1, all);
     }
     // copies: depth runs interleaved with the groups' colour runs
     int depth_to = first;          // sensors [first, depth_to) have their depth scheduled
     size_t depth_off = 0;
-    for (Group &g : l.groups) {
+    for (Group &g : groups) {
         if (depth_to < g.first + g.count) {
             Copy d;
             d.dev_off = depth_off;
@@ -503,7 +505,7 @@ int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int fi
                 d.bytes += rest;
                 to = end;
             }
-            l.copies.push_back(d);
+            copies.push_back(d);
             depth_to = to;
             depth_off += d.bytes;
         }
@@ -512,9 +514,14 @@ int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int fi
         cc.dev_off = g.c_off;
         cc.src_off = g.c_src;
         cc.bytes = g.cbytes;
-        l.copies.push_back(cc);
-        g.ready_after = (int)l.copies.size();
+        copies.push_back(cc);
+        g.ready_after = (int)copies.size();
     }
+}
+
+int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int first, int count, bool radial)
+{
+    plan_schedule(l.groups, l.copies, widths, heights, first, count, radial, c.group_override);
     if (radial)
         for (Group &g : l.groups) {
             g.radial_plan = get_plan(c, l, widths, heights, g.first, g.count);
@@ -1012,7 +1019,7 @@ static void depthMapAndColorSetRadialCorrection_impl(int n_maps, unsigned char *
     l.last_nv = -1;   // the lane's buffers are about to be reused
     l.last_plan = nullptr;
     l.groups.clear();
-    // the upload schedule of a call that starts with the correction: groups of >= 2.5 MiB of colours, each with a plan for its warp tables
+    // the upload schedule of a call that starts with the correction: groups of >= 2.5 MB of colours, each with a plan for its warp tables
     if (make_schedule(c, l, widths, heights, 0, n_maps, true)) return;
     const size_t G = l.groups.size();
     size_t dbytes = 0, cbytes = 0;
@@ -1064,6 +1071,52 @@ extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *d
                                                     int *heights, float *intr_params)
 {
     lsn::guarded_void("depthMapAndColorSetRadialCorrection", [&]() { depthMapAndColorSetRadialCorrection_impl(n_maps, depth_maps, depth_colors, widths, heights, intr_params); });
+}
+
+// Host-only (no device needed): the upload schedule a call with these frames would follow, as text -- "D[0-2] C[0-2] | D[3-7] C[3-5] |
+// C[6-7]": runs of the depth / colour arrays in upload order, `|` where a group of sensors becomes ready and is launched.  Exists
+// so that the scheduling logic can be tested without a GPU (tests/test_abi.py).
+static int lsnHostScheduleDescribe_impl(int n_maps, const int *widths, const int *heights, int first, int count, int radial, int sensors_per_group,
+                                       char *buf, int len)
+{
+    lsn::clear_error();
+    if (n_maps <= 0 || !widths || !heights || first < 0 || count <= 0 || first + count > n_maps || !buf || len <= 0) {
+        lsn::set_error("lsnHostScheduleDescribe: bad arguments");
+        return -1;
+    }
+    std::vector<Group> groups;
+    std::vector<Copy> copies;
+    plan_schedule(groups, copies, widths, heights, first, count, radial != 0, sensors_per_group);
+    auto sensor_at = [&](bool colours, size_t off) {   // which sensor starts at byte `off` of the lane's (packed) buffer
+        size_t at = 0;
+        for (int i = first; i < first + count; i++) {
+            if (at == off) return i;
+            at += (size_t)widths[i] * heights[i] * (colours ? 3 : 2);
+        }
+        return first + count;
+    };
+    std::string out;
+    size_t next_group = 0;
+    for (size_t i = 0; i < copies.size(); i++) {
+        const Copy &cp = copies[i];
+        const int a = sensor_at(cp.colours, cp.dev_off), b = sensor_at(cp.colours, cp.dev_off + cp.bytes) - 1;
+        char item[64];
+        if (a == b) snprintf(item, sizeof(item), "%c[%d]", cp.colours ? 'C' : 'D', a);
+        else snprintf(item, sizeof(item), "%c[%d-%d]", cp.colours ? 'C' : 'D', a, b);
+        if (!out.empty()) out += " ";
+        out += item;
+        bool ready = false;
+        for (; next_group < groups.size() && groups[next_group].ready_after == (int)i + 1; next_group++) ready = true;
+        if (ready && i + 1 < copies.size()) out += " |";
+    }
+    snprintf(buf, (size_t)len, "%s", out.c_str());
+    return (int)groups.size();
+}
+
+extern "C" int lsnHostScheduleDescribe(int n_maps, const int *widths, const int *heights, int first, int count, int radial, int sensors_per_group,
+                                       char *buf, int len)
+{
+    return lsn::guarded<int>("lsnHostScheduleDescribe", static_cast<int>(-1), [&]() { return lsnHostScheduleDescribe_impl(n_maps, widths, heights, first, count, radial, sensors_per_group, buf, len); });
 }
 
 static Mesh * createMesh_impl(void)

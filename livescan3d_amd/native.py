@@ -21,7 +21,7 @@ VERTEX_DTYPE = np.dtype([("R", "u1"), ("G", "u1"), ("B", "u1"), ("A", "u1"),
 # every symbol include/NativeUtils.h declares
 EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
-    "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh",
+    "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh", "lsnHostScheduleDescribe",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnPackSensorParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
@@ -107,6 +107,8 @@ def lib():
     L.lsnFusionSetParams.argtypes = [vp, vp, vp, vp, vp]
     L.lsnPackSensorParams.restype = C.c_int
     L.lsnPackSensorParams.argtypes = [vp, vp, vp]
+    L.lsnHostScheduleDescribe.restype = C.c_int
+    L.lsnHostScheduleDescribe.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.lsnFusionSetMode.restype = C.c_int
     L.lsnFusionSetMode.argtypes = [vp, C.c_int]
     L.lsnFusionRunStreamed.restype = C.c_int
@@ -296,6 +298,19 @@ def generate_mesh_from_depth_maps(depth_maps, depth_colors, widths, heights, int
         lib().deleteMesh(C.byref(mesh))
         raise NativeUtilsError(err)
     return _copy_mesh(mesh)
+
+
+def host_schedule(widths, heights, first=0, count=None, radial=False, sensors_per_group=0):
+    """The upload schedule the host exports follow for these frames (lsnHostScheduleDescribe; needs no GPU).
+    Returns (number of groups, text such as "D[0-2] C[0-2] | D[3-7] C[3-5] | C[6-7]")."""
+    widths, heights = _as(widths, np.int32), _as(heights, np.int32)
+    n = len(widths)
+    buf = C.create_string_buffer(4096)
+    g = lib().lsnHostScheduleDescribe(n, _ptr(widths), _ptr(heights), int(first), int(n - first if count is None else count), int(bool(radial)),
+                                      int(sensors_per_group), buf, len(buf))
+    if g < 0:
+        raise NativeUtilsError(last_error())
+    return g, buf.value.decode()
 
 
 def radial_correction(depth_maps, depth_colors, widths, heights, intr):

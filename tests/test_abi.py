@@ -290,3 +290,71 @@ def test_a_failed_allocation_leaves_an_empty_mesh_and_the_next_call_works(gpu, o
     assert len(failed) <= 1 and all("bad_alloc" in g[3] for g in failed), got
     assert [g for g in got if not g[3]] == [want] * (3 - len(failed)), got
     assert got[-1] == want
+
+
+# ---- the upload schedule of the host exports: pure host logic, testable without a GPU ------------------------------------------------
+
+def _parse_schedule(text):
+    """'D[0-2] C[0-2] | D[3-7] C[3-5] | C[6-7]' -> list of groups, each a list of (kind, first, last)."""
+    groups = []
+    for part in text.split("|"):
+        runs = []
+        for item in part.split():
+            m = re.fullmatch(r"([DC])\[(\d+)(?:-(\d+))?\]", item)
+            assert m, item
+            a = int(m.group(2))
+            runs.append((m.group(1), a, int(m.group(3)) if m.group(3) else a))
+        groups.append(runs)
+    return groups
+
+
+def test_host_upload_schedule_known_rigs():
+    """lsnHostScheduleDescribe on the rigs the numbers in DESIGN.md section 5 were measured on (and a few corners)."""
+    S = native.host_schedule
+    assert S([512] * 8, [424] * 8) == (3, "D[0-2] C[0-2] | D[3-7] C[3-5] | C[6-7]")                  # merge call: groups follow the >= 1 MiB depth runs
+    assert S([512] * 8, [424] * 8, radial=True) == (2, "D[0-3] C[0-3] | D[4-7] C[4-7]")              # tick as one call / radial export: >= 2.5 MB of colours
+    assert S([512] * 8, [424] * 8, first=3, count=1) == (1, "D[3] C[3]")                             # generateVerticesFromDepthMap(index 3)
+    assert S([1024] * 3, [768] * 3) == (3, "D[0] C[0] | D[1] C[1] | D[2] C[2]")                      # big frames: a group per sensor
+    assert S([512] * 8, [424] * 8, sensors_per_group=1) == (8, "D[0-2] C[0] | C[1] | C[2] | D[3-7] C[3] | C[4] | C[5] | C[6] | C[7]")
+    assert S([250] * 5, [121] * 5)[0] == 1                                                           # slices that break the wide-load alignment: one group
+    g, text = S([1024] * 40, [1024] * 40)
+    assert g <= 16 and text.startswith("D[0-2] C[0-2] |")                                            # more big sensors than group events: regrouped
+    with pytest.raises(native.NativeUtilsError):
+        S([512] * 2, [424] * 2, first=1, count=2)
+
+
+def test_host_upload_schedule_properties():
+    """For random rigs: every sensor's depth and colours go up exactly once and in order; a group is launched only after all of its own
+    frames (a depth run may run ahead of its group, never behind); runs below 1 MiB only occur where nothing could be merged."""
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        n = int(rng.integers(1, 25))
+        if rng.random() < 0.5:
+            w = [int(rng.choice([128, 256, 512, 640, 1024]))] * n
+            h = [int(rng.choice([96, 212, 424, 560, 768]))] * n
+        else:
+            w = [int(rng.choice([61, 100, 250, 256, 512, 1024])) for _ in range(n)]
+            h = [int(rng.choice([3, 37, 120, 212, 424])) for _ in range(n)]
+        first = int(rng.integers(0, n))
+        count = int(rng.integers(1, n - first + 1))
+        radial = bool(rng.integers(0, 2))
+        per = int(rng.choice([0, 0, 0, 1, 2, 3, 5]))
+        g, text = native.host_schedule(w, h, first=first, count=count, radial=radial, sensors_per_group=per)
+        groups = _parse_schedule(text)
+        assert len(groups) == g >= 1
+        seen = {"D": first, "C": first}           # next sensor expected per array
+        done_c = first
+        for runs in groups:
+            for kind, a, b in runs:
+                assert a == seen[kind] and b >= a, (text, kind, a)
+                seen[kind] = b + 1
+            # the group that becomes ready here: its sensors are those whose colours ended in this part; their depth must be there
+            assert any(k == "C" for k, _, _ in runs), text
+            assert seen["C"] > done_c and seen["D"] >= seen["C"], text
+            done_c = seen["C"]
+        assert seen == {"D": first + count, "C": first + count}, text
+        if per == 0 and g > 1:
+            for runs in groups[:-1]:
+                for kind, a, b in runs:
+                    nbytes = sum(w[i] * h[i] for i in range(a, b + 1)) * (2 if kind == "D" else 3)
+                    assert nbytes >= (1 << 20) or kind == "C" and not radial, (text, kind, a, b, nbytes)
