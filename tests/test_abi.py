@@ -358,3 +358,38 @@ def test_host_upload_schedule_properties():
                 for kind, a, b in runs:
                     nbytes = sum(w[i] * h[i] for i in range(a, b + 1)) * (2 if kind == "D" else 3)
                     assert nbytes >= (1 << 20) or kind == "C" and not radial, (text, kind, a, b, nbytes)
+
+
+_NULL_ARGS_SCRIPT = r"""
+import ctypes as C, re, sys
+sys.path.insert(0, {root!r})
+from livescan3d_amd import native
+L = native.lib()
+text = re.sub(r"/\*.*?\*/", "", open({header!r}).read(), flags=re.S)
+n = 0
+for ret, name, params in re.findall(r"\b([A-Za-z_][A-Za-z0-9_ \*]*?)\b([A-Za-z_][A-Za-z0-9_]*)\s*\(([^;{{}}]*)\)\s*;", text):
+    ps = [p.strip() for p in params.replace("\n", " ").split(",") if p.strip()]
+    if ps == ["void"]:
+        ps = []
+    kinds = ["p" if "*" in p else "f" if re.search(r"\bfloat\b", p) else "q" if re.search(r"\blong long\b", p) else "b" if re.search(r"\bbool\b", p) else "i" for p in ps]
+    f = getattr(L, name)
+    f.argtypes = [dict(p=C.c_void_p, f=C.c_float, q=C.c_longlong, b=C.c_bool, i=C.c_int)[k] for k in kinds]
+    ret = ret.strip()
+    f.restype = C.c_void_p if "*" in ret else C.c_float if "float" in ret else C.c_longlong if "long long" in ret else None if ret == "void" else C.c_int
+    print(name, flush=True)
+    f(*[None if k == "p" else 0.0 if k == "f" else 0 for k in kinds])
+    n += 1
+print("ALL", n)
+"""
+
+
+def test_every_export_survives_null_and_zero_arguments():
+    """Each of the exports include/NativeUtils.h declares, called with NULL for every pointer and 0 for every number (no GPU needed):
+    none may crash the process -- a P/Invoke caller that passes a wrong handle gets an error, not an access violation."""
+    import subprocess
+    import sys as _sys
+    r = subprocess.run([_sys.executable, "-c", _NULL_ARGS_SCRIPT.format(root=ROOT, header=os.path.join(ROOT, "include", "NativeUtils.h"))],
+                       capture_output=True, text=True, timeout=300)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines and lines[-1].startswith("ALL"), f"crashed in {lines[-1] if lines else '?'} (rc {r.returncode})\n{r.stderr[-1500:]}"
+    assert int(lines[-1].split()[1]) == len(native.EXPORTS)
