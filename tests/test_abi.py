@@ -240,6 +240,8 @@ def _run_with_env(script, **env):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+@pytest.mark.skipif(native.device_count() > 0, reason="written for a machine without a GPU (every compute call ends in 'no HIP device'); "
+                                                     "the GPU form is test_a_failed_allocation_leaves_an_empty_mesh_and_the_next_call_works")
 @pytest.mark.parametrize("nth", [1, 2, 3, 4, 5])
 def test_an_exception_inside_an_export_never_crosses_the_boundary(nth):
     """LSN_TEST_THROW=n makes the n-th guarded entry of the process throw std::bad_alloc from inside the export's body (what a
