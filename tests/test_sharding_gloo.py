@@ -72,6 +72,13 @@ def _free_port():
     return p
 
 
+def _skip_world8_beside_a_gpu(world):
+    """A GPU box admits at most 6 processes with its card open, and importing torch there opens it: the world-8 rehearsal is a CPU-container
+    test (where the driver runs the `not gpu` suite)."""
+    if world > 4 and torch.cuda.device_count() > 0:
+        pytest.skip("world 8 on gloo runs in the CPU container (a GPU box's process guard admits 6 processes on the card)")
+
+
 def _check_every_rank(tmp_path, orc, world, S, T, w, h):
     """Every rank's merged cloud and offset table equal the single-process merge of all S sensors, byte for byte."""
     from livescan3d_amd import synth
@@ -91,6 +98,7 @@ def _check_every_rank(tmp_path, orc, world, S, T, w, h):
 # (8, 8): BASELINE configs[3] -- 8 sensors sharded one per rank -- as a CPU rehearsal of ownership and offsets
 @pytest.mark.parametrize("world,S", [(2, 2), (2, 4), (8, 8)])
 def test_allgather_of_vertex_shards_equals_single_process_merge(tmp_path, orc, world, S):
+    _skip_world8_beside_a_gpu(world)
     T, w, h = (3, 64, 48) if world == 2 else (2, 64, 48)
     mp.spawn(_worker, args=(world, _free_port(), S, T, w, h, str(tmp_path)), nprocs=world, join=True)
     _check_every_rank(tmp_path, orc, world, S, T, w, h)
@@ -185,6 +193,7 @@ def _survivor_worker(rank, world, port, S, T, w, h, out_dir):
 
 @pytest.mark.parametrize("world,S", [(2, 4), (8, 8)])
 def test_survivor_exchange_equals_single_process_merge(tmp_path, orc, world, S):
+    _skip_world8_beside_a_gpu(world)
     T, w, h = 2, 64, 48
     mp.spawn(_survivor_worker, args=(world, _free_port(), S, T, w, h, str(tmp_path)), nprocs=world, join=True)
     _check_every_rank(tmp_path, orc, world, S, T, w, h)
