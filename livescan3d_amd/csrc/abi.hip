@@ -24,7 +24,7 @@
 //     kernel, no scan; the triangle passes run once, behind the last group, over the whole tick;
 //   * so kernel stores are the form for ONE small group (a single-sensor call: one launch, no count round trip).  Calls of several
 //     groups, and calls that start with the radial correction (~100 us of latency-bound closing rounds per group), build the mesh
-//     in HBM and let the COPY ENGINE take it home group by group (fuse_host_grouped): the engine runs beside the kernels, and the
+//     in HBM and let ASYNCHRONOUS COPIES (hipMemcpyAsync into the pinned block, own stream) take it home group by group (fuse_host_grouped): they run beside the kernels (in the trace they are __amd_rocclr_copyBuffer blit kernels; the closing rounds beside them stretch from 72 to ~150 us), and the
 //     length a DMA needs comes from a pinned word the group's last tile writes, read behind the launch's event;
 //   * registering the caller's arrays (hipHostRegister) was measured in rounds 2 and 4: 1.4 ms to register 8.7 MB, copies from
 //     registered memory 43 GB/s, kernel loads from it 40 GB/s -- slower than the pageable copy; the opt-in cache of round 2 is gone.
@@ -704,9 +704,9 @@ int write_back_runs(Lane &l, size_t k, unsigned char *back_d, unsigned char *bac
     return 0;
 }
 
-// The same call with the mesh built in HBM and the copy engine taking it home -- the form for calls of several groups and for calls
+// The same call with the mesh built in HBM and asynchronous copies taking it home -- the form for calls of several groups and for calls
 // that start with the radial correction.  While a kernel streams to host memory no other kernel completes (file comment), so with
-// several groups the storing launches serialise with everything else; the copy engine does not have that problem: group g's
+// several groups the storing launches serialise with everything else; a copy on another stream does not have that problem to the same degree: group g's
 // vertices leave (pinned destination, asynchronous) while group g+1 uploads, is corrected and fused.  What a DMA needs and a
 // storing kernel does not is a LENGTH: the last tile of a group's launch leaves the group's end offset in a pinned word, and the
 // host reads it once the launch's event has fired -- by then it has uploaded the next group, so the wait is short or none.
@@ -889,7 +889,7 @@ int materialize(Lane &l)
 //   merge / single-sensor calls: the kernels store straight into the mesh's host blocks (0.43 / 0.75 ms against 0.55 / 0.84 ms for the
 //       copy-engine form: a pageable upload and an asynchronous download do not run side by side -- the third and fourth upload
 //       run of a call take 103 instead of 37 us while the previous group's vertices are on their way down);
-//   calls that start with the radial correction: mesh in HBM, copy engine home group by group (1.1 against 1.26 ms: the ~100 us
+//   calls that start with the radial correction: mesh in HBM, asynchronous copies home group by group (1.1 against 1.26 ms: the ~100 us
 //       of latency-bound closing rounds per group cannot hide behind a storing kernel, but they do hide behind a DMA).
 // $LSN_HOST_PATH=direct / grouped forces one of them for every call (A/B runs).
 int fuse_host(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths, const int *heights,
