@@ -57,6 +57,7 @@ struct FuseArgs {
     int tiles_per_run;               // mode 1
     unsigned int epoch;              // mode 2: tag of this launch's look-back words (run_state is never cleared)
     int chunk;                       // write pass block order: 0 = tick-major; C > 0 = chunks of C consecutive tiles, all ticks of a chunk before the next chunk
+    int reverse_ticks;               // the write pass takes the ticks last to first (what the count pass read last is nearest in cache); $LSN_WRITE_FORWARD=1: first to last
     int tile0;                       // one-tick plans only: the launch covers tiles [tile0, tile0 + gridDim.x) of the tick (a group of sensors, run_frames)
     int host_out;                    // mode 2: `out` is pinned host memory (plain, destination-aligned stores; see stage_and_store)
     int *group_end_mirror;           // mode 2, optional (pinned host memory): where this launch's vertices end inside the tick, stored by its last tile
