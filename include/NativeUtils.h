@@ -364,9 +364,11 @@ long long lsnPlyBinaryBytes(int n_vertices, int n_triangles);
 long long lsnPlyPack(int device, const void *d_vertices, int n_vertices, const int *d_triangles, int n_triangles, void *d_out,
                      long long out_cap, void *stream);
 
-/* Host callers (LiveScanServer): the mesh the last generateMeshFromDepthMaps / generateVerticesFromDepthMap call returned
- * is still in HBM; these build its SendFrame stream / binary PLY image there and copy the bytes to `out` (host).  With
- * out == NULL they return an upper bound on (stream) / the exact (PLY) length.  Return the length, -1 on error. */
+/* Host callers (LiveScanServer): the mesh the last generateMeshFromDepthMaps / generateVerticesFromDepthMap /
+ * lsnCorrectAndGenerateMesh call of the process returned is still in HBM -- or its frames are, and it is rebuilt there on demand;
+ * these build its SendFrame stream / binary PLY image on the device and copy the bytes to `out` (host).  With
+ * out == NULL they return an upper bound on (stream) / the exact (PLY) length.  Return the length, -1 on error.
+ * "Last" means last: a thread that wants the bytes of ITS mesh must not let another thread make a mesh call in between. */
 long long lsnLastMeshTransferFrame(unsigned char *out, long long out_cap);
 long long lsnLastMeshPly(unsigned char *out, long long out_cap);
 
