@@ -329,7 +329,7 @@ int lsn::pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors,
     FuseArgs a;
     fill_args(p, a, d_depth, d_colors, nullptr, d_offsets);
     launch_count(p, true, s, a);
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames, a.offsets, nullptr);
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kScanThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames, a.offsets, nullptr);
     PackArgs pk;
     pk.mask = static_cast<unsigned char *>(d_mask);
     pk.depth_c = static_cast<unsigned short *>(d_depth_c);

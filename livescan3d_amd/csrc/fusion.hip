@@ -644,6 +644,7 @@ static LsnFusion * lsnFusionCreate_impl(int device, int n_ticks, int n_maps, con
     if (const char *env = getenv("LSN_TILES_PER_RUN")) p->tiles_per_run_override = atoi(env);
     if (const char *env = getenv("LSN_NO_THRESHOLDS")) p->thr_enabled = atoi(env) == 0;
     if (const char *env = getenv("LSN_LAZY_RGB")) p->lazy_rgb = atoi(env) != 0;
+    if (const char *env = getenv("LSN_ONE_TICK_TWO_PASS")) p->one_tick_two_pass = atoi(env) != 0;
     p->n_ticks = n_ticks;
     p->n_maps = n_maps;
     std::vector<FrameDesc> fr(n_maps);
@@ -1114,6 +1115,12 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (p->profile && next_event_pair(p, e0, e1)) return -1;
 
+    // One-tick plans (what a live caller holds: one merge per call) take the single pass by themselves: count -> scan -> write is three
+    // dependent launches around ~5 us of work, the single pass one ($LSN_ONE_TICK_TWO_PASS=1 when the plan is created keeps the three
+    // launches: A/B, bench `shapes`).
+    const bool single_pass = (p->mode == 2 && !with_pixmap && !hooks) || (p->mode == 0 && p->n_ticks == 1 && !hooks && !p->pipelined && !p->one_tick_two_pass);
+    if (p->mode == 0) p->timed_kernel = single_pass ? "fuse_kernel<4>" : nullptr;   // what the event pair below brackets
+
     if (p->pipelined && p->mode == 0 && !with_pixmap && !hooks) {
         // Count + scan of THIS call go to the side stream: they only read the inputs (promised resident by
         // lsnFusionSetPipelined) and write this call's half of the double-buffered scratch, so they overlap with the
@@ -1127,7 +1134,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         FuseArgs ac = a;
         ac.offsets = off_int;
         launch_count(p, vec, p->side, ac);
-        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, p->side, ac.tile_counts, ac.tiles_per_tick, ac.frames,
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kScanThreads), 0, p->side, ac.tile_counts, ac.tiles_per_tick, ac.frames,
                            ac.n_frames, off_int, nullptr);
         LSN_HIP(hipEventRecord(p->ev_counted, p->side));
         LSN_HIP(hipStreamWaitEvent(s, p->ev_counted, 0));
@@ -1137,9 +1144,9 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         if (e1) LSN_HIP(hipEventRecord(e1, s));
         LSN_HIP(hipEventRecord(p->ev_written[b], s));
         p->calls++;
-    } else if (p->mode == 0 || with_pixmap || hooks) {
+    } else if (!single_pass && (p->mode == 0 || with_pixmap || hooks)) {
         launch_count(p, vec, s, a);
-        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kScanThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames,
                            a.offsets, nullptr);
         if (hooks && hooks->h_offsets) LSN_HIP(hipMemcpyAsync(hooks->h_offsets, d_offsets, off_bytes, hipMemcpyDeviceToHost, s));
         if (hooks && hooks->counted) LSN_HIP(hipEventRecord(hooks->counted, s));
@@ -1149,7 +1156,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
         launch<1>(vec, grid, s, a, p->lazy_rgb);
         if (e1) LSN_HIP(hipEventRecord(e1, s));
         if (hooks && hooks->written) LSN_HIP(hipEventRecord(hooks->written, s));
-    } else if (p->mode == 2) {
+    } else if (single_pass) {
         // single pass: per-tile look-back words tagged with the launch's epoch (30 bits; the words are cleared when it wraps)
         if (p->epoch == 0 || p->epoch >= (1u << 30) - 1) {
             LSN_HIP(hipMemsetAsync(p->tile_state.p, 0, sizeof(unsigned long long) * (size_t)grid, s));
@@ -1265,7 +1272,7 @@ static int lsnFusionRunStreamed_impl(LsnFusion *p, const void *d_depth, const vo
         // nothing (valid) was counted ahead for this batch: do it now, like mode 0
         a.offsets = off_cur;
         launch_count(p, vec, s, a);
-        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, cur, a.tiles_per_tick, a.frames, a.n_frames, off_cur, nullptr);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kScanThreads), 0, s, cur, a.tiles_per_tick, a.frames, a.n_frames, off_cur, nullptr);
     }
     LSN_HIP(hipMemcpyAsync(d_offsets, off_cur, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
     a.offsets = d_offsets;
@@ -1281,7 +1288,7 @@ static int lsnFusionRunStreamed_impl(LsnFusion *p, const void *d_depth, const vo
     }
     if (e1) LSN_HIP(hipEventRecord(e1, s));
     if (d_next_depth) {
-        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, nxt, a.tiles_per_tick, a.frames, a.n_frames, off_nxt, nullptr);
+        hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kScanThreads), 0, s, nxt, a.tiles_per_tick, a.frames, a.n_frames, off_nxt, nullptr);
         p->counted_for = d_next_depth;
         p->counted_gen = p->params_gen;
         p->stream_half ^= 1;

@@ -419,44 +419,76 @@ __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)
 
 // Mode 0, between the count and the write launch: one workgroup per tick turns that tick's tile counts into exclusive
 // prefixes in place and fills the per-sensor offset table (offsets[tick][f] = first vertex of sensor f, [n_frames] = total).
+// 1024 threads x 8 consecutive counts each: a tick of up to 8192 tiles (16 x 1024x1024) is ONE round -- two 16-byte loads, a serial
+// prefix in registers, a wave scan of the lane totals, 16 wave totals through LDS -- where 256 threads x 1 count walked it in 32
+// rounds of three barriers each (the config-5 shape has 8 such ticks per step: 8 workgroups on 256 CUs, all of them that slow).
 // mirror (optional): the offset table is also stored there -- pinned host memory, so the host has the counts when the stream
 // is idle without a copy of its own.
+constexpr int kScanThreads = 1024;
+constexpr int kScanItems = 8;
+constexpr int kScanWaves = kScanThreads / 64;
+
 __device__ __forceinline__ void scan_tick(int *tc, int tiles_per_tick, const FrameDesc *frames, int n_frames, int *off, int *mirror_row,
-                                          int (&s_wave)[4], int &s_carry)
+                                          int (&s_wave)[kScanWaves])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < tiles_per_tick; c0 += kThreads) {
-        const int i = c0 + threadIdx.x;
-        int v = 0;
-        if (i < tiles_per_tick) v = tc[i];
-        const int incl = wave_inclusive_scan(v, lane);
+    int carry = 0;   // uniform: every thread adds the same round totals
+    for (int c0 = 0; c0 < tiles_per_tick; c0 += kScanThreads * kScanItems) {
+        const int i0 = c0 + (int)threadIdx.x * kScanItems;
+        int v[kScanItems];
+        const bool whole = i0 + kScanItems <= tiles_per_tick && (reinterpret_cast<uintptr_t>(tc + i0) & 15) == 0;
+        if (whole) {
+            const int4 a = reinterpret_cast<const int4 *>(tc + i0)[0], b = reinterpret_cast<const int4 *>(tc + i0)[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; k++) v[k] = i0 + k < tiles_per_tick ? tc[i0 + k] : 0;
+        }
+        int t = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; k++) {   // v[k] becomes the exclusive prefix inside the lane
+            const int x = v[k];
+            v[k] = t;
+            t += x;
+        }
+        const int incl = wave_inclusive_scan(t, lane);
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        int pre = s_carry;
-        for (int w = 0; w < wave; w++) pre += s_wave[w];
-        if (i < tiles_per_tick) tc[i] = pre + incl - v;
-        __syncthreads();
-        if (threadIdx.x == kThreads - 1) s_carry = pre + incl;
-        __syncthreads();
+        int pre = carry, round_tot = 0;
+#pragma unroll
+        for (int w = 0; w < kScanWaves; w++) {
+            const int x = s_wave[w];
+            if (w < wave) pre += x;
+            round_tot += x;
+        }
+        pre += incl - t;
+        if (whole) {
+            reinterpret_cast<int4 *>(tc + i0)[0] = make_int4(pre + v[0], pre + v[1], pre + v[2], pre + v[3]);
+            reinterpret_cast<int4 *>(tc + i0)[1] = make_int4(pre + v[4], pre + v[5], pre + v[6], pre + v[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; k++)
+                if (i0 + k < tiles_per_tick) tc[i0 + k] = pre + v[k];
+        }
+        carry += round_tot;
+        __syncthreads();   // s_wave is rewritten by the next round; the prefixes above are visible to the workgroup below
     }
     // frames are few: thread f looks up the prefix at its first tile (written above by this workgroup)
-    for (int f = threadIdx.x; f <= n_frames; f += kThreads) {
-        const int v = f < n_frames ? tc[frames[f].tile_start] : s_carry;
+    for (int f = threadIdx.x; f <= n_frames; f += kScanThreads) {
+        const int v = f < n_frames ? tc[frames[f].tile_start] : carry;
         off[f] = v;
         if (mirror_row) mirror_row[f] = v;
     }
 }
 
-__attribute__((unused)) __global__ __launch_bounds__(kThreads) void scan_kernel(int *tile_counts, int tiles_per_tick, const FrameDesc *frames, int n_frames,
+// Launch with dim3(n_ticks) x dim3(kScanThreads).
+__attribute__((unused)) __global__ __launch_bounds__(kScanThreads) void scan_kernel(int *tile_counts, int tiles_per_tick, const FrameDesc *frames, int n_frames,
                                                         int *offsets, int *mirror)
 {
-    __shared__ int s_wave[4];
-    __shared__ int s_carry;
+    __shared__ int s_wave[kScanWaves];
     const int tick = blockIdx.x;
     scan_tick(tile_counts + (long long)tick * tiles_per_tick, tiles_per_tick, frames, n_frames, offsets + (long long)tick * (n_frames + 1),
-                     mirror ? mirror + (long long)tick * (n_frames + 1) : nullptr, s_wave, s_carry);
+                     mirror ? mirror + (long long)tick * (n_frames + 1) : nullptr, s_wave);
 }
 
 
@@ -508,6 +540,7 @@ struct LsnFusion {
     lsn::DevBuf thr;
     bool thr_valid = false;
     bool thr_enabled = true;             // $LSN_NO_THRESHOLDS=1 keeps the arithmetic count pass (ablation / tests)
+    bool one_tick_two_pass = false;      // $LSN_ONE_TICK_TWO_PASS=1: a one-tick plan keeps count -> scan -> write instead of the single pass (A/B)
     bool lazy_rgb = true;                // the write pass loads colours only where a lane kept a pixel; $LSN_LAZY_RGB=0 loads them with the depth (ablation)
     int runs_with_params = 0;
     std::vector<float> last_intr, last_wt;

@@ -90,7 +90,19 @@ __device__ __forceinline__ unsigned int pixel_triangles(const int (&W)[4][4], in
 // undirected edge has ONE metric = their minimum and passes for a triangle iff metric < that triangle's threshold.  The four
 // candidate triangles of a pixel share 5 edges (and the vertical one with the next pixel): 5 metrics per pixel instead
 // of 12 edge walks, no branches.  D: depth rows y-2 .. y+1, columns x0-1 .. x0+9; M: vertex indices of rows y-1, y.
-__device__ __forceinline__ int tri_threshold(int s) { return (272 * s + 2181900) / 300000; }   // :26, in integers
+// depth_thr as tri_ok computes it: (272 s + 2181900) / 300000 (:26, in integers)
+
+// "metric < tri_threshold(s)" without the division: metric + 1 <= floor((272 s + 2181900) / 300000)  <=>  300000 (metric + 1) <= 272 s + 2181900
+// <=>  18750 metric <= 17 s + 117618 (divide by 16, floor the constant: both sides are integers).  metric <= 65535 and s <= 3 * 65535, so both
+// sides fit 32 bits (18750 * 65535 < 2^31) and their factors 24 -- v_mul_u32_u24 / v_mad_u32_u24, full rate, where the division by a constant
+// was a quarter-rate v_mul_hi_u32 plus shifts per threshold, four thresholds per pixel.  A triangle passes when ALL THREE of its edge metrics
+// are below its threshold, i.e. when their maximum is: one v_max3_u32, one multiply, one compare per triangle instead of three compares.
+// Equivalence with tri_threshold for every s and every metric: tests/test_fast_division.py.
+constexpr unsigned int kThrMul = 18750u, kThrSum = 17u, kThrAdd = 117618u;
+__device__ __forceinline__ bool edges_pass(unsigned int m0, unsigned int m1, unsigned int m2, unsigned int s)
+{
+    return __umul24(max(m0, max(m1, m2)), kThrMul) <= __umul24(s, kThrSum) + kThrAdd;
+}
 
 // edge_metric with the probes pre-biased: Z = depth + 2^17 for a valid probe pixel, 2^30 for an invalid one (depth 0), so
 // that |x - probe| becomes one v_sad_u32 on non-negative operands and an invalid probe yields a difference no threshold
@@ -135,13 +147,11 @@ __device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerL
         const unsigned int pu = ev[c - 1], ru = ev[c];                                   // P - U, R - UR
         const bool zP = vP != 0, zU = vU != 0, zUR = vUR != 0, zR = vR != 0;            // :22-23
         const unsigned int sPR = vP + vR, sUUR = vU + vUR;
-        const unsigned int th0 = (unsigned int)tri_threshold((int)(sPR + vU)), th1 = (unsigned int)tri_threshold((int)(sUUR + vR));
-        const unsigned int th2 = (unsigned int)tri_threshold((int)(sUUR + vP)), th3 = (unsigned int)tri_threshold((int)(sPR + vUR));
-        const bool t0 = zR & zU & zP & (d1 < th0) & (pu < th0) & (hP < th0);            // R,U,P   (:117)
-        const bool t1 = zR & zUR & zU & (ru < th1) & (hU < th1) & (d1 < th1);           // R,UR,U  (:118)
+        const bool t0 = zR & zU & zP & edges_pass(d1, pu, hP, sPR + vU);                // R,U,P   (:117)
+        const bool t1 = zR & zUR & zU & edges_pass(ru, hU, d1, sUUR + vR);              // R,UR,U  (:118)
         const bool alt = !(t0 | t1);                                                    // :120
-        const bool t2 = alt & zP & zUR & zU & (d2 < th2) & (hU < th2) & (pu < th2);     // P,UR,U (:122)
-        const bool t3 = alt & zP & zR & zUR & (hP < th3) & (ru < th3) & (d2 < th3);     // P,R,UR (:123)
+        const bool t2 = alt & zP & zUR & zU & edges_pass(d2, hU, pu, sUUR + vP);        // P,UR,U (:122)
+        const bool t3 = alt & zP & zR & zUR & edges_pass(hP, ru, d2, sPR + vUR);        // P,R,UR (:123)
         const bool mP = (mP9 >> k) & 1u, mU = (mU9 >> k) & 1u, mUR = (mU9 >> (k + 1)) & 1u, mR = (mP9 >> (k + 1)) & 1u;
         const bool in_cols = (x >= 1) & (x < w - 2);                                    // :87-90
         unsigned int m = 0;
@@ -420,7 +430,7 @@ static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles,
     if (vec) hipLaunchKernelGGL((tri_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, t);
     else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
     const bool mirror = hooks && hooks->mirror && hooks->h_tri_offsets;
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kThreads), 0, s, t.tile_counts, t.tiles_per_tick, t.frames, p->n_maps,
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)p->n_ticks), dim3(kScanThreads), 0, s, t.tile_counts, t.tiles_per_tick, t.frames, p->n_maps,
                        d_tri_offsets, mirror ? hooks->h_tri_offsets : nullptr);
     if (hooks && hooks->h_tri_offsets && !mirror)
         LSN_HIP(hipMemcpyAsync(hooks->h_tri_offsets, d_tri_offsets, sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1), hipMemcpyDeviceToHost, s));
