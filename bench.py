@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- fused frames/s of the LiveScan3D fusion hot path on MI355X (+ ICP iteration ms).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU -- under torch.distributed.run, or started by
+                                                          bench.py itself as a child process when no launcher is around it)
 
 A "step" fuses `--ticks` ticks of `--sensors` synthetic 512x424 Kinect streams (depth u16 + RGB8, resident in HBM
 before the timed region) into `--ticks` merged coloured clouds: unproject + R(p+t) + AABB crop + raster-order
@@ -90,8 +91,56 @@ def leg(result, name):
         result[name] = {"error": f"{type(ex).__name__}: {ex}"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves -- as a CHILD process (never an exec:
+    nothing in this process has touched the GPU yet, and nothing will), `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` on 127.0.0.1 and a free port -- relay rank 0's JSON line and leave with the child's status.  Under an existing launcher
+    (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL between processes needs on these hosts
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in child.stdout:                                # rank 0's line is the only thing the ranks put on stdout; anything else goes by
+        if out.lstrip().startswith("{"):
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    raise SystemExit(rc if rc != 0 or line is not None else 1)
+
+
+def launch_probe(args):
+    """LSN_BENCH_LAUNCH_PROBE=1: the ranks meet over gloo, count each other and rank 0 prints one line -- the launch path of an N > 1 run
+    (self_launch or an outer launcher, rendezvous, the relay of the line) without a GPU.  tests/test_sharding_gloo.py."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    seen = torch.ones(1, dtype=torch.int32)
+    dist.all_reduce(seen)
+    if dist.get_rank() == 0:
+        print(json.dumps({"probe": True, "n_gpus": args.gpus, "n_ranks_seen": int(seen.item()), "world_size": dist.get_world_size()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if os.environ.get("LSN_BENCH_LAUNCH_PROBE") == "1":
+        return launch_probe(args)
     # stdout carries the ONE JSON line and nothing else: RCCL (version banner, "NCCL WARN ..." lines) and other native code
     # print on fd 1, so fd 1 is pointed at stderr for the whole run and the line goes out through a private copy of the real stdout
     sys.stdout.flush()
@@ -106,8 +155,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libNativeUtils has no CPU path")
@@ -297,6 +344,14 @@ def main():
     if args.mode in (1, 2) and fus.plan.lookback_failed(stream):
         raise SystemExit("look-back compaction gave up on a bounded spin: results invalid")
 
+    # N > 1: how many ranks actually took part, as the communicators themselves report it (not what the command line asked for): every rank
+    # adds a one through torch's group; the library's own RCCL communicator (lsnShard*) is asked for its ncclCommCount
+    ranks_seen = None
+    if multi:
+        ones = torch.ones(1, dtype=torch.int32, device="cpu" if share else dev)
+        dist.all_reduce(ones)
+        ranks_seen = {"process_group": int(ones.item()), "library_communicator": shard.shard.ranks_seen() if use_shard else None}
+
     result = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -308,6 +363,7 @@ def main():
             "value": B * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
+            **({"n_ranks_seen": ranks_seen["process_group"], "n_ranks_seen_by": ranks_seen} if multi else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "settle_ms": settle_ms,

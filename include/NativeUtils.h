@@ -92,6 +92,23 @@ void lsnCorrectAndGenerateMesh(int n_maps, unsigned char *depth_maps, unsigned c
 int lsnHostScheduleDescribe(int n_maps, const int *widths, const int *heights, int first, int count, int radial, int sensors_per_group,
                             char *buf, int len);
 
+/* Merge calls sharded over several devices.  $LSN_HOST_DEVICES=a,b,... (>= 2 entries, read at the first call; an entry may repeat):
+ * generateMeshFromDepthMaps and lsnCorrectAndGenerateMesh give every listed device one contiguous block of the call's sensors -- uploaded
+ * over that device's link, fused there, and stored by its kernels over its link into the SAME pinned Mesh blocks, behind the blocks
+ * before it (formMesh's sensor order and triangle rebase, src/NativeUtils/depthprocessing.cpp:1594-1626; the reference's std::thread per
+ * sensor, :708-733, with a device where it has a thread).  The mesh returned is byte for byte the one-device mesh.
+ * lsnHostShardDescribe (host-only): how n_maps sensors are cut over n_devices (0 = as configured by the environment) -- text such as
+ * "0:[0-3] 1:[4-7]" into buf, the block bounds into first_out (n_devices + 1 ints; may be NULL).  Returns the number of shards, -1 on
+ * bad arguments. */
+int lsnHostShardDescribe(int n_maps, int n_devices, int *first_out, char *buf, int len);
+
+/* Test hooks (no device needed).  lsnTestFaultPoints: how many fault points of a kind the process has passed (0 = guarded entries,
+ * 1 = device / pinned allocations; $LSN_TEST_THROW / $LSN_TEST_FAIL_ALLOC = n make the n-th one throw std::bad_alloc inside the export).
+ * lsnHostPoolStats: the pool of pinned mesh blocks -- blocks out with callers (a block a failed call did not return would stay here),
+ * blocks waiting for reuse, bytes out; any pointer may be NULL. */
+long long lsnTestFaultPoints(int kind);
+int lsnHostPoolStats(int *live_blocks, int *pooled_blocks, long long *live_bytes);
+
 /* Replaces createMesh / deleteMesh, src/NativeUtils/depthprocessing.cpp:1818-1835.  deleteMesh releases the two
  * arrays only (not the struct) and, unlike the reference, also nulls them so a second call is harmless. */
 Mesh *createMesh(void);
@@ -279,6 +296,9 @@ int lsnShardStep(LsnShard *shard, const void *d_depth_local, const void *d_color
 LsnFusion *lsnShardPlan(LsnShard *shard, int whole);
 /* bytes this rank contributed to the collectives of the last step (what every other rank received from it) */
 long long lsnShardLastBytesSent(const LsnShard *shard);
+/* the rank count the connected communicator itself reports (ncclCommCount; its ncclCommUserRank must equal the handle's rank);
+ * -1 when the handle is not connected or the RCCL in use lacks the call */
+int lsnShardRanksSeen(LsnShard *shard);
 
 /* The plan's sticky device-side error flag since the last check (synchronises `stream`, clears the flag):
  *   0 = fine; 1 = a look-back launch (mode 1) gave up on a bounded spin; 2 = a write pass found a tile whose survivors

@@ -33,10 +33,12 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <map>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -62,12 +64,15 @@ void set_error(const char *fmt, ...) noexcept
 // Test hook of the exception trampoline (lsn::guarded): $LSN_TEST_THROW=n makes the n-th guarded entry of the process throw
 // std::bad_alloc from inside the guarded region; $LSN_TEST_FAIL_ALLOC=n makes the n-th device / pinned allocation throw it
 // (what a std::vector or std::map growing under memory pressure would do).  Read once.
+static std::atomic<long> fault_points_seen[2];
+long test_fault_points(int kind) { return kind >= 0 && kind < 2 ? fault_points_seen[kind].load() : -1; }
+
 void test_fault_point(int kind)
 {
     static const long want[2] = {getenv("LSN_TEST_THROW") ? atol(getenv("LSN_TEST_THROW")) : 0,
                                  getenv("LSN_TEST_FAIL_ALLOC") ? atol(getenv("LSN_TEST_FAIL_ALLOC")) : 0};
-    static std::atomic<long> seen[2];
-    if (want[kind] > 0 && ++seen[kind] == want[kind]) throw std::bad_alloc();
+    const long n = ++fault_points_seen[kind];
+    if (want[kind] > 0 && n == want[kind]) throw std::bad_alloc();
 }
 
 }  // namespace lsn
@@ -229,6 +234,7 @@ constexpr int kMaxGroups = 16;
 // threads (MainWindowForm.cs:238,304); each of the three families has its own lane, so they only meet at the pool of pinned blocks.
 struct Lane {
     std::mutex mu;
+    int device = 0;           // the device the lane's streams, buffers and plans live on
     hipStream_t stream = nullptr, up = nullptr, down = nullptr, back = nullptr;   // kernels; uploads; mesh downloads; write-backs of corrected maps
     hipEvent_t ev_group[kMaxGroups] = {};    // "group g's vertices are in HBM (and its corrected maps final)"
     hipEvent_t ev_tri = nullptr;             // "the triangle counts are known"
@@ -244,9 +250,69 @@ struct Lane {
     int last_nv = -1, last_nt = 0;
     bool last_in_hbm = false, last_radial = false, last_tri = false;
     LsnFusion *last_plan = nullptr;
+    // ... or it was a call sharded over the devices of $LSN_HOST_DEVICES: the mesh only exists in host memory and its inputs are spread
+    // over the shards' lanes; what materialize() needs to rebuild it here
+    bool last_sharded = false;
+    std::vector<int> last_w, last_h;
+    std::vector<float> last_intr, last_wt, last_bounds;
     std::vector<Group> groups;
     std::vector<Copy> copies;
 };
+
+// A thread that runs one job at a time for the thread that hands it over.  A pageable upload keeps the thread that issues it until the
+// bytes are on the device (file comment), so D links are only busy at once when D threads issue the copies: one worker per device of
+// $LSN_HOST_DEVICES beyond the first (the calling thread serves the first).  Started on first use, never joined (the context is never
+// destroyed): an idle worker sits in its condition variable and touches nothing.
+struct Worker {
+    std::mutex mu;
+    std::condition_variable cv;
+    void (*fn)(void *, int) = nullptr;
+    void *arg = nullptr;
+    int index = 0;
+    bool busy = false, started = false;
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return fn != nullptr; });
+            void (*f)(void *, int) = fn;
+            void *a = arg;
+            const int i = index;
+            fn = nullptr;
+            lk.unlock();
+            f(a, i);   // never throws: the job catches everything itself
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void submit(void (*f)(void *, int), void *a, int i)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!started) {
+            std::thread(&Worker::loop, this).detach();
+            started = true;
+        }
+        fn = f;
+        arg = a;
+        index = i;
+        busy = true;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !busy; });
+    }
+};
+
+// One device of $LSN_HOST_DEVICES: its lane (streams, buffers, plans -- only used under the merge lane's lock) and its worker.
+struct HostShard {
+    Lane lane;
+    Worker worker;
+};
+
+constexpr int kMaxShards = 16;
 
 struct Ctx {
     Lane merge, single;       // lane of the merge / radial / last-mesh calls; lane of the single-sensor calls
@@ -256,6 +322,7 @@ struct Ctx {
     std::atomic<Lane *> last_lane{nullptr};   // the lane whose call finished last: lsnLastMesh* read the mesh it left in HBM
     bool ready = false;
     int device = 0;
+    std::vector<HostShard *> shards;   // $LSN_HOST_DEVICES=a,b,...: merge calls are sharded over these devices (>= 2 entries; an entry may repeat)
     int host_path = 0;        // $LSN_HOST_PATH: 0 = by call (default), 1 = "direct" (kernel stores) always, 2 = "grouped" (copy engine) always
     int group_override = 0;   // $LSN_HOST_GROUP: sensors per group (0 = by size)
     hipStream_t icp_stream = nullptr;
@@ -278,6 +345,25 @@ Ctx &ctx()
     return *c;
 }
 
+// "0,1,2" -> devices; every entry must name a visible device, an entry may repeat (two shards on one device: the rehearsal a one-GPU box allows)
+int parse_device_list(const char *text, int n_visible, std::vector<int> &out)
+{
+    out.clear();
+    const char *p = text;
+    while (*p) {
+        char *end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p || v < 0 || v >= n_visible || (int)out.size() >= kMaxShards) {
+            lsn::set_error("NativeUtils: LSN_HOST_DEVICES=%s: expected up to %d comma-separated device numbers below %d", text, kMaxShards, n_visible);
+            return -1;
+        }
+        out.push_back((int)v);
+        p = end;
+        while (*p == ',' || *p == ' ') p++;
+    }
+    return 0;
+}
+
 // Takes c.init_mu itself; callers may hold c.mu or c.icp_mu.
 int ensure_ready(Ctx &c)
 {
@@ -297,11 +383,26 @@ int ensure_ready(Ctx &c)
     }
     LSN_HIP(hipSetDevice(c.device));
     LSN_HIP(hipStreamCreateWithFlags(&c.icp_stream, hipStreamNonBlocking));
-    for (Lane *l : {&c.merge, &c.single}) {
+    std::vector<int> shard_devices;
+    if (const char *e = getenv("LSN_HOST_DEVICES")) {
+        if (parse_device_list(e, n, shard_devices)) return -1;
+        if (shard_devices.size() < 2) shard_devices.clear();   // one device: nothing to shard over
+    }
+    std::vector<Lane *> lanes = {&c.merge, &c.single};
+    c.merge.device = c.single.device = c.device;
+    for (int dev : shard_devices) {
+        HostShard *sh = new HostShard();
+        sh->lane.device = dev;
+        c.shards.push_back(sh);
+        lanes.push_back(&sh->lane);
+    }
+    for (Lane *l : lanes) {
+        LSN_HIP(hipSetDevice(l->device));
         for (hipStream_t *s : {&l->stream, &l->up, &l->down, &l->back}) LSN_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
         LSN_HIP(hipEventCreateWithFlags(&l->ev_tri, hipEventDisableTiming));
         for (int i = 0; i < kMaxGroups; i++) LSN_HIP(hipEventCreateWithFlags(&l->ev_group[i], hipEventDisableTiming));
     }
+    LSN_HIP(hipSetDevice(c.device));
     if (const char *e = getenv("LSN_HOST_PATH")) c.host_path = !strcmp(e, "direct") ? 1 : (!strcmp(e, "grouped") || !strcmp(e, "copy")) ? 2 : 0;
     if (const char *e = getenv("LSN_HOST_GROUP")) c.group_override = atoi(e);
     c.ready = true;
@@ -333,7 +434,8 @@ void *pinned_get(Ctx &c, size_t bytes)
     }
     void *p = nullptr;
     size_t cap = (bytes + 4095) & ~(size_t)4095;
-    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+    // portable: every device of $LSN_HOST_DEVICES stores into the same block
+    if (hipHostMalloc(&p, cap, c.shards.empty() ? hipHostMallocDefault : hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         lsn::set_error("NativeUtils: hipHostMalloc(%zu) failed", cap);
         return nullptr;
@@ -395,7 +497,7 @@ LsnFusion *get_plan(Ctx &c, Lane &l, const int *widths, const int *heights, int 
             kv = l.plans.erase(kv);
         }
     }
-    LsnFusion *plan = lsnFusionCreate(c.device, 1, count, widths + first, heights + first);
+    LsnFusion *plan = lsnFusionCreate(l.device, 1, count, widths + first, heights + first);
     if (!plan) return nullptr;
     try {
         l.plans[key] = plan;
@@ -414,8 +516,8 @@ int ensure_tables(Lane &l, int n)
     if (l.h_toff) (void)hipHostFree(l.h_toff);
     l.h_off = l.h_toff = nullptr;
     l.h_off_cap = 0;
-    LSN_HIP(hipHostMalloc((void **)&l.h_off, sizeof(int) * (size_t)(n + 64), hipHostMallocDefault));
-    LSN_HIP(hipHostMalloc((void **)&l.h_toff, sizeof(int) * (size_t)(n + 64), hipHostMallocDefault));
+    LSN_HIP(hipHostMalloc((void **)&l.h_off, sizeof(int) * (size_t)(n + 64), hipHostMallocPortable));
+    LSN_HIP(hipHostMalloc((void **)&l.h_toff, sizeof(int) * (size_t)(n + 64), hipHostMallocPortable));
     l.h_off_cap = n + 64;
     return 0;
 }
@@ -553,139 +655,155 @@ struct PhaseTrace {
     }
 };
 
-// Fuses `count` sensors of one tick from host buffers into out_mesh, the kernels storing straight into the mesh's host blocks
-// (file comment).  first/count select the sensors (generateVerticesFromDepthMap uses one).  The lane's lock is held.
-// radial (optional): the call starts with the radial correction of the frames (depthMapAndColorSetRadialCorrection) on the device;
-// radial_back_d / radial_back_c (optional): the corrected maps are also copied to these host arrays, like the separate export does.
-int fuse_host_direct(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths, const int *heights,
-                     const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count, bool with_triangles, bool radial,
-                     unsigned char *radial_back_d, unsigned char *radial_back_c)
-{
-    l.last_nv = -1;
-    l.last_plan = nullptr;
-    static const bool trace_env = getenv("LSN_HOST_TRACE") && atoi(getenv("LSN_HOST_TRACE")) != 0;
-    static std::atomic<int> trace_calls{0};
+// Everything one merge / single-sensor / correct-and-merge call holds while it runs, and the steps its two flows share: the plan and
+// the upload schedule, the lane's device buffers, the pinned blocks that become Mesh::vertices / Mesh::triangles, the upload loop that
+// hands every group of sensors to the flow the moment its frames are on the device, the hand-over to the caller.
+// The destructor IS the error path: unless commit() has handed the blocks to the caller, it drains the lane -- no kernel may store to,
+// and no copy land in, a block that goes back to the pool, and no kernel may still write the lane's pinned tables when the lock is
+// released -- and returns the blocks.  Whatever ended the call takes it: a failed HIP call, a refused launch, or an exception
+// (std::bad_alloc from a table that grows, a test's fault injection) on its way to the trampoline.  The lane's lock is held throughout.
+struct HostCall {
+    Ctx &c;
+    Lane &l;
+    const unsigned char *depth_maps, *depth_colors;
+    const int *widths, *heights;
+    const float *intr, *wt, *bounds6;
+    int first, count;                       // the sensors of the call (generateVerticesFromDepthMap uses one)
+    bool with_triangles, radial;            // radial: the call starts with the radial correction of the frames, on the device
+    unsigned char *back_d, *back_c;         // optional: the corrected maps are also copied to these host arrays, like the separate export does
+    LsnFusion *plan = nullptr;
+    size_t G = 0;
+    long long cap = 0;
+    void *host = nullptr, *host_tri = nullptr;
+    bool back = false, committed = false;
+    const char *run_d = nullptr, *run_c = nullptr;   // what the fusion and triangle launches read: the raw frames, or the corrected ones
     PhaseTrace tr;
-    if (trace_env) {
-        const int k = trace_calls++;
-        tr.on = k >= 10 && k < 13;
+
+    HostCall(Ctx &c_, Lane &l_, const unsigned char *dm, const unsigned char *dc, const int *w, const int *h, const float *in, const float *wtp,
+             const float *b6, int first_, int count_, bool tri, bool rad, unsigned char *bd, unsigned char *bc)
+        : c(c_), l(l_), depth_maps(dm), depth_colors(dc), widths(w), heights(h), intr(in), wt(wtp), bounds6(b6), first(first_), count(count_),
+          with_triangles(tri), radial(rad), back_d(bd), back_c(bc)
+    {
     }
-    tr.mark("enter");
-    l.groups.clear();
-    LsnFusion *plan = get_plan(c, l, widths, heights, first, count);
-    if (!plan) return -1;
-    l.last_plan = plan;
-    if (make_schedule(c, l, widths, heights, first, count, radial)) return -1;
-    const size_t G = l.groups.size();
-    size_t dbytes = 0, cbytes = 0;
-    for (const Group &g : l.groups) {
-        dbytes += g.dbytes;
-        cbytes += g.cbytes;
-    }
-    const long long cap = lsnFusionTickCapacity(plan);
-    if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_off.reserve(sizeof(int) * (size_t)(count + 1)) ||
-        l.d_tri_off.reserve(sizeof(int) * (size_t)(count + 1)) || ensure_tables(l, count + 2))
-        return -1;
-    if (radial && (l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16))) return -1;
-    const bool back = radial && radial_back_d && radial_back_c;
-    // the mesh's host blocks, sized for the most the frames can give (recycled through the pool: the same blocks tick after tick)
-    void *host = pinned_get(c, (size_t)cap * sizeof(VertexC4ubV3f));
-    void *host_tri = with_triangles ? pinned_get(c, (size_t)cap * 2 * 12) : nullptr;
-    auto fail = [&]() {
-        drain(l);   // nothing of a failed call stays in flight: no kernel may store to a block that goes back to the pool
+    HostCall(const HostCall &) = delete;
+    HostCall &operator=(const HostCall &) = delete;
+    ~HostCall()
+    {
+        if (committed) return;
+        drain(l);
         if (host) pinned_put(c, host);
         if (host_tri) pinned_put(c, host_tri);
-        return -1;
-    };
-    if (!host || (with_triangles && !host_tri)) return fail();
-    l.h_off[count] = -1;       // the total: stored by the last tile of the last group
-    l.h_off[count + 1] = 0;    // the look-back's give-up flag
-    l.h_toff[count] = 0;
-    if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, l.stream)) return fail();
-    tr.mark("setup");
+    }
 
-    // what the fusion and triangle launches read: the raw frames, or the corrected ones
-    const char *run_d = radial ? l.d_depth2.as<char>() : l.d_depth.as<char>();
-    const char *run_c = radial ? l.d_colors2.as<char>() : l.d_colors.as<char>();
-    // One group (a single sensor: ~1 MB up, ~2 MB down, all fixed latency; or frames the scheme cannot cut): its copies go
-    // asynchronously on the kernels' stream.  Several groups: every copy blocks on the upload stream until the bytes are there, so
-    // the launch behind it needs no event, and runs (storing to the host) while the next copy is on its way up.
-    size_t next_group = 0;
-    for (size_t i = 0; i < l.copies.size(); i++) {
-        const Copy &cp = l.copies[i];
-        char *dst = (cp.colours ? l.d_colors.as<char>() : l.d_depth.as<char>()) + cp.dev_off;
-        const unsigned char *src = (cp.colours ? depth_colors : depth_maps) + cp.src_off;
-        const hipError_t e = G == 1 ? hipMemcpyAsync(dst, src, cp.bytes, hipMemcpyHostToDevice, l.stream)
-                                    : hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyHostToDevice, l.up);
-        if (e != hipSuccess) {
-            lsn::set_error("NativeUtils: upload failed: %s", hipGetErrorString(e));
-            return fail();
+    // Plan, schedule, buffers, the vertex block.  in_hbm: the mesh is built in the lane's HBM buffers (the copy-engine flow), else the
+    // kernels store into the pinned blocks and the triangle block is taken here as well; extra_tab: pinned table words beyond
+    // offsets [count + 1] and the give-up flag.
+    int begin(bool in_hbm, int extra_tab)
+    {
+        l.last_nv = -1;
+        l.last_plan = nullptr;
+        l.last_sharded = false;
+        static const bool trace_env = getenv("LSN_HOST_TRACE") && atoi(getenv("LSN_HOST_TRACE")) != 0;
+        static std::atomic<int> trace_calls{0};
+        if (trace_env) {
+            const int k = trace_calls++;
+            tr.on = k >= 10 && k < 13;
         }
-        tr.mark(cp.colours ? "upC" : "upD");
-        for (; next_group < G && l.groups[next_group].ready_after == (int)i + 1; next_group++) {
-            const Group &g = l.groups[next_group];
-            if (radial) {
-                // out of place: raw frames in d_depth / d_colors, corrected ones in the second pair, which the launches below read
-                if (lsnFusionRadialCorrectTo(g.radial_plan, intr + 7 * g.first, l.d_depth.as<char>() + g.d_off, l.d_colors.as<char>() + g.c_off,
-                                             l.d_depth2.as<char>() + g.d_off, l.d_colors2.as<char>() + g.c_off, l.stream))
-                    return fail();
-                if (back && hipEventRecord(l.ev_group[next_group], l.stream) != hipSuccess) return fail();
+        tr.mark("enter");
+        l.groups.clear();
+        plan = get_plan(c, l, widths, heights, first, count);
+        if (!plan) return -1;
+        l.last_plan = plan;
+        if (make_schedule(c, l, widths, heights, first, count, radial)) return -1;
+        G = l.groups.size();
+        size_t dbytes = 0, cbytes = 0;
+        for (const Group &g : l.groups) {
+            dbytes += g.dbytes;
+            cbytes += g.cbytes;
+        }
+        cap = lsnFusionTickCapacity(plan);
+        if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_off.reserve(sizeof(int) * (size_t)(count + 1)) ||
+            l.d_tri_off.reserve(sizeof(int) * (size_t)(count + 1)) || ensure_tables(l, count + 2 + extra_tab))
+            return -1;
+        if (radial && (l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16))) return -1;
+        if (in_hbm && (l.d_out.reserve((size_t)cap * 16) || (with_triangles && l.d_tri.reserve((size_t)cap * 2 * 12)))) return -1;
+        back = radial && back_d && back_c;
+        // the mesh's host blocks, sized for the most the frames can give (recycled through the pool: the same blocks tick after tick);
+        // capacity-sized because the first vertices leave before the count is known
+        host = pinned_get(c, (size_t)cap * sizeof(VertexC4ubV3f));
+        if (!host) return -1;
+        if (!in_hbm && with_triangles && !(host_tri = pinned_get(c, (size_t)cap * 2 * 12))) return -1;
+        l.h_off[count] = -1;       // the total: stored by the last tile of the last group
+        l.h_off[count + 1] = 0;    // the look-back's give-up flag
+        l.h_toff[count] = 0;
+        if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, l.stream)) return -1;
+        run_d = radial ? l.d_depth2.as<char>() : l.d_depth.as<char>();
+        run_c = radial ? l.d_colors2.as<char>() : l.d_colors.as<char>();
+        tr.mark("setup");
+        return 0;
+    }
+
+    // The upload schedule, run by run; group k is handed to on_group(k) -- corrected first, if the call asks for it -- as soon as its
+    // frames have landed.  One group (a single sensor: ~1 MB up, ~2 MB down, all fixed latency; or frames the scheme cannot cut): its
+    // copies go asynchronously on the kernels' stream.  Several groups: every copy blocks on the upload stream until the bytes are
+    // there, so the launch behind it needs no event, and runs while the next copy is on its way up.
+    template <class F>
+    int upload(F &&on_group)
+    {
+        size_t next_group = 0;
+        for (size_t i = 0; i < l.copies.size(); i++) {
+            const Copy &cp = l.copies[i];
+            char *dst = (cp.colours ? l.d_colors.as<char>() : l.d_depth.as<char>()) + cp.dev_off;
+            const unsigned char *src = (cp.colours ? depth_colors : depth_maps) + cp.src_off;
+            const hipError_t e = G == 1 ? hipMemcpyAsync(dst, src, cp.bytes, hipMemcpyHostToDevice, l.stream)
+                                        : hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyHostToDevice, l.up);
+            if (e != hipSuccess) {
+                lsn::set_error("NativeUtils: upload failed: %s", hipGetErrorString(e));
+                return -1;
             }
-            if (lsn::run_frames(plan, run_d, run_c, host, l.d_off.as<int>(), g.first - first, g.first - first + g.count, next_group == 0, with_triangles,
-                                l.h_off, nullptr, true, l.stream))
-                return fail();
-            tr.mark("launch");
-        }
-    }
-    if (with_triangles && lsn::run_triangles(plan, run_d, host_tri, l.d_tri_off.as<int>(), l.h_toff, true, l.stream)) return fail();
-    if (back) {
-        // the corrected maps go home group by group (copy engine, pageable destination: each copy blocks) while the launches run
-        for (size_t k = 0; k < G; k++) {
-            const Group &b = l.groups[k];
-            if (hipStreamWaitEvent(l.down, l.ev_group[k], 0) != hipSuccess ||
-                hipMemcpyWithStream(radial_back_d + b.d_src, l.d_depth2.as<char>() + b.d_off, b.dbytes, hipMemcpyDeviceToHost, l.down) != hipSuccess ||
-                hipMemcpyWithStream(radial_back_c + b.c_src, l.d_colors2.as<char>() + b.c_off, b.cbytes, hipMemcpyDeviceToHost, l.down) != hipSuccess) {
-                lsn::set_error("NativeUtils: write-back of the corrected maps failed: %s", hipGetErrorString(hipGetLastError()));
-                return fail();
+            tr.mark(cp.colours ? "upC" : "upD");
+            for (; next_group < G && l.groups[next_group].ready_after == (int)i + 1; next_group++) {
+                const Group &g = l.groups[next_group];
+                // out of place: raw frames in d_depth / d_colors, corrected ones in the second pair, which the launches read
+                if (radial && lsnFusionRadialCorrectTo(g.radial_plan, intr + 7 * g.first, l.d_depth.as<char>() + g.d_off, l.d_colors.as<char>() + g.c_off,
+                                                       l.d_depth2.as<char>() + g.d_off, l.d_colors2.as<char>() + g.c_off, l.stream))
+                    return -1;
+                if (on_group(next_group, g)) return -1;
+                tr.mark("launch");
             }
-            tr.mark("back");
         }
+        return 0;
     }
-    tr.mark("queued");
-    if (hipStreamSynchronize(l.stream) != hipSuccess) {
-        lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
-        return fail();
+
+    // One launch, single pass, over group k's sensors, continuing where group k - 1 stopped (fusion.hip: run_frames).
+    int fuse_group(size_t k, const Group &g, void *vertices, int *group_end_mirror, bool host_out)
+    {
+        return lsn::run_frames(plan, run_d, run_c, vertices, l.d_off.as<int>(), g.first - first, g.first - first + g.count, k == 0, with_triangles, l.h_off,
+                               group_end_mirror, host_out, l.stream);
     }
-    tr.mark("sync");
-    // the kernels left the counts in the pinned tables
-    const int nv = l.h_off[count], nt = with_triangles ? l.h_toff[count] : 0;
-    if (l.h_off[count + 1] != 0) {
-        (void)lsnFusionCheck(plan, l.stream);   // clears the plan's sticky flag
-        lsn::set_error("NativeUtils: the single-pass fusion gave up on a predecessor tile (look-back spin limit)");
-        return fail();
+
+    // The mesh is the caller's from here on (deleteMesh returns its blocks to the pool).
+    void commit(Mesh *out, int nv, int nt, bool in_hbm)
+    {
+        if (nt == 0 && host_tri) {
+            pinned_put(c, host_tri);
+            host_tri = nullptr;
+        }
+        l.last_nv = nv;
+        l.last_nt = nt;
+        l.last_in_hbm = in_hbm;
+        l.last_radial = radial;
+        l.last_tri = with_triangles;
+        out->nVertices = nv;
+        out->vertices = static_cast<VertexC4ubV3f *>(host);
+        out->nTriangles = nt;
+        out->triangles = nt > 0 ? static_cast<int *>(host_tri) : g_no_triangles;
+        committed = true;
+        c.last_lane.store(&l);
+        tr.mark("done");
+        tr.print();
     }
-    if (nv < 0 || nv > cap || nt < 0 || nt > 2 * cap) {
-        lsn::set_error("NativeUtils: device returned impossible counts (%d vertices, %d triangles)", nv, nt);
-        return fail();
-    }
-    if (nt == 0) {
-        if (host_tri) pinned_put(c, host_tri);
-        host_tri = nullptr;
-    }
-    l.last_nv = nv;
-    l.last_nt = nt;
-    l.last_in_hbm = false;
-    l.last_radial = radial;
-    l.last_tri = with_triangles;
-    out->nVertices = nv;
-    out->vertices = static_cast<VertexC4ubV3f *>(host);
-    out->nTriangles = nt;
-    out->triangles = nt > 0 ? static_cast<int *>(host_tri) : g_no_triangles;
-    c.last_lane.store(&l);
-    tr.mark("done");
-    tr.print();
-    return 0;
-}
+};
 
 // The corrected maps of group k go home in the runs of the upload schedule (>= 1 MiB each: a smaller pageable copy is staged through
 // a bounce buffer): every run whose last group is k.  Pageable destination: these copies keep the thread; on their own stream.
@@ -704,166 +822,430 @@ int write_back_runs(Lane &l, size_t k, unsigned char *back_d, unsigned char *bac
     return 0;
 }
 
-// The same call with the mesh built in HBM and asynchronous copies taking it home -- the form for calls of several groups and for calls
-// that start with the radial correction.  While a kernel streams to host memory no other kernel completes (file comment), so with
-// several groups the storing launches serialise with everything else; a copy on another stream does not have that problem to the same degree: group g's
-// vertices leave (pinned destination, asynchronous) while group g+1 uploads, is corrected and fused.  What a DMA needs and a
-// storing kernel does not is a LENGTH: the last tile of a group's launch leaves the group's end offset in a pinned word, and the
-// host reads it once the launch's event has fired -- by then it has uploaded the next group, so the wait is short or none.
-int fuse_host_grouped(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths, const int *heights,
-                      const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count, bool with_triangles, bool radial,
-                      unsigned char *radial_back_d, unsigned char *radial_back_c)
+// Flow 1: the kernels store the vertices and the triangles straight into the mesh's host blocks (file comment).
+int fuse_host_direct(HostCall &h, Mesh *out)
 {
-    l.last_nv = -1;
-    l.last_plan = nullptr;
-    static const bool trace_env = getenv("LSN_HOST_TRACE") && atoi(getenv("LSN_HOST_TRACE")) != 0;
-    static std::atomic<int> trace_calls{0};
-    PhaseTrace tr;
-    if (trace_env) {
-        const int k = trace_calls++;
-        tr.on = k >= 10 && k < 13;
-    }
-    tr.mark("enter");
-    l.groups.clear();
-    LsnFusion *plan = get_plan(c, l, widths, heights, first, count);
-    if (!plan) return -1;
-    l.last_plan = plan;
-    if (make_schedule(c, l, widths, heights, first, count, radial)) return -1;
-    const size_t G = l.groups.size();
-    size_t dbytes = 0, cbytes = 0;
-    for (const Group &g : l.groups) {
-        dbytes += g.dbytes;
-        cbytes += g.cbytes;
-    }
-    const long long cap = lsnFusionTickCapacity(plan);
-    const int n_tab = count + 2 + (int)G;   // offsets [count + 1], give-up flag, then the groups' end offsets
-    if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_out.reserve((size_t)cap * 16) ||
-        l.d_off.reserve(sizeof(int) * (size_t)(count + 1)) || l.d_tri_off.reserve(sizeof(int) * (size_t)(count + 1)) || ensure_tables(l, n_tab))
+    Lane &l = h.l;
+    if (h.begin(false, 0)) return -1;
+    if (h.upload([&](size_t k, const Group &g) -> int {
+            if (h.back && hipEventRecord(l.ev_group[k], l.stream) != hipSuccess) return -1;   // "group k's corrected maps are final"
+            return h.fuse_group(k, g, h.host, nullptr, true);
+        }))
         return -1;
-    if (radial && (l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16))) return -1;
-    if (with_triangles && l.d_tri.reserve((size_t)cap * 2 * 12)) return -1;
-    const bool back = radial && radial_back_d && radial_back_c;
-    void *host = pinned_get(c, (size_t)cap * sizeof(VertexC4ubV3f));   // capacity-sized: the first vertices leave before the count is known
-    void *host_tri = nullptr;
-    auto fail = [&]() {
-        drain(l);   // nothing of a failed call stays in flight: no copy may land in a block that goes back to the pool
-        if (host) pinned_put(c, host);
-        if (host_tri) pinned_put(c, host_tri);
+    if (h.with_triangles && lsn::run_triangles(h.plan, h.run_d, h.host_tri, l.d_tri_off.as<int>(), l.h_toff, true, l.stream)) return -1;
+    if (h.back) {
+        // the corrected maps go home group by group (copy engine, pageable destination: each copy blocks) while the launches run
+        for (size_t k = 0; k < h.G; k++) {
+            const Group &b = l.groups[k];
+            if (hipStreamWaitEvent(l.down, l.ev_group[k], 0) != hipSuccess ||
+                hipMemcpyWithStream(h.back_d + b.d_src, l.d_depth2.as<char>() + b.d_off, b.dbytes, hipMemcpyDeviceToHost, l.down) != hipSuccess ||
+                hipMemcpyWithStream(h.back_c + b.c_src, l.d_colors2.as<char>() + b.c_off, b.cbytes, hipMemcpyDeviceToHost, l.down) != hipSuccess) {
+                lsn::set_error("NativeUtils: write-back of the corrected maps failed: %s", hipGetErrorString(hipGetLastError()));
+                return -1;
+            }
+            h.tr.mark("back");
+        }
+    }
+    h.tr.mark("queued");
+    if (hipStreamSynchronize(l.stream) != hipSuccess) {
+        lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
         return -1;
-    };
-    if (!host) return fail();
-    int *h_end = l.h_off + count + 2;
-    l.h_off[count + 1] = 0;    // the look-back's give-up flag
-    if (lsnFusionSetParams(plan, intr + 7 * first, wt + 12 * first, bounds6, l.stream)) return fail();
-    tr.mark("setup");
+    }
+    h.tr.mark("sync");
+    // the kernels left the counts in the pinned tables
+    const int nv = l.h_off[h.count], nt = h.with_triangles ? l.h_toff[h.count] : 0;
+    if (l.h_off[h.count + 1] != 0) {
+        (void)lsnFusionCheck(h.plan, l.stream);   // clears the plan's sticky flag
+        lsn::set_error("NativeUtils: the single-pass fusion gave up on a predecessor tile (look-back spin limit)");
+        return -1;
+    }
+    if (nv < 0 || nv > h.cap || nt < 0 || nt > 2 * h.cap) {
+        lsn::set_error("NativeUtils: device returned impossible counts (%d vertices, %d triangles)", nv, nt);
+        return -1;
+    }
+    h.commit(out, nv, nt, false);
+    return 0;
+}
 
-    const char *run_d = radial ? l.d_depth2.as<char>() : l.d_depth.as<char>();
-    const char *run_c = radial ? l.d_colors2.as<char>() : l.d_colors.as<char>();
+// Flow 2: the mesh is built in HBM and asynchronous copies take it home -- the form for calls that start with the radial correction.
+// While a kernel streams to host memory no other kernel completes (file comment), so with several groups the storing launches
+// serialise with everything else; a copy on another stream does not have that problem to the same degree: group g's vertices leave
+// (pinned destination, asynchronous) while group g+1 uploads, is corrected and fused.  What a DMA needs and a storing kernel does not
+// is a LENGTH: the last tile of a group's launch leaves the group's end offset in a pinned word, and the host reads it once the
+// launch's event has fired -- by then it has uploaded the next group, so the wait is short or none.
+int fuse_host_grouped(HostCall &h, Mesh *out)
+{
+    Lane &l = h.l;
+    if (h.begin(true, (int)kMaxGroups)) return -1;   // table: offsets [count + 1], give-up flag, then the groups' end offsets
+    const int count = h.count;
+    int *h_end = l.h_off + count + 2;
     int sent = 0;   // vertices already on their way home
-    // group k's launches have been enqueued: when its event has fired, its vertices (and corrected maps) go home
+    // group k's launches have been enqueued: when its event has fired, its vertices go home
     auto service = [&](size_t k) -> int {
         const Group &g = l.groups[k];
         LSN_HIP(hipEventSynchronize(l.ev_group[k]));
         const int end = h_end[k];
-        if (l.h_off[count + 1] != 0 || end < sent || end > cap) {
+        if (l.h_off[count + 1] != 0 || end < sent || end > h.cap) {
             lsn::set_error("NativeUtils: the fusion of sensors %d..%d failed on the device (end offset %d, flag %d)", g.first, g.first + g.count - 1, end,
                            l.h_off[count + 1]);
             return -1;
         }
         if (end > sent)
-            LSN_HIP(hipMemcpyAsync(static_cast<char *>(host) + (size_t)sent * 16, l.d_out.as<char>() + (size_t)sent * 16, (size_t)(end - sent) * 16,
+            LSN_HIP(hipMemcpyAsync(static_cast<char *>(h.host) + (size_t)sent * 16, l.d_out.as<char>() + (size_t)sent * 16, (size_t)(end - sent) * 16,
                                    hipMemcpyDeviceToHost, l.down));
         sent = end;
-        tr.mark("down");
+        h.tr.mark("down");
         return 0;
     };
     // the corrected maps only start home once every upload and launch of the call has been issued (their copies keep the thread)
     auto write_back = [&](size_t k) -> int {
-        const int rc = write_back_runs(l, k, radial_back_d, radial_back_c);
-        tr.mark("back");
+        const int rc = write_back_runs(l, k, h.back_d, h.back_c);
+        h.tr.mark("back");
         return rc;
     };
-    size_t next_group = 0;
-    for (size_t i = 0; i < l.copies.size(); i++) {
-        const Copy &cp = l.copies[i];
-        char *dst = (cp.colours ? l.d_colors.as<char>() : l.d_depth.as<char>()) + cp.dev_off;
-        const unsigned char *src = (cp.colours ? depth_colors : depth_maps) + cp.src_off;
-        const hipError_t e = G == 1 ? hipMemcpyAsync(dst, src, cp.bytes, hipMemcpyHostToDevice, l.stream)
-                                    : hipMemcpyWithStream(dst, src, cp.bytes, hipMemcpyHostToDevice, l.up);
-        if (e != hipSuccess) {
-            lsn::set_error("NativeUtils: upload failed: %s", hipGetErrorString(e));
-            return fail();
-        }
-        tr.mark(cp.colours ? "upC" : "upD");
-        for (; next_group < G && l.groups[next_group].ready_after == (int)i + 1; next_group++) {
-            const Group &g = l.groups[next_group];
-            if (radial && lsnFusionRadialCorrectTo(g.radial_plan, intr + 7 * g.first, l.d_depth.as<char>() + g.d_off, l.d_colors.as<char>() + g.c_off,
-                                                   l.d_depth2.as<char>() + g.d_off, l.d_colors2.as<char>() + g.c_off, l.stream))
-                return fail();
-            h_end[next_group] = -1;
-            if (lsn::run_frames(plan, run_d, run_c, l.d_out.p, l.d_off.as<int>(), g.first - first, g.first - first + g.count, next_group == 0,
-                                with_triangles, l.h_off, h_end + next_group, false, l.stream) ||
-                hipEventRecord(l.ev_group[next_group], l.stream) != hipSuccess)
-                return fail();
-            tr.mark("launch");
-            if (next_group > 0 && service(next_group - 1)) return fail();   // the group before: done while this one was uploading
-        }
-    }
-    if (with_triangles) {
-        // the triangle passes over the whole tick, behind the last group (they only read what the groups left in HBM)
-        if (lsn::run_triangles(plan, run_d, l.d_tri.p, l.d_tri_off.as<int>(), l.h_toff, false, l.stream) || hipEventRecord(l.ev_tri, l.stream) != hipSuccess)
-            return fail();
-    }
+    if (h.upload([&](size_t k, const Group &g) -> int {
+            h_end[k] = -1;
+            if (h.fuse_group(k, g, l.d_out.p, h_end + k, false) || hipEventRecord(l.ev_group[k], l.stream) != hipSuccess) return -1;
+            return k > 0 ? service(k - 1) : 0;   // the group before: done while this one was uploading
+        }))
+        return -1;
+    // the triangle passes over the whole tick, behind the last group (they only read what the groups left in HBM); ev_tri fires when the
+    // triangle COUNTS are in the pinned table -- behind the scan, before the write pass -- so the block for the triangles is there and
+    // its download queued while the write pass still runs
+    if (h.with_triangles && lsn::run_triangles(h.plan, h.run_d, l.d_tri.p, l.d_tri_off.as<int>(), l.h_toff, false, l.stream, l.ev_tri)) return -1;
     // the corrected maps of all groups but the last (their events fired long ago), the last group's vertices, then the triangles
     // (asynchronous) BEFORE the last group's maps, so that the thread-keeping copies share the link with the triangle download
-    if (back)
-        for (size_t k = 0; k + 1 < G; k++)
-            if (hipEventSynchronize(l.ev_group[k]) != hipSuccess || write_back(k)) return fail();
-    if (service(G - 1)) return fail();
+    if (h.back)
+        for (size_t k = 0; k + 1 < h.G; k++)
+            if (hipEventSynchronize(l.ev_group[k]) != hipSuccess || write_back(k)) return -1;
+    if (service(h.G - 1)) return -1;
     const int nv = sent;
     int nt = 0;
-    if (with_triangles) {
+    if (h.with_triangles) {
         if (hipEventSynchronize(l.ev_tri) != hipSuccess) {
             lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
-            return fail();
+            return -1;
         }
         nt = l.h_toff[count];
-        if (nt < 0 || nt > 2 * cap) {
+        if (nt < 0 || nt > 2 * h.cap) {
             lsn::set_error("NativeUtils: device returned an impossible triangle count %d", nt);
-            return fail();
+            return -1;
         }
         if (nt > 0) {
-            // the triangle write pass is still running: the copy waits for it on the kernels' stream
-            host_tri = pinned_get(c, (size_t)nt * 12);
-            if (!host_tri || hipMemcpyAsync(host_tri, l.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, l.stream) != hipSuccess) {
+            // on the kernels' stream: the copy starts when the triangle write pass, which may still be running, has ended
+            h.host_tri = pinned_get(h.c, (size_t)nt * 12);
+            if (!h.host_tri || hipMemcpyAsync(h.host_tri, l.d_tri.p, (size_t)nt * 12, hipMemcpyDeviceToHost, l.stream) != hipSuccess) {
                 if (!lsn::has_error()) lsn::set_error("NativeUtils: triangle download failed: %s", hipGetErrorString(hipGetLastError()));
-                return fail();
+                return -1;
             }
         }
-        tr.mark("tri");
+        h.tr.mark("tri");
     }
-    if (back && write_back(G - 1)) return fail();
+    if (h.back && write_back(h.G - 1)) return -1;
     if (hipStreamSynchronize(l.down) != hipSuccess || hipStreamSynchronize(l.stream) != hipSuccess) {
         lsn::set_error("NativeUtils: %s", hipGetErrorString(hipGetLastError()));
-        return fail();
+        return -1;
     }
-    tr.mark("sync");
+    h.tr.mark("sync");
     if (nv != l.h_off[count]) {
         lsn::set_error("NativeUtils: the groups' end offsets (%d) and the tick's total (%d) disagree", nv, l.h_off[count]);
-        return fail();
+        return -1;
     }
-    l.last_nv = nv;
-    l.last_nt = nt;
+    h.commit(out, nv, nt, true);
+    return 0;
+}
+
+// ---- flow 3: the call sharded over several devices ($LSN_HOST_DEVICES) ----------------------------------------------------------------
+//
+// One GPU's merge call sits at the floor of ONE PCIe link: 8.7 MB up and 15-43 MB down around ~30 us of kernels.
+// The consumer of the merged cloud is the host (Marshal.Copy, KinectServer.cs:376-389), so the form in which more GPUs buy anything is
+// more LINKS: device d takes the contiguous sensor block d of the tick (the reference's per-sensor fan-out, depthprocessing.cpp:708-733,
+// with a device where it has a thread), uploads it over its own link and stores its vertices and triangles over its own link into
+// the SAME pinned Mesh blocks -- behind the blocks before it, which is formMesh's sensor order (:1594-1608) and its triangle rebase
+// (:1614-1626).  No GPU talks to another one; nothing is gathered.
+// What a device needs from the others is where its vertices START, i.e. the others' counts.  So every device runs the two-pass form
+// here: count pass (depth only -- it runs while the colours are still on their way up) + scan -> the block's count lands in a pinned
+// word -> the worker threads exchange the counts through atomics (each waits only for devices BEFORE it, and nobody waits before it has
+// published: no cycle) -> write pass, storing straight to the host block at the block's base.  The triangles repeat the pattern.
+// One thread per device, because a pageable upload keeps the thread that issues it.
+struct ShardedCall {
+    Ctx &c;
+    const unsigned char *depth_maps, *depth_colors;
+    const int *widths, *heights;
+    const float *intr, *wt, *bounds6;
+    int count = 0, D = 0;
+    bool with_triangles = false, radial = false, back = false;
+    unsigned char *back_d = nullptr, *back_c = nullptr;
+    int first[kMaxShards + 1] = {};                    // device d owns sensors [first[d], first[d + 1])
+    void *host = nullptr, *host_tri = nullptr;
+    std::atomic<int> nv[kMaxShards], nt[kMaxShards];   // -1 = not known yet
+    std::atomic<int> failed{0};
+    std::mutex err_mu;
+    char error[lsn::kErrorLen] = {0};
+
+    explicit ShardedCall(Ctx &c_) : c(c_)
+    {
+        for (int d = 0; d < kMaxShards; d++) {
+            nv[d].store(-1);
+            nt[d].store(-1);
+        }
+    }
+    void fail(const char *what)   // first failure wins; its text reaches the caller's error channel (the worker's own is thread-local)
+    {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!failed.load()) snprintf(error, sizeof(error), "%s", what && *what ? what : "a device's part of the call failed");
+        failed.store(1);
+    }
+    // sum of `counts` of the devices before d, or -1 once somebody has failed
+    long long base_of(const std::atomic<int> *counts, int d)
+    {
+        long long base = 0;
+        for (int e = 0; e < d; e++) {
+            int v;
+            while ((v = counts[e].load(std::memory_order_acquire)) < 0) {
+                if (failed.load()) return -1;
+                std::this_thread::yield();
+            }
+            base += v;
+        }
+        return failed.load() ? -1 : base;
+    }
+};
+
+// How a call of `count` sensors is cut over D devices: contiguous blocks in sensor order, sizes as even as they come.
+void plan_shards(int count, int n_devices, int *first, int &D)
+{
+    D = n_devices < count ? n_devices : count;
+    if (D > kMaxShards) D = kMaxShards;
+    if (D < 1) D = 1;
+    for (int d = 0; d <= D; d++) first[d] = (int)((long long)count * d / D);
+}
+
+// Device d's part of a sharded call; runs on worker d (d = 0: on the calling thread).  Returns 0 or -1 with the thread's error text set.
+int shard_part(ShardedCall &sc, int d)
+{
+    Ctx &c = sc.c;
+    Lane &l = c.shards[d]->lane;
+    LSN_HIP(hipSetDevice(l.device));
+    const int f0 = sc.first[d], n = sc.first[d + 1] - f0;
+    size_t d_src = 0, c_src = 0, dbytes = 0, cbytes = 0;
+    for (int i = 0; i < f0 + n; i++) {
+        const size_t px = (size_t)sc.widths[i] * sc.heights[i];
+        (i < f0 ? d_src : dbytes) += px * 2;
+        (i < f0 ? c_src : cbytes) += px * 3;
+    }
+    l.groups.clear();
+    LsnFusion *plan = get_plan(c, l, sc.widths, sc.heights, f0, n);
+    if (!plan) return -1;
+    const long long cap = lsnFusionTickCapacity(plan);
+    if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_off.reserve(sizeof(int) * (size_t)(n + 1)) ||
+        l.d_tri_off.reserve(sizeof(int) * (size_t)(n + 1)) || ensure_tables(l, n + 2))
+        return -1;
+    if (sc.radial && (l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16))) return -1;
+    if (lsnFusionSetParams(plan, sc.intr + 7 * f0, sc.wt + 12 * f0, sc.bounds6, l.stream)) return -1;
+    const char *run_d = sc.radial ? l.d_depth2.as<char>() : l.d_depth.as<char>();
+    const char *run_c = sc.radial ? l.d_colors2.as<char>() : l.d_colors.as<char>();
+    l.h_off[n] = -1;
+    l.h_toff[n] = -1;
+    hipEvent_t ev_counted = l.ev_group[0], ev_corrected = l.ev_group[1];
+    // depth up; the count pass (depth only) runs while the colours follow -- unless the call starts with the correction, which needs both
+    LSN_HIP(hipMemcpyWithStream(l.d_depth.p, sc.depth_maps + d_src, dbytes, hipMemcpyHostToDevice, l.up));
+    if (!sc.radial && lsn::run_count(plan, run_d, run_c, l.d_off.as<int>(), l.h_off, ev_counted, l.stream)) return -1;
+    LSN_HIP(hipMemcpyWithStream(l.d_colors.p, sc.depth_colors + c_src, cbytes, hipMemcpyHostToDevice, l.up));
+    if (sc.radial) {
+        if (lsnFusionRadialCorrectTo(plan, sc.intr + 7 * f0, l.d_depth.p, l.d_colors.p, l.d_depth2.p, l.d_colors2.p, l.stream)) return -1;
+        LSN_HIP(hipEventRecord(ev_corrected, l.stream));
+        if (lsn::run_count(plan, run_d, run_c, l.d_off.as<int>(), l.h_off, ev_counted, l.stream)) return -1;
+    }
+    LSN_HIP(hipEventSynchronize(ev_counted));
+    const int nv = l.h_off[n];
+    if (nv < 0 || nv > cap) {
+        lsn::set_error("NativeUtils: device %d returned an impossible vertex count %d for sensors %d..%d", l.device, nv, f0, f0 + n - 1);
+        return -1;
+    }
+    sc.nv[d].store(nv, std::memory_order_release);
+    const long long base = sc.base_of(sc.nv, d);
+    if (base < 0) return -1;   // another device failed: its text is the call's
+    if (base + nv > 0x7FFFFFFFll) {
+        lsn::set_error("NativeUtils: the merged cloud exceeds 2^31-1 vertices");
+        return -1;
+    }
+    if (lsn::run_write(plan, run_d, run_c, static_cast<char *>(sc.host) + (size_t)base * 16, l.d_off.as<int>(), sc.with_triangles, true, l.stream)) return -1;
+    if (sc.back) {
+        // the corrected maps of this block go home (pageable destination: the copies keep this thread) while the write pass stores
+        LSN_HIP(hipStreamWaitEvent(l.back, ev_corrected, 0));
+        LSN_HIP(hipMemcpyWithStream(sc.back_d + d_src, l.d_depth2.p, dbytes, hipMemcpyDeviceToHost, l.back));
+        LSN_HIP(hipMemcpyWithStream(sc.back_c + c_src, l.d_colors2.p, cbytes, hipMemcpyDeviceToHost, l.back));
+    }
+    if (sc.with_triangles) {
+        if (lsn::run_triangles_count(plan, run_d, l.d_tri_off.as<int>(), l.h_toff, l.ev_tri, l.stream)) return -1;
+        LSN_HIP(hipEventSynchronize(l.ev_tri));
+        const int nt = l.h_toff[n];
+        if (nt < 0 || nt > 2 * cap) {
+            lsn::set_error("NativeUtils: device %d returned an impossible triangle count %d", l.device, nt);
+            return -1;
+        }
+        sc.nt[d].store(nt, std::memory_order_release);
+        const long long tbase = sc.base_of(sc.nt, d);
+        if (tbase < 0) return -1;
+        if (tbase + nt > 0x7FFFFFFFll / 3) {
+            lsn::set_error("NativeUtils: the merged mesh exceeds the triangle count an int index array can hold");
+            return -1;
+        }
+        if (nt > 0 && lsn::run_triangles_write(plan, run_d, static_cast<char *>(sc.host_tri) + (size_t)tbase * 12, (int)base, true, l.stream)) return -1;
+    } else {
+        sc.nt[d].store(0, std::memory_order_release);
+    }
+    LSN_HIP(hipStreamSynchronize(l.stream));
+    LSN_HIP(hipStreamSynchronize(l.back));
+    return 0;   // (no lsnFusionCheck: the frames both passes read are the lane's own buffers, which nothing else touches under the lock)
+}
+
+void shard_job(void *arg, int d)
+{
+    ShardedCall &sc = *static_cast<ShardedCall *>(arg);
+    int rc = -1;
+    try {
+        lsn::clear_error();
+        rc = shard_part(sc, d);
+    } catch (const std::exception &e) {
+        lsn::set_error("device part %d: %s", d, e.what());
+    } catch (...) {
+        lsn::set_error("device part %d: unknown exception", d);
+    }
+    if (rc) {
+        sc.fail(lsn::error_buffer());
+        // nobody may wait for this device's counts any longer (they see `failed`), and nothing of it may stay in flight
+        drain(sc.c.shards[d]->lane);
+    }
+}
+
+// The merge lane's lock is held (it serialises the calls; the shards' lanes are only ever used under it).
+int fuse_host_sharded(Ctx &c, Lane &ml, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths, const int *heights,
+                      const float *intr, const float *wt, Mesh *out, const float *bounds6, int count, bool with_triangles, bool radial,
+                      unsigned char *radial_back_d, unsigned char *radial_back_c)
+{
+    ml.last_nv = -1;
+    ml.last_plan = nullptr;
+    ml.last_sharded = false;
+    ShardedCall sc(c);
+    sc.depth_maps = depth_maps; sc.depth_colors = depth_colors;
+    sc.widths = widths; sc.heights = heights;
+    sc.intr = intr; sc.wt = wt; sc.bounds6 = bounds6;
+    sc.count = count;
+    sc.with_triangles = with_triangles;
+    sc.radial = radial;
+    sc.back = radial && radial_back_d && radial_back_c;
+    sc.back_d = radial_back_d; sc.back_c = radial_back_c;
+    plan_shards(count, (int)c.shards.size(), sc.first, sc.D);
+    long long cap = 0;
+    for (int i = 0; i < count; i++) cap += (long long)widths[i] * heights[i];
+    if (cap > 0x7FFFFFFFll) {
+        lsn::set_error("NativeUtils: a tick may not exceed 2^31-1 pixels (Mesh.nVertices is an int)");
+        return -1;
+    }
+    struct Blocks {   // the error path, like HostCall's: by the time it runs every worker has finished and drained its lane
+        Ctx &c;
+        void *host = nullptr, *host_tri = nullptr;
+        bool committed = false;
+        explicit Blocks(Ctx &c_) : c(c_) {}
+        ~Blocks()
+        {
+            if (committed) return;
+            if (host) pinned_put(c, host);
+            if (host_tri) pinned_put(c, host_tri);
+        }
+    } blocks(c);
+    blocks.host = pinned_get(c, (size_t)cap * sizeof(VertexC4ubV3f));
+    if (!blocks.host) return -1;
+    if (with_triangles && !(blocks.host_tri = pinned_get(c, (size_t)cap * 2 * 12))) return -1;
+    sc.host = blocks.host;
+    sc.host_tri = blocks.host_tri;
+    struct Join {   // the workers hold pointers into this frame: nothing leaves it before they have finished
+        Ctx &c;
+        int started = 0;
+        explicit Join(Ctx &c_) : c(c_) {}
+        ~Join()
+        {
+            for (int d = 1; d <= started; d++) c.shards[d]->worker.wait();
+        }
+    } join(c);
+    for (int d = 1; d < sc.D; d++) {
+        c.shards[d]->worker.submit(shard_job, &sc, d);
+        join.started = d;
+    }
+    shard_job(&sc, 0);
+    for (int d = 1; d < sc.D; d++) c.shards[d]->worker.wait();
+    join.started = 0;
+    (void)hipSetDevice(c.device);
+    if (sc.failed.load()) {
+        for (int d = 0; d < sc.D; d++) drain(c.shards[d]->lane);   // every device's part has ended; nothing may store into a returned block
+        lsn::set_error("%s", sc.error);
+        return -1;
+    }
+    long long nv = 0, nt = 0;
+    for (int d = 0; d < sc.D; d++) {
+        nv += sc.nv[d].load();
+        nt += sc.nt[d].load();
+    }
+    if (nt == 0 && blocks.host_tri) {
+        pinned_put(c, blocks.host_tri);
+        blocks.host_tri = nullptr;
+    }
+    // what lsnLastMesh* would need to rebuild this mesh on one device (materialize)
+    ml.last_w.assign(widths, widths + count);
+    ml.last_h.assign(heights, heights + count);
+    ml.last_intr.assign(intr, intr + 7 * (size_t)count);
+    ml.last_wt.assign(wt, wt + 12 * (size_t)count);
+    ml.last_bounds.assign(bounds6, bounds6 + 6);
+    ml.last_nv = (int)nv;
+    ml.last_nt = (int)nt;
+    ml.last_in_hbm = false;
+    ml.last_sharded = true;
+    ml.last_radial = radial;
+    ml.last_tri = with_triangles;
+    out->nVertices = (int)nv;
+    out->vertices = static_cast<VertexC4ubV3f *>(blocks.host);
+    out->nTriangles = (int)nt;
+    out->triangles = nt > 0 ? static_cast<int *>(blocks.host_tri) : g_no_triangles;
+    blocks.committed = true;
+    c.last_lane.store(&ml);
+    return 0;
+}
+
+// lsnLastMesh* after a sharded call: the frames the devices fused (corrected, if the call started with the correction) are still in their
+// lanes' buffers; they are gathered onto the merge lane's device, where the whole rig's plan rebuilds the mesh.  Merge lane's lock held.
+int materialize_sharded(Ctx &c, Lane &l)
+{
+    const int count = (int)l.last_w.size();
+    int first[kMaxShards + 1], D = 0;
+    plan_shards(count, (int)c.shards.size(), first, D);
+    LSN_HIP(hipSetDevice(l.device));
+    l.groups.clear();
+    LsnFusion *plan = get_plan(c, l, l.last_w.data(), l.last_h.data(), 0, count);
+    if (!plan) return -1;
+    const long long cap = lsnFusionTickCapacity(plan);
+    if (l.d_depth.reserve((size_t)cap * 2 + 16) || l.d_colors.reserve((size_t)cap * 3 + 16) || l.d_out.reserve((size_t)cap * 16) ||
+        l.d_off.reserve(sizeof(int) * (size_t)(count + 1)) || l.d_tri_off.reserve(sizeof(int) * (size_t)(count + 1)) ||
+        (l.last_tri && l.d_tri.reserve((size_t)cap * 2 * 12)))
+        return -1;
+    if (lsnFusionSetParams(plan, l.last_intr.data(), l.last_wt.data(), l.last_bounds.data(), l.stream)) return -1;
+    size_t d_off = 0, c_off = 0;
+    for (int d = 0; d < D; d++) {
+        Lane &sl = c.shards[d]->lane;
+        size_t px = 0;
+        for (int i = first[d]; i < first[d + 1]; i++) px += (size_t)l.last_w[i] * l.last_h[i];
+        const void *src_d = l.last_radial ? sl.d_depth2.p : sl.d_depth.p, *src_c = l.last_radial ? sl.d_colors2.p : sl.d_colors.p;
+        LSN_HIP(hipMemcpyPeerAsync(l.d_depth.as<char>() + d_off, l.device, src_d, sl.device, px * 2, l.stream));
+        LSN_HIP(hipMemcpyPeerAsync(l.d_colors.as<char>() + c_off, l.device, src_c, sl.device, px * 3, l.stream));
+        d_off += px * 2;
+        c_off += px * 3;
+    }
+    if (l.last_tri ? lsn::run_mesh(plan, l.d_depth.p, l.d_colors.p, l.d_out.p, l.d_off.as<int>(), l.d_tri.p, l.d_tri_off.as<int>(), l.stream, nullptr)
+                   : lsn::run_hooked(plan, l.d_depth.p, l.d_colors.p, l.d_out.p, l.d_off.as<int>(), l.stream, nullptr))
+        return -1;
+    LSN_HIP(hipStreamSynchronize(l.stream));
     l.last_in_hbm = true;
-    l.last_radial = radial;
-    l.last_tri = with_triangles;
-    out->nVertices = nv;
-    out->vertices = static_cast<VertexC4ubV3f *>(host);
-    out->nTriangles = nt;
-    out->triangles = nt > 0 ? static_cast<int *>(host_tri) : g_no_triangles;
-    c.last_lane.store(&l);
-    tr.mark("done");
-    tr.print();
     return 0;
 }
 
@@ -872,6 +1254,7 @@ int fuse_host_grouped(Ctx &c, Lane &l, const unsigned char *depth_maps, const un
 int materialize(Lane &l)
 {
     if (l.last_nv < 0 || l.last_in_hbm) return 0;
+    if (l.last_sharded) return materialize_sharded(ctx(), l);
     LsnFusion *plan = l.last_plan;
     if (!plan) return -1;
     const long long cap = lsnFusionTickCapacity(plan);
@@ -896,11 +1279,13 @@ int fuse_host(Ctx &c, Lane &l, const unsigned char *depth_maps, const unsigned c
               const float *intr, const float *wt, Mesh *out, const float *bounds6, int first, int count, bool with_triangles, bool radial = false,
               unsigned char *radial_back_d = nullptr, unsigned char *radial_back_c = nullptr)
 {
+    // a merge call on a context with several devices ($LSN_HOST_DEVICES), more than one sensor: one sensor block per device and link
+    if (&l == &c.merge && c.shards.size() >= 2 && count >= 2 && first == 0)
+        return fuse_host_sharded(c, l, depth_maps, depth_colors, widths, heights, intr, wt, out, bounds6, count, with_triangles, radial, radial_back_d,
+                                 radial_back_c);
+    HostCall h(c, l, depth_maps, depth_colors, widths, heights, intr, wt, bounds6, first, count, with_triangles, radial, radial_back_d, radial_back_c);
     const bool direct = c.host_path == 1 || (c.host_path == 0 && !radial);
-    return direct ? fuse_host_direct(c, l, depth_maps, depth_colors, widths, heights, intr, wt, out, bounds6, first, count, with_triangles, radial,
-                                     radial_back_d, radial_back_c)
-                  : fuse_host_grouped(c, l, depth_maps, depth_colors, widths, heights, intr, wt, out, bounds6, first, count, with_triangles, radial,
-                                      radial_back_d, radial_back_c);
+    return direct ? fuse_host_direct(h, out) : fuse_host_grouped(h, out);
 }
 
 }  // namespace
@@ -1071,6 +1456,62 @@ extern "C" void depthMapAndColorSetRadialCorrection(int n_maps, unsigned char *d
                                                     int *heights, float *intr_params)
 {
     lsn::guarded_void("depthMapAndColorSetRadialCorrection", [&]() { depthMapAndColorSetRadialCorrection_impl(n_maps, depth_maps, depth_colors, widths, heights, intr_params); });
+}
+
+// Host-only (no device needed): how a merge call over `n_maps` sensors is cut over `n_devices` devices of $LSN_HOST_DEVICES, as text --
+// "0:[0-3] 1:[4-7]": shard:[first-last sensor], blocks contiguous and in sensor order (the order their vertices take in the Mesh) -- and,
+// when first_out is given, the block bounds themselves (n_devices + 1 ints are enough).  Returns the number of shards used
+// (min(n_devices, n_maps), at most 16), -1 on bad arguments.  n_devices = 0: the devices this process was configured with.
+static int lsnHostShardDescribe_impl(int n_maps, int n_devices, int *first_out, char *buf, int len)
+{
+    lsn::clear_error();
+    if (n_devices == 0) {
+        std::vector<int> devs;
+        const char *e = getenv("LSN_HOST_DEVICES");
+        if (e && parse_device_list(e, 1 << 30, devs)) return -1;
+        n_devices = devs.size() >= 2 ? (int)devs.size() : 1;
+    }
+    if (n_maps <= 0 || n_devices < 0) {
+        lsn::set_error("lsnHostShardDescribe: bad arguments");
+        return -1;
+    }
+    int first[kMaxShards + 1], D = 0;
+    plan_shards(n_maps, n_devices, first, D);
+    std::string out;
+    for (int d = 0; d < D; d++) {
+        char item[64];
+        if (first[d + 1] - first[d] == 1) snprintf(item, sizeof(item), "%s%d:[%d]", d ? " " : "", d, first[d]);
+        else snprintf(item, sizeof(item), "%s%d:[%d-%d]", d ? " " : "", d, first[d], first[d + 1] - 1);
+        out += item;
+    }
+    if (buf && len > 0) snprintf(buf, (size_t)len, "%s", out.c_str());
+    if (first_out)
+        for (int d = 0; d <= D; d++) first_out[d] = first[d];
+    return D;
+}
+
+extern "C" int lsnHostShardDescribe(int n_maps, int n_devices, int *first_out, char *buf, int len)
+{
+    return lsn::guarded<int>("lsnHostShardDescribe", static_cast<int>(-1), [&]() { return lsnHostShardDescribe_impl(n_maps, n_devices, first_out, buf, len); });
+}
+
+// Test hooks (tests/test_abi.py): how many fault points of a kind (0 = guarded entries, 1 = device / pinned allocations) the process has
+// passed -- so that a test can aim $LSN_TEST_FAIL_ALLOC at one particular allocation of one particular call -- and what the pool of
+// pinned mesh blocks holds: blocks out with callers (or leaked), blocks waiting for reuse, bytes out.
+extern "C" long long lsnTestFaultPoints(int kind) { return lsn::test_fault_points(kind); }
+
+extern "C" int lsnHostPoolStats(int *live_blocks, int *pooled_blocks, long long *live_bytes)
+{
+    return lsn::guarded<int>("lsnHostPoolStats", static_cast<int>(-1), [&]() {
+        Ctx &c = ctx();
+        std::lock_guard<std::mutex> tg(c.tab_mu);
+        long long bytes = 0;
+        for (const auto &kv : c.live) bytes += (long long)kv.second;
+        if (live_blocks) *live_blocks = (int)c.live.size();
+        if (pooled_blocks) *pooled_blocks = (int)c.pool.size();
+        if (live_bytes) *live_bytes = bytes;
+        return 0;
+    });
 }
 
 // Host-only (no device needed): the upload schedule a call with these frames would follow, as text -- "D[0-2] C[0-2] | D[3-7] C[3-5] |

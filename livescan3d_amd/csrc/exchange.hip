@@ -553,6 +553,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // optional: what the communicator itself reports (lsnShardRanksSeen)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     std::string path;   // the file the entry points came from
 };
 
@@ -607,6 +609,8 @@ Rccl *rccl()
     t->GroupStart = (decltype(t->GroupStart))dlsym(lib, "ncclGroupStart");
     t->GroupEnd = (decltype(t->GroupEnd))dlsym(lib, "ncclGroupEnd");
     t->GetErrorString = (decltype(t->GetErrorString))dlsym(lib, "ncclGetErrorString");
+    t->CommCount = (decltype(t->CommCount))dlsym(lib, "ncclCommCount");
+    t->CommUserRank = (decltype(t->CommUserRank))dlsym(lib, "ncclCommUserRank");
     if (!t->GetUniqueId || !t->CommInitRank || !t->CommDestroy || !t->AllGather || !t->GroupStart || !t->GroupEnd || !t->GetErrorString) {
         lsn::set_error("lsnShard: librccl.so.1 lacks an expected entry point");
         delete t;
@@ -855,6 +859,33 @@ static int lsnShardRcclPath_impl(char *buf, int len)
 extern "C" int lsnShardRcclPath(char *buf, int len)
 {
     return lsn::guarded<int>("lsnShardRcclPath", static_cast<int>(-1), [&]() { return lsnShardRcclPath_impl(buf, len); });
+}
+
+// What the connected communicator itself reports: its rank count, or -1 (not connected / the RCCL in use lacks ncclCommCount / the
+// communicator's own rank differs from the handle's).  bench.py puts it into the N > 1 line as n_ranks_seen.
+static int lsnShardRanksSeen_impl(LsnShard *sh)
+{
+    lsn::clear_error();
+    Rccl *r = rccl();
+    if (!sh || !r) return -1;
+    std::lock_guard<std::mutex> g(sh->mu);
+    if (!sh->comm || !r->CommCount) {
+        lsn::set_error("lsnShardRanksSeen: %s", !sh->comm ? "the handle is not connected" : "this RCCL has no ncclCommCount");
+        return -1;
+    }
+    int n = -1, me = sh->rank;
+    LSN_NCCL(r->CommCount(sh->comm, &n));
+    if (r->CommUserRank) LSN_NCCL(r->CommUserRank(sh->comm, &me));
+    if (me != sh->rank) {
+        lsn::set_error("lsnShardRanksSeen: the communicator says rank %d, the handle %d", me, sh->rank);
+        return -1;
+    }
+    return n;
+}
+
+extern "C" int lsnShardRanksSeen(LsnShard *sh)
+{
+    return lsn::guarded<int>("lsnShardRanksSeen", static_cast<int>(-1), [&]() { return lsnShardRanksSeen_impl(sh); });
 }
 
 extern "C" LsnFusion *lsnShardPlan(LsnShard *sh, int whole) { return sh ? (whole ? sh->whole : sh->local) : nullptr; }

@@ -299,7 +299,10 @@ __device__ __forceinline__ int tile_lookback(const FuseArgs &a, int tick, int ti
 // LAZY (write pass only): the colours are loaded after the keep predicates are known, by the lanes that kept a pixel --
 // spatially coherent frames (real scenes: background beyond the crop box, invalid regions) then never fetch the colour
 // lines of rejected areas; the price is that the colour load no longer flies together with the depth load.
-template <int MODE, bool VEC, bool LAZY = false>
+// HOST (write pass of the two-pass form only): `out` is pinned host memory -- plain, destination-aligned stores (stage_and_store's note).  A
+// template parameter and not a run-time flag, so that the device-resident instantiations keep their code (and their streaming stores: a
+// run-time choice between a streaming and a plain store is folded into one plain store, mesh.hip); mode 4 has the run-time a.host_out.
+template <int MODE, bool VEC, bool LAZY = false, bool HOST = false>
 __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
 {
     constexpr bool kWrite = MODE != 0;
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
             }
         }
     }
-    stage_and_store(stage, keep, vert, wave_off + below, tile_tot, a.out + tick * a.tick_vert_stride + base, MODE == 4 && a.host_out != 0);
+    stage_and_store(stage, keep, vert, wave_off + below, tile_tot, a.out + tick * a.tick_vert_stride + base, HOST || (MODE == 4 && a.host_out != 0));
 }
 
 // ---- mode 1: one launch, runs of tiles with a decoupled look-back per run ---------------------------------------
@@ -1233,6 +1236,69 @@ int lsn::run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, voi
     a.group_end_mirror = group_end_mirror;
     a.host_out = host_out ? 1 : 0;
     launch<4>(vec, p->tile_start[f1] - p->tile_start[f0], s, a, p->lazy_rgb);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+// The two halves of the two-pass form of a ONE-TICK plan, for a caller that has to know the tick's vertex count before it can say where
+// the vertices go: the sensor blocks of a call sharded over several devices (abi.hip) -- device d's vertices start where the devices
+// before it end, inside ONE pinned host block.  run_count: count pass (depth only: it can run while the colours are still on their
+// way up) + scan, the offset table also stored to `offsets_mirror` (pinned), `counted` recorded behind it.  run_write: the write pass
+// at the scanned offsets, vertices to `vertices` -- pinned host memory when host_out (plain, destination-aligned stores).  The two
+// calls must see the same buffers (d_colors decides the wide-load form in both); the plan's prefixes link them, so nothing else may
+// run on the plan in between (the lane's lock).
+int lsn::run_count(LsnFusion *p, const void *d_depth, const void *d_colors, int *d_offsets, int *offsets_mirror, hipEvent_t counted, hipStream_t s)
+{
+    if (!p || !d_depth || !d_colors || !d_offsets || p->n_ticks != 1) {
+        lsn::set_error("run_count: bad arguments");
+        return -1;
+    }
+    if (!p->params_set) {
+        lsn::set_error("run_count: lsnFusionSetParams has not been called");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    if (ensure_thresholds(p, s)) return -1;
+    FuseArgs a;
+    fill_args(p, a, d_depth, d_colors, nullptr, d_offsets);
+    const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && (p->tick_depth_elems % 8) == 0;
+    launch_count(p, vec, s, a);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, s, a.tile_counts, a.tiles_per_tick, a.frames, a.n_frames, a.offsets, offsets_mirror);
+    LSN_HIP(hipGetLastError());
+    if (counted) LSN_HIP(hipEventRecord(counted, s));
+    return 0;
+}
+
+int lsn::run_write(LsnFusion *p, const void *d_depth, const void *d_colors, void *vertices, int *d_offsets, bool with_pixmap, bool host_out, hipStream_t s)
+{
+    if (!p || !d_depth || !d_colors || !vertices || !d_offsets || p->n_ticks != 1 || ((uintptr_t)vertices & 15) != 0) {
+        lsn::set_error("run_write: bad arguments");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    const bool vec = p->vec_ok && ((uintptr_t)d_depth & 15) == 0 && ((uintptr_t)d_colors & 7) == 0 && (p->tick_depth_elems % 8) == 0;
+    if (with_pixmap) {
+        if (vec ? (p->pm_first.reserve(sizeof(int) * ((size_t)p->cap / 8 + 2)) || p->pm_mask.reserve((size_t)p->cap / 8 + 2))
+                : p->pixmap.reserve(sizeof(int) * (size_t)p->cap))
+            return -1;
+        p->pixmap_compact = vec;
+    }
+    struct PixmapScope {
+        LsnFusion *p;
+        PixmapScope(LsnFusion *q, bool on) : p(q) { p->want_pixmap = on; }
+        ~PixmapScope() { p->want_pixmap = false; }
+    } scope(p, with_pixmap);
+    FuseArgs a;
+    fill_args(p, a, d_depth, d_colors, vertices, d_offsets);
+    const int grid = p->tiles_per_tick;
+    if (host_out) {
+        if (vec) hipLaunchKernelGGL((fuse_kernel<1, true, true, true>), dim3(grid), dim3(kThreads), 0, s, a);
+        else     hipLaunchKernelGGL((fuse_kernel<1, false, true, true>), dim3(grid), dim3(kThreads), 0, s, a);
+    } else {
+        launch<1>(vec, grid, s, a, p->lazy_rgb);
+    }
     LSN_HIP(hipGetLastError());
     return 0;
 }

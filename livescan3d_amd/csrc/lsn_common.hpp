@@ -22,6 +22,7 @@ char *error_buffer() noexcept;                         // fixed thread-local sto
 void set_error(const char *fmt, ...) noexcept;
 inline void clear_error() noexcept { error_buffer()[0] = 0; }
 inline bool has_error() noexcept { return error_buffer()[0] != 0; }
+long test_fault_points(int kind);                      // how many fault points of that kind the process has passed
 void test_fault_point(int kind);                       // 0 = guarded entry, 1 = allocation; throws std::bad_alloc when a test asks for it
 
 // Every extern "C" entry point runs its body through this: no exception may cross the C-ABI into a P/Invoke frame
@@ -119,10 +120,20 @@ int run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_ve
              hipStream_t s, const RunHooks *hooks);
 
 // One launch, single pass, over frames [f0, f1) of a one-tick plan (fusion.hip); and the triangle passes alone over the whole tick, for
-// a pixel -> vertex map that run_frames(with_pixmap) launches have filled (mesh.hip).  tri_mirror: optional pinned copy of the table.
+// a pixel -> vertex map that run_frames(with_pixmap) launches have filled (mesh.hip).  tri_mirror: optional pinned copy of the table;
+// tri_counted: optional event recorded behind the scan (the counts are in the mirror), before the triangle write pass.
 int run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_vertices, int *d_offsets, int f0, int f1, bool first_of_tick,
                bool with_pixmap, int *offsets_mirror, int *group_end_mirror, bool host_out, hipStream_t s);
-int run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, bool host_out, hipStream_t s);
+int run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, bool host_out, hipStream_t s,
+                  hipEvent_t tri_counted = nullptr);
+
+// The two halves of the two-pass form of a one-tick plan (fusion.hip) and of its triangle passes (mesh.hip), for a caller that places
+// the tick's vertices / triangles behind somebody else's: abi.hip's calls sharded over devices.  index_base: added to every vertex index a
+// triangle names (formMesh's rebase, depthprocessing.cpp:1614-1626, across devices).
+int run_count(LsnFusion *p, const void *d_depth, const void *d_colors, int *d_offsets, int *offsets_mirror, hipEvent_t counted, hipStream_t s);
+int run_write(LsnFusion *p, const void *d_depth, const void *d_colors, void *vertices, int *d_offsets, bool with_pixmap, bool host_out, hipStream_t s);
+int run_triangles_count(LsnFusion *p, const void *d_depth, int *d_tri_offsets, int *tri_mirror, hipEvent_t tri_counted, hipStream_t s);
+int run_triangles_write(LsnFusion *p, const void *d_depth, void *d_triangles, int index_base, bool host_out, hipStream_t s);
 
 // The survivor exchange's two ends with the back-to-back stream layout (exchange.hip; see their definitions).
 int pack_survivors(LsnFusion *p, const void *d_depth, const void *d_colors, void *d_mask, void *d_depth_c, void *d_rgb_c, int *d_tile_prefix,

@@ -26,6 +26,8 @@ struct TriArgs {
     int tiles_per_tick;
     int win;                    // triangles staged per LDS round of the write pass
     int host_out;               // `tri` is pinned host memory: the launch picks the HOST form of the write pass
+    int index_base;             // added to every vertex index a triangle names: the tick's vertices start there in the caller's cloud (a call
+                                // sharded over devices, abi.hip: formMesh's rebase across devices); 0 everywhere else
     long long tick_pix_stride;  // pixels per tick
     long long tick_tri_stride;  // triangles per tick (capacity)
 };
@@ -227,13 +229,13 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 // a pixel without a vertex gets the index of the next one: never read, its triangles are not in `code` (:133-134)
-                int run = first[r];
+                int run = first[r] + a.index_base;
 #pragma unroll
                 for (int c = 0; c < kPxPerLane; c++) {
                     M[r][c] = run;
                     run += (int)((mask9[r] >> c) & 1u);
                 }
-                M[r][8] = first_next[r];
+                M[r][8] = first_next[r] + a.index_base;
             }
         }
     } else if (VEC) {
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
                     const unsigned int m = (code >> (4 * k)) & 15u;
                     if (m) {
                         const long long p = (long long)y * w + x;
-                        const int mP = map[p], mU = map[p - w], mUR = map[p - w + 1], mR = map[p + 1];
+                        // (every index a code bit names exists, :133-134: no -1 is rebased)
+                        const int mP = map[p] + a.index_base, mU = map[p - w] + a.index_base, mUR = map[p - w + 1] + a.index_base, mR = map[p + 1] + a.index_base;
                         const bool b0 = (m & 1u) != 0, b12 = (m & 6u) != 0, low = (m & 3u) != 0;
                         if ((unsigned int)r < (unsigned int)kTriWin) {
                             const int o = stage_slot(lead, r);
@@ -405,10 +408,9 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
 
 }  // namespace
 
-// The triangle passes of a tick whose pixel -> vertex map is filled (count -> scan -> write); p->mu held.
-static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, hipStream_t s, const lsn::RunHooks *hooks)
+// The triangle passes of a tick whose pixel -> vertex map is filled, in two halves (count -> scan | write); p->mu held.
+static bool tri_args(LsnFusion *p, const void *d_depth, void *d_triangles, TriArgs &t)
 {
-    TriArgs t;
     t.frames = p->frames.as<FrameDesc>();
     t.tiles = p->tile_frame.as<TileDesc>();
     t.depth = static_cast<const unsigned short *>(d_depth);
@@ -421,11 +423,17 @@ static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles,
     t.tiles_per_tick = p->tiles_per_tick;
     static const int win_env = getenv("LSN_TRI_WINDOW") ? atoi(getenv("LSN_TRI_WINDOW")) : kTriWinDefault;
     t.win = std::min(4096, std::max(256, win_env)) & ~15;
-    const size_t stage_bytes = sizeof(int) * (size_t)(stage_ints(t.win) + 3 * 64);
-    t.host_out = hooks && hooks->host_out;
+    t.host_out = 0;
+    t.index_base = 0;
     t.tick_pix_stride = p->cap;
     t.tick_tri_stride = 2 * p->cap;
-    const bool vec = p->pixmap_compact && ((uintptr_t)d_depth & 15) == 0;   // the vertex pass above wrote the compact map iff it ran its wide-load form
+    return p->pixmap_compact && ((uintptr_t)d_depth & 15) == 0;   // the vertex pass wrote the compact map iff it ran its wide-load form
+}
+
+static int triangle_count_passes(LsnFusion *p, const void *d_depth, int *d_tri_offsets, hipStream_t s, const lsn::RunHooks *hooks)
+{
+    TriArgs t;
+    const bool vec = tri_args(p, d_depth, nullptr, t);
     const int grid = p->tiles_per_tick * p->n_ticks;
     if (vec) hipLaunchKernelGGL((tri_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, t);
     else     hipLaunchKernelGGL((tri_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, t);
@@ -435,7 +443,19 @@ static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles,
     if (hooks && hooks->h_tri_offsets && !mirror)
         LSN_HIP(hipMemcpyAsync(hooks->h_tri_offsets, d_tri_offsets, sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1), hipMemcpyDeviceToHost, s));
     if (hooks && hooks->tri_counted) LSN_HIP(hipEventRecord(hooks->tri_counted, s));
-    if (t.host_out) {
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int triangle_write_pass(LsnFusion *p, const void *d_depth, void *d_triangles, int index_base, bool host_out, hipStream_t s)
+{
+    TriArgs t;
+    const bool vec = tri_args(p, d_depth, d_triangles, t);
+    t.host_out = host_out;
+    t.index_base = index_base;
+    const size_t stage_bytes = sizeof(int) * (size_t)(stage_ints(t.win) + 3 * 64);
+    const int grid = p->tiles_per_tick * p->n_ticks;
+    if (host_out) {
         if (vec) hipLaunchKernelGGL((tri_kernel<1, true, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
         else     hipLaunchKernelGGL((tri_kernel<1, false, true>), dim3(grid), dim3(kThreads), stage_bytes, s, t);
     } else {
@@ -444,6 +464,12 @@ static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles,
     }
     LSN_HIP(hipGetLastError());
     return 0;
+}
+
+static int triangle_passes(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, hipStream_t s, const lsn::RunHooks *hooks)
+{
+    if (triangle_count_passes(p, d_depth, d_tri_offsets, s, hooks)) return -1;
+    return triangle_write_pass(p, d_depth, d_triangles, 0, hooks && hooks->host_out, s);
 }
 
 extern "C" long long lsnFusionTickTriangleCapacity(const LsnFusion *p) { return p ? 2 * p->cap : 0; }
@@ -485,7 +511,8 @@ int lsn::run_mesh(LsnFusion *p, const void *d_depth, const void *d_colors, void 
     return triangle_passes(p, d_depth, d_triangles, d_tri_offsets, s, hooks);
 }
 
-int lsn::run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, bool host_out, hipStream_t s)
+int lsn::run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_tri_offsets, int *tri_mirror, bool host_out, hipStream_t s,
+                       hipEvent_t tri_counted)
 {
     if (!p || !d_depth || !d_triangles || !d_tri_offsets) {
         lsn::set_error("run_triangles: null argument");
@@ -500,6 +527,38 @@ int lsn::run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int
     hooks.mirror = tri_mirror != nullptr;
     hooks.host_out = host_out;
     hooks.h_tri_offsets = tri_mirror;
+    hooks.tri_counted = tri_counted;
     return triangle_passes(p, d_depth, d_triangles, d_tri_offsets, s, &hooks);
 }
 
+
+// The same in two calls, for a caller that has to know the tick's triangle count before it can say where the triangles go (abi.hip: the
+// sensor blocks of a call sharded over devices).  Nothing else may run on the plan in between (the lane's lock).
+int lsn::run_triangles_count(LsnFusion *p, const void *d_depth, int *d_tri_offsets, int *tri_mirror, hipEvent_t tri_counted, hipStream_t s)
+{
+    if (!p || !d_depth || !d_tri_offsets) {
+        lsn::set_error("run_triangles_count: null argument");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    if (p->tri_counts.reserve(sizeof(int) * (size_t)p->tiles_per_tick * p->n_ticks) ||
+        p->tri_codes.reserve(sizeof(unsigned int) * (size_t)p->tiles_per_tick * p->n_ticks * kThreads))
+        return -1;
+    lsn::RunHooks hooks;
+    hooks.mirror = tri_mirror != nullptr;
+    hooks.h_tri_offsets = tri_mirror;
+    hooks.tri_counted = tri_counted;
+    return triangle_count_passes(p, d_depth, d_tri_offsets, s, &hooks);
+}
+
+int lsn::run_triangles_write(LsnFusion *p, const void *d_depth, void *d_triangles, int index_base, bool host_out, hipStream_t s)
+{
+    if (!p || !d_depth || !d_triangles) {
+        lsn::set_error("run_triangles_write: null argument");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    return triangle_write_pass(p, d_depth, d_triangles, index_base, host_out, s);
+}

@@ -21,12 +21,12 @@ VERTEX_DTYPE = np.dtype([("R", "u1"), ("G", "u1"), ("B", "u1"), ("A", "u1"),
 # every symbol include/NativeUtils.h declares
 EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
-    "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh", "lsnHostScheduleDescribe",
+    "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh", "lsnHostScheduleDescribe", "lsnHostShardDescribe", "lsnTestFaultPoints", "lsnHostPoolStats",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnPackSensorParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
     "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
-    "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardPrepare", "lsnShardConnect", "lsnShardRcclPath", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent",
+    "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardPrepare", "lsnShardConnect", "lsnShardRcclPath", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent", "lsnShardRanksSeen",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnTransferLastPath", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
@@ -107,6 +107,12 @@ def lib():
     L.lsnFusionSetParams.argtypes = [vp, vp, vp, vp, vp]
     L.lsnPackSensorParams.restype = C.c_int
     L.lsnPackSensorParams.argtypes = [vp, vp, vp]
+    L.lsnHostShardDescribe.restype = C.c_int
+    L.lsnHostShardDescribe.argtypes = [C.c_int, C.c_int, vp, C.c_char_p, C.c_int]
+    L.lsnTestFaultPoints.restype = C.c_longlong
+    L.lsnTestFaultPoints.argtypes = [C.c_int]
+    L.lsnHostPoolStats.restype = C.c_int
+    L.lsnHostPoolStats.argtypes = [vp, vp, vp]
     L.lsnHostScheduleDescribe.restype = C.c_int
     L.lsnHostScheduleDescribe.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.lsnFusionSetMode.restype = C.c_int
@@ -185,6 +191,8 @@ def lib():
     L.lsnShardMergedCapacity.argtypes = [vp]
     L.lsnShardLastBytesSent.restype = C.c_longlong
     L.lsnShardLastBytesSent.argtypes = [vp]
+    L.lsnShardRanksSeen.restype = C.c_int
+    L.lsnShardRanksSeen.argtypes = [vp]
     L.lsnShardSetParams.restype = C.c_int
     L.lsnShardSetParams.argtypes = [vp, vp, vp, vp, vp]
     L.lsnShardStep.restype = C.c_int
@@ -298,6 +306,24 @@ def generate_mesh_from_depth_maps(depth_maps, depth_colors, widths, heights, int
         lib().deleteMesh(C.byref(mesh))
         raise NativeUtilsError(err)
     return _copy_mesh(mesh)
+
+
+def host_shards(n_maps, n_devices=0):
+    """How a merge call over n_maps sensors is cut over n_devices devices of $LSN_HOST_DEVICES (lsnHostShardDescribe; needs no GPU).
+    Returns (block bounds [first_0, ..., first_D], text such as "0:[0-3] 1:[4-7]")."""
+    buf = C.create_string_buffer(1024)
+    first = (C.c_int * 18)()
+    d = lib().lsnHostShardDescribe(int(n_maps), int(n_devices), first, buf, len(buf))
+    if d < 0:
+        raise NativeUtilsError(last_error())
+    return [int(first[i]) for i in range(d + 1)], buf.value.decode()
+
+
+def host_pool_stats():
+    """(blocks out with callers, blocks waiting for reuse, bytes out) of the pool of pinned mesh blocks (lsnHostPoolStats)."""
+    live, pooled, nbytes = C.c_int(0), C.c_int(0), C.c_longlong(0)
+    _check(lib().lsnHostPoolStats(C.byref(live), C.byref(pooled), C.byref(nbytes)), "lsnHostPoolStats")
+    return live.value, pooled.value, nbytes.value
 
 
 def host_schedule(widths, heights, first=0, count=None, radial=False, sensors_per_group=0):
@@ -578,6 +604,10 @@ class Shard:
 
     def last_bytes_sent(self):
         return int(lib().lsnShardLastBytesSent(self._h))
+
+    def ranks_seen(self):
+        """The rank count the connected communicator itself reports (ncclCommCount); -1 if it cannot say."""
+        return int(lib().lsnShardRanksSeen(self._h))
 
     def plan(self, whole=True):
         """A non-owning FusionPlan view of one of the handle's plans (profile / kernel_stats / check only)."""

@@ -1,4 +1,4 @@
-// fake_rccl.cpp -- TEST DOUBLE, not a product path.  The seven nccl* entry points lsnShard* binds (exchange.hip: struct Rccl),
+// fake_rccl.cpp -- TEST DOUBLE, not a product path.  The nccl* entry points lsnShard* binds (exchange.hip: struct Rccl),
 // implemented for ranks that are processes on ONE host sharing ONE GPU: every all-gather is staged through a POSIX
 // shared-memory segment (device -> shm slot of the rank, barrier, every slot -> device).  RCCL refuses two ranks on one
 // device, so this is the only way the world > 1 code of lsnShardStep (rank offsets, the grouped collectives, the chunked
@@ -139,6 +139,20 @@ extern "C" ncclResult_t ncclCommDestroy(ncclComm_t c)
     if (c->hdr->attached.fetch_sub(1) == 1) shm_unlink(c->name);  // the last rank out removes the segment
     munmap(c->hdr, c->map_bytes);
     delete c;
+    return ncclSuccess;
+}
+
+extern "C" ncclResult_t ncclCommCount(const ncclComm_t c, int *count)
+{
+    if (!c || !count) return ncclInvalidArgument;
+    *count = c->hdr->attached.load();     // the ranks attached to the segment right now, not the number this rank was told
+    return ncclSuccess;
+}
+
+extern "C" ncclResult_t ncclCommUserRank(const ncclComm_t c, int *rank)
+{
+    if (!c || !rank) return ncclInvalidArgument;
+    *rank = c->rank;
     return ncclSuccess;
 }
 

@@ -294,6 +294,52 @@ def test_a_failed_allocation_leaves_an_empty_mesh_and_the_next_call_works(gpu, o
     assert got[-1] == want
 
 
+_LATE_ALLOC_SCRIPT = r"""
+import ctypes as C, hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from livescan3d_amd import native, synth
+rig = synth.make_rig("scene", 8, 256, 212, seed=43, bounds=synth.CROP_BOUNDS)
+L = native.lib()
+rows = []
+for _ in range(5):
+    before = int(L.lsnTestFaultPoints(1))
+    try:
+        if {flow!r} == "tick":
+            v, t, _, _ = native.correct_and_generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        else:
+            v, t = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        row = [len(v), len(t), hashlib.sha256(v.tobytes() + t.tobytes()).hexdigest(), ""]
+    except native.NativeUtilsError as ex:
+        row = [0, 0, "", str(ex)]
+    rows.append(row + [before, int(L.lsnTestFaultPoints(1))] + list(native.host_pool_stats()))
+print(json.dumps(rows))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flow", ["tick", "merge"])
+def test_an_allocation_that_fails_behind_the_launches_returns_every_block(gpu, flow):
+    """A steady-state call allocates nothing but the mesh's pinned blocks -- and in the copy-engine flow (the tick as one call) the triangle
+    block is taken AFTER every kernel and vertex copy of the call has been queued.  Each allocation of the third call is made to throw in
+    turn: the call must end in an empty mesh with nothing in flight, the pool must hold no block out (a block the failed call kept would
+    show as `live`), and the calls after it return the same mesh as before.  (The wrappers copy the mesh and call deleteMesh, so between
+    calls nothing is out.)"""
+    clean = _run_with_env(_LATE_ALLOC_SCRIPT.format(root=ROOT, flow=flow), LSN_TEST_FAIL_ALLOC="0")
+    want = clean[0][:4]
+    assert want[0] > 1000 and want[1] > 1000 and not want[3]
+    assert all(r[:4] == want and r[6] == 0 for r in clean), clean          # live blocks == 0 after every clean call
+    first, last = clean[2][4] + 1, clean[2][5]                             # the fault points the third call passes
+    assert last - first + 1 >= 2, clean                                     # at least the vertex and the triangle block
+    for nth in range(first, last + 1):
+        got = _run_with_env(_LATE_ALLOC_SCRIPT.format(root=ROOT, flow=flow), LSN_TEST_FAIL_ALLOC=str(nth))
+        assert [r[:4] for r in got[:2]] == [want, want], (nth, got)
+        assert got[2][0] == 0 and "bad_alloc" in got[2][3], (nth, got)
+        assert [r[:4] for r in got[3:]] == [want, want], (nth, got)
+        assert all(r[6] == 0 for r in got), (nth, got)                      # nothing left out -- after the failed call either
+        assert got[4][7] <= clean[4][7] + 1, (nth, got)                     # and the pool did not grow past its steady state
+
+
 # ---- the upload schedule of the host exports: pure host logic, testable without a GPU ------------------------------------------------
 
 def _parse_schedule(text):
@@ -395,3 +441,52 @@ def test_every_export_survives_null_and_zero_arguments():
     lines = r.stdout.strip().splitlines()
     assert r.returncode == 0 and lines and lines[-1].startswith("ALL"), f"crashed in {lines[-1] if lines else '?'} (rc {r.returncode})\n{r.stderr[-1500:]}"
     assert int(lines[-1].split()[1]) == len(native.EXPORTS)
+
+
+# ---- merge calls sharded over the devices of $LSN_HOST_DEVICES: the split is pure host logic -------------------------------------------
+
+def test_host_shard_split_known_cases():
+    H = native.host_shards
+    assert H(8, 2) == ([0, 4, 8], "0:[0-3] 1:[4-7]")                        # BASELINE configs[2]'s rig on two devices
+    assert H(8, 8) == ([0, 1, 2, 3, 4, 5, 6, 7, 8], " ".join(f"{d}:[{d}]" for d in range(8)))   # configs[3]: one sensor per device
+    assert H(16, 8)[0] == list(range(0, 17, 2))                              # configs[4]: two per device
+    assert H(3, 8) == ([0, 1, 2, 3], "0:[0] 1:[1] 2:[2]")                     # more devices than sensors: the spare ones stay idle
+    assert H(8, 3) == ([0, 2, 5, 8], "0:[0-1] 1:[2-4] 2:[5-7]")
+    assert H(5, 1) == ([0, 5], "0:[0-4]")
+    with pytest.raises(native.NativeUtilsError):
+        H(0, 2)
+
+
+def test_host_shard_split_properties():
+    """For every sensor count and device count: the blocks are contiguous, in sensor order (= the order their vertices take in the Mesh:
+    formMesh concatenates the sensors in index order, depthprocessing.cpp:1594-1608), cover every sensor once, none is empty, and their
+    sizes differ by at most one; and the vertex / triangle bases the devices derive from each other's counts are the exclusive prefix sums
+    in that order (restated here on random counts: what ShardedCall::base_of computes)."""
+    rng = np.random.default_rng(11)
+    for n in list(range(1, 40)) + [64, 100]:
+        for dev in range(1, 20):
+            first, text = native.host_shards(n, dev)
+            D = len(first) - 1
+            assert D == min(dev, n, 16) and first[0] == 0 and first[-1] == n
+            sizes = np.diff(first)
+            assert (sizes >= 1).all() and sizes.max() - sizes.min() <= 1
+            assert len(text.split()) == D
+            counts = rng.integers(0, 217088, size=n)
+            per_dev = [int(counts[first[d]:first[d + 1]].sum()) for d in range(D)]
+            bases = [sum(per_dev[:d]) for d in range(D)]
+            for d in range(D):   # device d's first vertex = the vertices of every sensor before its block
+                assert bases[d] == int(counts[:first[d]].sum())
+
+
+def test_host_devices_environment_is_validated(tmp_path):
+    """A device list that names a device the machine does not have (here: none at all, or one beyond the count) must end in an error text,
+    not in a crash or a silent one-device run."""
+    script = (f"import sys; sys.path.insert(0, {ROOT!r}); from livescan3d_amd import native\n"
+              "print(native.host_shards(8, 0))\n")
+    import subprocess, sys as _sys
+    e = dict(os.environ, LSN_HOST_DEVICES="0,0,0")
+    r = subprocess.run([_sys.executable, "-c", script], capture_output=True, text=True, env=e, timeout=120)
+    assert r.returncode == 0 and "0:[0-1] 1:[2-4] 2:[5-7]" in r.stdout, r.stderr[-1000:]
+    e = dict(os.environ, LSN_HOST_DEVICES="0,x")
+    r = subprocess.run([_sys.executable, "-c", script], capture_output=True, text=True, env=e, timeout=120)
+    assert r.returncode != 0 and "LSN_HOST_DEVICES" in r.stderr

@@ -489,11 +489,14 @@ _FLOW_CASES = [("two_groups", "scene", 3, 512, 424),      # D[0-2] C[0-1] | C[2]
 
 
 @pytest.mark.parametrize("env", [{}, {"LSN_HOST_PATH": "direct"}, {"LSN_HOST_PATH": "grouped"}, {"LSN_HOST_GROUP": "1"},
-                                 {"LSN_HOST_GROUP": "3", "LSN_HOST_PATH": "grouped"}])
+                                 {"LSN_HOST_GROUP": "3", "LSN_HOST_PATH": "grouped"},
+                                 {"LSN_HOST_DEVICES": "0,0"}, {"LSN_HOST_DEVICES": "0,0,0"}, {"LSN_HOST_DEVICES": "0,0,0,0,0,0,0,0"}])
 def test_every_host_flow_returns_the_oracles_mesh(gpu, orc, env):
     """generateMeshFromDepthMaps and lsnCorrectAndGenerateMesh through every flow of the library (kernel stores into the pinned mesh
-    blocks / mesh in HBM + copy engine; sensors per upload group by size, forced to 1 and to 3) on rigs that exercise the schedule's
-    corners: the meshes, the written-back corrected maps and the TransferServer stream of the call's mesh must be the oracle's."""
+    blocks / mesh in HBM + copy engine; sensors per upload group by size, forced to 1 and to 3; the call sharded over 2, 3 and 8 "devices"
+    -- the one GPU of the box listed several times, the only rehearsal a one-GPU box allows: every shard has its own thread, streams,
+    buffers and plans, only the links are not distinct) on rigs that exercise the schedule's corners: the meshes, the written-back
+    corrected maps and the TransferServer stream of the call's mesh must be the oracle's."""
     import hashlib
     import subprocess
     import sys as _sys

@@ -197,3 +197,35 @@ def test_survivor_exchange_equals_single_process_merge(tmp_path, orc, world, S):
     T, w, h = 2, 64, 48
     mp.spawn(_survivor_worker, args=(world, _free_port(), S, T, w, h, str(tmp_path)), nprocs=world, join=True)
     _check_every_rank(tmp_path, orc, world, S, T, w, h)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around_it():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it (what the driver's N > 1 tier would run if it launched the bench the
+    way it launches N = 1): bench.py starts `python -m torch.distributed.run --nproc-per-node 2 bench.py ...` as a child process before it
+    imports torch, relays rank 0's one JSON line and leaves with the child's status.  LSN_BENCH_LAUNCH_PROBE=1 swaps the GPU work for a gloo
+    head count, so the launch path itself runs here."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["LSN_BENCH_LAUNCH_PROBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # ONE line on stdout, whatever the ranks and the launcher print
+    line = json.loads(lines[0])
+    assert line["n_ranks_seen"] == 2 and line["world_size"] == 2 and line["n_gpus"] == 2
+    assert "without a launcher" in r.stderr
+
+
+def test_bench_without_a_gpu_fails_loudly_through_the_self_launch():
+    """The same command for real on this GPU-less container: the ranks refuse to run (no CPU path) and the parent reports their status."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LSN_BENCH_LAUNCH_PROBE")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the GPU-less container")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--core-only"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "needs a HIP device" in r.stderr

@@ -394,13 +394,107 @@ def test_shard_step_several_ranks_on_one_gpu(gpu, tmp_path, world, sizes, chunks
     tests/fake_rccl -- the seven nccl* entry points over a shared-memory segment -- and `world` processes share this GPU:
     rank offsets, the grouped all-gathers, the chunked second-stream pipeline, the reconstruction of every rank's sensors
     (or the vertex exchange on the ragged rig) all run as they would on `world` GPUs, and every rank must end up with the
-    single-plan merged cloud; rank 0 also holds its result against the CPU oracle's merge of all sensors.  World 8 (configs[3] itself) cannot be rehearsed here: a GPU box admits at most 6 processes on its
-    card, so 4 ranks x 1 sensor is the largest one-sensor-per-rank case."""
+    single-plan merged cloud; rank 0 also holds its result against the CPU oracle's merge of all sensors.  (World 8 = configs[3] itself:
+    test_configs3_true_split_world8_on_one_gpu, rank threads inside 4 processes.)"""
     if not os.path.exists(FAKE_RCCL):
         pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
     mp.spawn(_shard_worker_multi, args=(world, _free_port(), sizes, chunks, padded, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def _shard_worker_world8(proc, n_procs, port, out):
+    """BASELINE configs[3] at its true split: 8 shards x 1 sensor x 512x424.  A GPU box admits 6 processes on its card, so the 8 ranks are
+    8 LsnShard handles driven by 2 threads in each of 4 processes (ctypes releases the GIL: the blocking rendezvous and collectives of the
+    ranks of one process run side by side); every rank holds its merged cloud against the CPU oracle's merge of all 8 sensors."""
+    sys.path.insert(0, ROOT)
+    os.environ["LSN_RCCL_LIBRARY"] = FAKE_RCCL
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import threading
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from livescan3d_amd import native, synth
+    from oracle import orc
+    dist.init_process_group("gloo", rank=proc, world_size=n_procs)   # carries the 128-byte id and the verdicts only
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    world, T, S, w, h = 8, 2, 8, 512, 424
+    per_proc = world // n_procs
+    P = w * h
+    rigs = [synth.make_rig("scene" if k else "noise", S, w, h, seed=31, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).to(dev)     # [T, S * P]
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).to(dev)
+    want = [orc.generate_mesh_vertices(r.depth_maps, r.depth_colors, r.widths, r.heights, rigs[0].intr, rigs[0].wt, rigs[0].bounds) for r in rigs]
+    # 1. every rank prepares on its own; the processes agree that all 8 are ready before anybody enters the blocking rendezvous
+    shards, errs = {}, []
+    for t in range(per_proc):
+        rank = proc * per_proc + t
+        try:
+            shards[rank] = native.Shard(0, rank, world, None, T, [w] * S, [h] * S)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(f"rank {rank}: {ex}")
+    ident = native.shard_unique_id() if proc == 0 and not errs else None
+    reports = [None] * n_procs
+    dist.all_gather_object(reports, (errs, ident))
+    verdicts = {}
+    if not any(e for e, _ in reports):
+        ident = reports[0][1]
+
+        def drive(rank):
+            try:
+                sh = shards[rank]
+                st = torch.cuda.Stream(device=dev)
+                sh.connect(ident)                                       # ncclCommInitRank: returns once all 8 ranks have called it
+                seen = sh.ranks_seen()
+                sh.set_params(rigs[0].intr, rigs[0].wt, rigs[0].bounds, st.cuda_stream)
+                mine_d = depth[:, rank * P:(rank + 1) * P].contiguous()
+                mine_c = rgb[:, 3 * rank * P:3 * (rank + 1) * P].contiguous()
+                torch.cuda.synchronize()
+                ok = seen == world
+                for rep in range(2):
+                    mv, mo = sh.step(mine_d.data_ptr(), mine_c.data_ptr(), st.cuda_stream)
+                    st.synchronize()
+                    from livescan3d_amd.sharding import _device_view
+                    merged = _device_view(mv, (T, sh.capacity, 16), torch.uint8, dev).cpu().numpy()
+                    moff = _device_view(mo, (T, S + 1), torch.int32, dev).cpu().numpy()
+                    for k in range(T):
+                        verts, counts = want[k]
+                        n = int(moff[k, -1])
+                        ok = ok and n == len(verts) and n > 0 and list(np.diff(moff[k])) == list(counts) and merged[k, :n].tobytes() == verts.tobytes()
+                verdicts[rank] = "ok" if ok else f"mismatch (ranks seen {seen})"
+            except Exception as ex:  # noqa: BLE001
+                verdicts[rank] = f"{type(ex).__name__}: {ex}"
+
+        threads = [threading.Thread(target=drive, args=(r,)) for r in shards]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    else:
+        verdicts = {r: "not started: " + "; ".join(sum((e for e, _ in reports), [])) for r in range(proc * per_proc, (proc + 1) * per_proc)}
+    for sh in shards.values():
+        sh.close()
+    everything = [None] * n_procs
+    dist.all_gather_object(everything, verdicts)
+    dist.destroy_process_group()
+    if proc == 0:
+        flat = {r: v for d in everything for r, v in d.items()}
+        with open(out, "w") as f:
+            f.write("ok" if len(flat) == world and all(v == "ok" for v in flat.values()) else f"failed {flat}")
+
+
+def test_configs3_true_split_world8_on_one_gpu(gpu, tmp_path):
+    """BASELINE configs[3]: 8 sensors sharded one per rank, 512x424, through lsnShardPrepare / lsnShardConnect / lsnShardStep with a world of 8
+    (tests/fake_rccl carries the collectives: RCCL refuses several ranks on one device; 4 processes x 2 rank threads keep inside the box's
+    6-process guard).  Every one of the 8 ranks must end with the oracle's merged cloud of all 8 sensors, byte for byte, and its communicator
+    must report 8 ranks.  What this cannot show: the real library's rendezvous and stream ordering at world > 1 (no multi-GPU box in reach)."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_shard_worker_world8, args=(4, _free_port(), out), nprocs=4, join=True)
     assert open(out).read() == "ok"
 
 
