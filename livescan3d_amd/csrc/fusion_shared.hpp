@@ -69,9 +69,30 @@ struct FuseArgs {
     float minX, minY, minZ, maxX, maxY, maxZ;
 };
 
+// Kernel arguments of the triangulation passes (mesh.hip: tri_kernel<0 / 1>).
+struct TriArgs {
+    const FrameDesc *frames;
+    const TileDesc *tiles;
+    const unsigned short *depth;
+    const int *pixmap;   // [n_ticks][pixels per tick] (rigs whose widths are not multiples of 8) ...
+    const int *pm_first; // ... or [n_ticks][pixels per tick / 8]: the first vertex index of every lane of 8 pixels ...
+    const unsigned char *pm_mask;   // ... and the mask of its pixels that have a vertex
+    int *tri;            // [n_ticks][tri_cap][3]
+    int *tile_counts;    // [n_ticks * tiles_per_tick] counts, then exclusive prefixes (scan_kernel)
+    unsigned int *codes; // [n_ticks * tiles_per_tick * 256] per-lane 4-bit-per-pixel triangle codes: count pass -> write pass
+    int tiles_per_tick;
+    int win;                    // triangles staged per LDS round of the write pass
+    int host_out;               // `tri` is pinned host memory: the launch picks the HOST form of the write pass
+    int index_base;             // added to every vertex index a triangle names: the tick's vertices start there in the caller's cloud (a call
+                                // sharded over devices, abi.hip: formMesh's rebase across devices); 0 everywhere else
+    long long tick_pix_stride;  // pixels per tick
+    long long tick_tri_stride;  // triangles per tick (capacity)
+};
+
 }  // namespace lsn
 using lsn::FrameDesc;
 using lsn::FuseArgs;
+using lsn::TriArgs;
 using lsn::SensorParams;
 using lsn::TileDesc;
 

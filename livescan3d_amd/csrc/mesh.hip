@@ -13,24 +13,7 @@ namespace {
 // y in [2, h-2), x in [1, w-2).  Same structure as the vertex path: count -> scan_kernel -> write, 8 pixels per lane,
 // the 4 x 11 depth window and the 2 x 9 index window of a lane live in registers.  All integer arithmetic.
 
-struct TriArgs {
-    const FrameDesc *frames;
-    const TileDesc *tiles;
-    const unsigned short *depth;
-    const int *pixmap;   // [n_ticks][pixels per tick] (rigs whose widths are not multiples of 8) ...
-    const int *pm_first; // ... or [n_ticks][pixels per tick / 8]: the first vertex index of every lane of 8 pixels ...
-    const unsigned char *pm_mask;   // ... and the mask of its pixels that have a vertex
-    int *tri;            // [n_ticks][tri_cap][3]
-    int *tile_counts;    // [n_ticks * tiles_per_tick] counts, then exclusive prefixes (scan_kernel)
-    unsigned int *codes; // [n_ticks * tiles_per_tick * 256] per-lane 4-bit-per-pixel triangle codes: count pass -> write pass
-    int tiles_per_tick;
-    int win;                    // triangles staged per LDS round of the write pass
-    int host_out;               // `tri` is pinned host memory: the launch picks the HOST form of the write pass
-    int index_base;             // added to every vertex index a triangle names: the tick's vertices start there in the caller's cloud (a call
-                                // sharded over devices, abi.hip: formMesh's rebase across devices); 0 everywhere else
-    long long tick_pix_stride;  // pixels per tick
-    long long tick_tri_stride;  // triangles per tick (capacity)
-};
+// (TriArgs, the kernel argument block, is declared in fusion_shared.hpp next to FuseArgs)
 
 constexpr int kTriWinDefault = 1536;  // triangles staged per LDS round (18 KB); a multiple of 16 (LSN_TRI_WINDOW: 256 .. 4096)
 // The staged window is padded by one int per 16 triangles: a lane of 8 pixels on a closed surface holds 16 triangles, so the k-th
