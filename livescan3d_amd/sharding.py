@@ -3,7 +3,7 @@
 ShardedFusion is a thin caller of the library's lsnShard* exports (C++ host glue + RCCL inside libNativeUtils.so,
 include/NativeUtils.h part 2b); torch.distributed is only used to hand rank 0's 128-byte RCCL id to the other ranks and to agree
 that every rank is ready.  (The same protocol driven from Python over torch.distributed -- the CPU rehearsal of the N > 1 logic and
-bench.py's comparison legs -- lives in tests/exchange_rehearsal.py; it is not part of the package.)
+bench.py's comparison legs -- lives in bench_support/exchange.py; it is not part of the package.)
 
 The reference fans createVertices out over one std::thread per sensor and concatenates the per-sensor clouds in
 sensor order (src/NativeUtils/depthprocessing.cpp:708-733, formMesh :1594-1608).  Across GPUs the same structure is:

@@ -22,7 +22,7 @@ def _worker(rank, port, compact, out):
     import torch.distributed as dist
     from livescan3d_amd import synth
     from livescan3d_amd.fusion import DeviceFusion
-    from tests.exchange_rehearsal import MergedCloudExchange
+    from bench_support.exchange import MergedCloudExchange
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -160,7 +160,7 @@ def _survivor_worker(rank, port, out):
     import torch.distributed as dist
     from livescan3d_amd import synth
     from livescan3d_amd.fusion import DeviceFusion
-    from tests.exchange_rehearsal import SurvivorExchange
+    from bench_support.exchange import SurvivorExchange
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)

@@ -25,6 +25,11 @@ for d in sorted(glob.glob("$out/*/")):
             for c, v in cs.items():
                 summary[k][c] = round(sum(v) / len(v), 1)
                 summary[k]["dispatches"] = len(v)
+import hashlib
+hsh = hashlib.sha256()
+for f in ("mesh.hip", "radial.hip", "fusion.hip", "fusion_shared.hpp"):
+    hsh.update(open("livescan3d_amd/csrc/" + f, "rb").read())
+summary["_sources_sha256"] = hsh.hexdigest()     # bench.py reports these counters only while the kernels are the ones they were read from
 summary["_workload"] = "tools/tick_driver.py $kind 16: 16 ticks x 8 x 512x424 $kind frames per launch (128 frames, 27.8 M pixels), radial -> vertices -> triangles"
 json.dump(summary, open("$out/summary.json", "w"), indent=1, sort_keys=True)
 for k, v in sorted(summary.items()):
