@@ -14,21 +14,20 @@ def bench_shapes(args, torch, synth, DeviceFusion, dev, dev_index):
     """BASELINE.json's other shapes on one GPU, device resident like the headline: configs[4]'s 1-GPU forms (16 x 1024x1024 = the whole
     rig on one GPU, 2 x 1024x1024 = its per-GPU share at 8 GPUs) and the latency case (8 x 512x424, ONE tick per call).  Per shape:
     ms per step, the write kernel's HBM fraction (HIP events inside the library) and the whole step's."""
-    out = {"note": "hash-noise frames; several ticks per step: count -> scan -> write, one tick per step: the single pass (fuse_kernel<4>); "
-                   "frac = (2 P + 19 V) bytes / time of the kernel named / 8 TB/s, step_frac = the same bytes / step time"}
+    out = {"note": "hash-noise frames, count -> scan -> write; frac = (2 P + 19 V) bytes / time of the kernel named / 8 TB/s, step_frac = the same "
+                   "bytes / step time.  `_single_pass`: the one-tick plan made with LSN_ONE_TICK_SINGLE_PASS=1 (fuse_kernel<4>, one launch instead of "
+                   "three): no faster -- a one-tick call is launch latency plus one workgroup's load -> compute -> store chain (profiles/r05_ab_lookback.txt)"}
     stream = torch.cuda.current_stream().cuda_stream
-    # one-tick plans take the single pass by themselves (one launch instead of count -> scan -> write); `_two_pass`: the same plan made with
-    # LSN_ONE_TICK_TWO_PASS=1 (read when a plan is created), i.e. round 4's three launches
-    for name, S, w, h, T, two_pass in (("16x1024x1024_x8ticks", 16, 1024, 1024, 8, False), ("2x1024x1024_x32ticks", 2, 1024, 1024, 32, False),
-                                       ("8x512x424_x1tick", 8, 512, 424, 1, False), ("8x512x424_x1tick_two_pass", 8, 512, 424, 1, True)):
+    for name, S, w, h, T, single_pass in (("16x1024x1024_x8ticks", 16, 1024, 1024, 8, False), ("2x1024x1024_x32ticks", 2, 1024, 1024, 32, False),
+                                          ("8x512x424_x1tick", 8, 512, 424, 1, False), ("8x512x424_x1tick_single_pass", 8, 512, 424, 1, True)):
         P = w * h
         rig = synth.make_rig("noise", S, w, h, seed=1, bounds=synth.CROP_BOUNDS)
-        if two_pass:
-            os.environ["LSN_ONE_TICK_TWO_PASS"] = "1"
+        if single_pass:
+            os.environ["LSN_ONE_TICK_SINGLE_PASS"] = "1"
         try:
             fus = DeviceFusion(T, [w] * S, [h] * S, device=dev_index, mode=0)
         finally:
-            os.environ.pop("LSN_ONE_TICK_TWO_PASS", None)
+            os.environ.pop("LSN_ONE_TICK_SINGLE_PASS", None)
         fus.set_params(rig.intr, rig.wt, rig.bounds)
         d, c = synth.noise_frames_torch(dev, 1, T, S, w, h)
         d, c = d.view(T, S * P), c.view(T, S * P * 3)

@@ -239,6 +239,13 @@ constexpr int kSpinLimit = 1 << 20;
 // Mode 2 (single pass, one look-back per TILE) tags its words instead of clearing them: bits 63..34 = the launch's epoch,
 // 33..32 = flag, low 32 bits = value; a word of another epoch reads as "empty".
 constexpr int kEpochShift = 34;
+#ifndef LSN_LOOK_SLOTS
+#define LSN_LOOK_SLOTS 1
+#endif
+#ifndef LSN_LOOK_AGENT_ONLY
+#define LSN_LOOK_AGENT_ONLY 0
+#endif
+constexpr int kLookSlots = LSN_LOOK_SLOTS;   // predecessor words per lane and round trip of the look-back (x 64 lanes); build-time for A/B runs
 constexpr unsigned long long kTileAggregate = 1ull << 32, kTilePrefix = 2ull << 32;
 
 // Exclusive prefix of this tile inside its tick, by decoupled look-back (wave 0 of the workgroup; 64 predecessors per poll).
@@ -256,35 +263,56 @@ __device__ __forceinline__ int tile_lookback(const FuseArgs &a, int tick, int ti
     int pos = tile - 1 - lane;  // lane 0 looks at the nearest predecessor
     bool done = tile == 0;
     int spins = 0;
+    static_assert(kLookSlots >= 1 && kLookSlots <= 16, "LSN_LOOK_SLOTS");
+    const bool near_polls = a.n_ticks > 1 && !LSN_LOOK_AGENT_ONLY;
     while (!done) {
-        unsigned long long w = tag | kTilePrefix;  // before the first tile: prefix 0
-        if (pos >= 0) {
-            // most polls take the short way (sc0: past the CU's L1 only; the word is in this XCD's L2 when the producer ran on
-            // this XCD); every fourth goes to memory (agent scope), so a producer on another XCD is seen as well -- a stale L2
-            // line can only read as "empty" (epoch tag)
-            if ((spins & 3) != 3) w = __hip_atomic_load(&st[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else w = __hip_atomic_load(&st[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const unsigned int flag = (w >> kEpochShift) == a.epoch ? (unsigned int)(w >> 32) & 3u : 0u;
-        const unsigned long long pref = __ballot(flag == 2);
-        const int first = pref ? __ffsll((long long)pref) - 1 : 63;
-        const unsigned long long relevant = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
-        const bool poisoned = (__ballot(flag == 3) & relevant) != 0;
-        if (poisoned || (__ballot(flag == 0) & relevant) != 0) {
-            if (poisoned || ++spins > kSpinLimit) {
-                if (lane == 0) {
-                    atomicExch(a.error_flag, 1);
-                    if (a.offsets_mirror) a.offsets_mirror[a.n_frames + 1] = 1;
-                    __hip_atomic_store(&st[tile], tag | (3ull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                return -1;
+        // kLookSlots x 64 predecessors per round trip: the words of all slots are in flight together, then slot after slot is evaluated like
+        // one 64-wide poll.  Built for one-tick launches, where every tile is resident, publishes its aggregate at about the same time and a
+        // tile far down the tick sums hundreds of aggregates in dependent rounds of 64 -- and measured SLOWER the wider the window (8 x 512x424,
+        // one tick: 16.1 us with 1 slot, 16.0 with 4, 18.1 with 8, 19.0 with 16; 16 x 1024x1024: 85 / 104 / 128 / 143 us; 64 ticks: 359 / 370 /
+        // 416 / 507 us -- profiles/r05_ab_lookback.txt): the polls are uncached 8-byte loads and their number, not the depth of the chain, is
+        // what costs.  The default stays 1 slot; -DLSN_LOOK_SLOTS=n rebuilds the A/B.
+        unsigned long long ws[kLookSlots];
+#pragma unroll
+        for (int j = 0; j < kLookSlots; j++) {
+            const int q = pos - 64 * j;
+            ws[j] = tag | kTilePrefix;  // before the first tile: prefix 0
+            if (q >= 0) {
+                // most polls take the short way (sc0: past the CU's L1 only; the word is in this XCD's L2 when the producer ran on
+                // this XCD); every fourth goes to memory (agent scope), so a producer on another XCD is seen as well -- a stale L2
+                // line can only read as "empty" (epoch tag).  A one-tick launch spreads the tick's tiles over all XCDs: every poll goes to memory
+                if (near_polls && (spins & 3) != 3) ws[j] = __hip_atomic_load(&st[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else ws[j] = __hip_atomic_load(&st[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __builtin_amdgcn_s_sleep(1);
-            continue;
         }
-        acc += wave_sum(lane <= first ? (int)(unsigned int)w : 0);
-        if (pref) done = true;
-        else pos -= 64;
+        bool again = false;
+#pragma unroll
+        for (int j = 0; j < kLookSlots; j++) {
+            if (done || again) break;
+            const unsigned long long w = ws[j];
+            const unsigned int flag = (w >> kEpochShift) == a.epoch ? (unsigned int)(w >> 32) & 3u : 0u;
+            const unsigned long long pref = __ballot(flag == 2);
+            const int first = pref ? __ffsll((long long)pref) - 1 : 63;
+            const unsigned long long relevant = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+            const bool poisoned = (__ballot(flag == 3) & relevant) != 0;
+            if (poisoned || (__ballot(flag == 0) & relevant) != 0) {
+                if (poisoned || ++spins > kSpinLimit) {
+                    if (lane == 0) {
+                        atomicExch(a.error_flag, 1);
+                        if (a.offsets_mirror) a.offsets_mirror[a.n_frames + 1] = 1;
+                        __hip_atomic_store(&st[tile], tag | (3ull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    return -1;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                pos -= 64 * j;   // the slots before this one are summed: the next round starts here
+                again = true;
+                break;
+            }
+            acc += wave_sum(lane <= first ? (int)(unsigned int)w : 0);
+            if (pref) done = true;
+        }
+        if (!done && !again) pos -= 64 * kLookSlots;
     }
     if (lane == 0 && tile != 0)
         __hip_atomic_store(&st[tile], tag | kTilePrefix | (unsigned int)(acc + tile_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -647,7 +675,7 @@ static LsnFusion * lsnFusionCreate_impl(int device, int n_ticks, int n_maps, con
     if (const char *env = getenv("LSN_TILES_PER_RUN")) p->tiles_per_run_override = atoi(env);
     if (const char *env = getenv("LSN_NO_THRESHOLDS")) p->thr_enabled = atoi(env) == 0;
     if (const char *env = getenv("LSN_LAZY_RGB")) p->lazy_rgb = atoi(env) != 0;
-    if (const char *env = getenv("LSN_ONE_TICK_TWO_PASS")) p->one_tick_two_pass = atoi(env) != 0;
+    if (const char *env = getenv("LSN_ONE_TICK_SINGLE_PASS")) p->one_tick_single_pass = atoi(env) != 0;
     p->n_ticks = n_ticks;
     p->n_maps = n_maps;
     std::vector<FrameDesc> fr(n_maps);
@@ -1118,10 +1146,12 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (p->profile && next_event_pair(p, e0, e1)) return -1;
 
-    // One-tick plans (what a live caller holds: one merge per call) take the single pass by themselves: count -> scan -> write is three
-    // dependent launches around ~5 us of work, the single pass one ($LSN_ONE_TICK_TWO_PASS=1 when the plan is created keeps the three
-    // launches: A/B, bench `shapes`).
-    const bool single_pass = (p->mode == 2 && !with_pixmap && !hooks) || (p->mode == 0 && p->n_ticks == 1 && !hooks && !p->pipelined && !p->one_tick_two_pass);
+    // One-tick plans (what a live device-resident caller holds: one merge per call): count -> scan -> write is three dependent launches
+    // around ~5 us of work, the single pass one -- and measured no faster (8 x 512x424: 21.4 us per call against 20.0-21.6; 1 x 512x424, 106
+    // tiles: still 14.9 us per call, i.e. the call is launch latency + one workgroup's load -> compute -> store chain, not the look-back) and
+    // slower on big ticks (16 x 1024x1024: 90 against 60 us) -- profiles/r05_ab_lookback.txt.  So the three launches stay the default;
+    // $LSN_ONE_TICK_SINGLE_PASS=1 when the plan is created selects the single pass (A/B, bench `shapes`).
+    const bool single_pass = (p->mode == 2 && !with_pixmap && !hooks) || (p->mode == 0 && p->n_ticks == 1 && !hooks && !p->pipelined && p->one_tick_single_pass);
     if (p->mode == 0) p->timed_kernel = single_pass ? "fuse_kernel<4>" : nullptr;   // what the event pair below brackets
 
     if (p->pipelined && p->mode == 0 && !with_pixmap && !hooks) {

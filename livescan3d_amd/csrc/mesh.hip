@@ -84,11 +84,6 @@ __device__ __forceinline__ unsigned int pixel_triangles(const int (&W)[4][4], in
 // are below its threshold, i.e. when their maximum is: one v_max3_u32, one multiply, one compare per triangle instead of three compares.
 // Equivalence with tri_threshold for every s and every metric: tests/test_fast_division.py.
 constexpr unsigned int kThrMul = 18750u, kThrSum = 17u, kThrAdd = 117618u;
-__device__ __forceinline__ bool edges_pass(unsigned int m0, unsigned int m1, unsigned int m2, unsigned int s)
-{
-    return __umul24(max(m0, max(m1, m2)), kThrMul) <= __umul24(s, kThrSum) + kThrAdd;
-}
-
 // edge_metric with the probes pre-biased: Z = depth + 2^17 for a valid probe pixel, 2^30 for an invalid one (depth 0), so
 // that |x - probe| becomes one v_sad_u32 on non-negative operands and an invalid probe yields a difference no threshold
 // can reach -- no select per edge.  (2 vB - vA) + 2^17 and (2 vA - vB) + 2^17 lie in [65537, 262142].
@@ -101,60 +96,133 @@ __device__ __forceinline__ unsigned int abs_diff_u32(unsigned int a, unsigned in
     return r;
 }
 
-__device__ __forceinline__ unsigned int edge_metric_biased(unsigned int vA, unsigned int vB, unsigned int zBeyondB, unsigned int zBeyondA)
+// The depth window of a lane as it is loaded: per row the pixel left of the lane's eight (0 = there is none), the eight as four packed
+// pairs, the two to their right as one packed pair.
+struct DepthRow {
+    unsigned int left;
+    unsigned int mid[4];
+    unsigned int right;
+};
+
+// depth | bias of window column c (0 .. 10) of a row, straight from the packed pairs: ONE instruction per value (v_and_or_b32 for the low
+// half of a pair, v_perm_b32 for the high half: bytes 2,3 of the pair under bytes 2,3 of the bias) where unpacking and biasing were two.
+// Nothing below needs the raw depth: differences of two biased values are the differences of the depths, "depth != 0" is "value != bias",
+// and the three-depth sum of a triangle carries 3 x bias, which the threshold's constant takes back (kThrAddBiased).
+template <int C>
+__device__ __forceinline__ unsigned int biased_depth(const DepthRow &r)
 {
-    const unsigned int a = abs_diff_u32(vA, vB);                                         // |vB - vA|                 (:35)
-    const unsigned int f = abs_diff_u32(2u * vB + kProbeBias - vA, zBeyondB);            // |d - (beyondB - vB)|      (:39-47)
-    const unsigned int b = abs_diff_u32(2u * vA + kProbeBias - vB, zBeyondA);            // |d - (vA - beyondA)|      (:50-56)
+    if (C == 0) return r.left | kProbeBias;
+    const unsigned int pair = C <= 8 ? r.mid[(C - 1) >> 1] : r.right;
+    const bool high = C <= 8 ? ((C - 1) & 1) != 0 : C == 10;
+    return high ? __builtin_amdgcn_perm(kProbeBias, pair, 0x07060302u) : ((pair & 0xFFFFu) | kProbeBias);
+}
+
+// The edge metric on biased values: zA, zB the edge's ends (depth | bias), pBeyondB / pBeyondA the probes one step further (depth | bias, or
+// kProbeInvalid for a depth of 0 -- a difference no threshold reaches).  With d = zB - zA: 2 vB - vA + bias = zB + d, 2 vA - vB + bias = zA - d.
+__device__ __forceinline__ unsigned int edge_metric_z(unsigned int zA, unsigned int zB, unsigned int pBeyondB, unsigned int pBeyondA)
+{
+    const unsigned int d = zB - zA;
+    const unsigned int a = abs_diff_u32(zA, zB);                    // |vB - vA|                 (:35)
+    const unsigned int f = abs_diff_u32(zB + d, pBeyondB);          // |d - (beyondB - vB)|      (:39-47)
+    const unsigned int b = abs_diff_u32(zA - d, pBeyondA);          // |d - (vA - beyondA)|      (:50-56)
     return min(a, min(f, b));
 }
 
-// mU9 / mP9: bit c = the pixel of column x0 + c in row y - 1 / row y has a vertex (c = 0 .. 8)
-__device__ __forceinline__ unsigned int lane_triangles(const int (&D)[4][kPxPerLane + 3], unsigned int mU9, unsigned int mP9, int x0, int w)
+// edges_pass for a sum of three BIASED depths: 17 (s - 3 bias) + 117618 = 17 s + (117618 - 51 bias); the constant is negative, the sum is
+// not (s >= 3 bias), so the wrapped 32-bit arithmetic gives the true value.
+constexpr unsigned int kThrAddBiased = kThrAdd - 51u * kProbeBias;
+__device__ __forceinline__ bool edges_pass_z(unsigned int m0, unsigned int m1, unsigned int m2, unsigned int s_biased)
 {
-    unsigned int Z[4][kPxPerLane + 3];
+    return __umul24(max(m0, max(m1, m2)), kThrMul) <= __umul24(s_biased, kThrSum) + kThrAddBiased;
+}
+
+// a + b + c as one v_add3_u32 (left alone the compiler shares a two-term sum between two triangles and spends six adds on four sums).
+// (Tried and dropped: collecting a verdict with one v_addc_co_u32 -- mask + mask + carry-in -- instead of a select and an or: the verdict
+// has to become a lane mask operand first, which costs the compiler a select and a compare: 972 against 941 VALU instructions per lane.)
+__device__ __forceinline__ unsigned int add3(unsigned int a, unsigned int b, unsigned int c)
+{
+    unsigned int r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// bit k of an 8-bit mask -> bit 4 k
+__device__ __forceinline__ unsigned int spread_to_nibbles(unsigned int x)
+{
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    return (x | (x << 3)) & 0x11111111u;
+}
+
+// mU9 / mP9: bit c = the pixel of column x0 + c in row y - 1 / row y has a vertex (c = 0 .. 8).  rows[0 .. 3] = depth rows y-2 .. y+1.
+// The per-pixel verdicts t0 .. t3 of the four candidate triangles are collected as four 8-bit masks (bit k = pixel k); everything that
+// does not depend on the depths -- which pixels have vertices (:113-114, :133-134), which columns count (:87-90), "2 and 3 only when
+// neither 0 nor 1 passed" (:120) -- is then a handful of bit operations per LANE instead of per pixel, and the masks are interleaved into
+// the 4-bits-per-pixel code word the write pass reads.
+__device__ __forceinline__ unsigned int lane_triangles(const DepthRow (&rows)[4], unsigned int mU9, unsigned int mP9, int x0, int w)
+{
+    unsigned int Z[4][kPxPerLane + 3], Pz[4][kPxPerLane + 3];   // depth | bias; the same as a probe (invalid -> kProbeInvalid)
+    bool ok[4][kPxPerLane + 3];
+#define LSN_ROW(R)                                                                                         \
+    {                                                                                                      \
+        Z[R][0] = biased_depth<0>(rows[R]); Z[R][1] = biased_depth<1>(rows[R]); Z[R][2] = biased_depth<2>(rows[R]);    \
+        Z[R][3] = biased_depth<3>(rows[R]); Z[R][4] = biased_depth<4>(rows[R]); Z[R][5] = biased_depth<5>(rows[R]);    \
+        Z[R][6] = biased_depth<6>(rows[R]); Z[R][7] = biased_depth<7>(rows[R]); Z[R][8] = biased_depth<8>(rows[R]);    \
+        Z[R][9] = biased_depth<9>(rows[R]); Z[R][10] = biased_depth<10>(rows[R]);                                      \
+    }
+    LSN_ROW(0) LSN_ROW(1) LSN_ROW(2) LSN_ROW(3)
+#undef LSN_ROW
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int c = 0; c < kPxPerLane + 3; c++) Z[r][c] = D[r][c] != 0 ? (unsigned int)D[r][c] + kProbeBias : kProbeInvalid;
+        for (int c = 0; c < kPxPerLane + 3; c++) {
+            ok[r][c] = Z[r][c] != kProbeBias;
+            Pz[r][c] = ok[r][c] ? Z[r][c] : kProbeInvalid;
+        }
     unsigned int ev[kPxPerLane + 1];   // P-U of window column c = 1 .. 9
 #pragma unroll
-    for (int c = 1; c <= kPxPerLane + 1; c++) ev[c - 1] = edge_metric_biased(D[2][c], D[1][c], Z[0][c], Z[3][c]);
-    unsigned int code = 0;
+    for (int c = 1; c <= kPxPerLane + 1; c++) ev[c - 1] = edge_metric_z(Z[2][c], Z[1][c], Pz[0][c], Pz[3][c]);
+    unsigned int T0 = 0, T1 = 0, T2 = 0, T3 = 0;
 #pragma unroll
     for (int k = 0; k < kPxPerLane; k++) {
-        const int c = k + 1, x = x0 + k;
-        const unsigned int vP = D[2][c], vU = D[1][c], vUR = D[1][c + 1], vR = D[2][c + 1];
-        const unsigned int hP = edge_metric_biased(vP, vR, Z[2][c + 2], Z[2][c - 1]);   // P - R
-        const unsigned int hU = edge_metric_biased(vU, vUR, Z[1][c + 2], Z[1][c - 1]);  // U - UR
-        const unsigned int d1 = edge_metric_biased(vU, vR, Z[3][c + 2], Z[0][c - 1]);   // U - R   (down-right)
-        const unsigned int d2 = edge_metric_biased(vP, vUR, Z[0][c + 2], Z[3][c - 1]);  // P - UR  (up-right)
-        const unsigned int pu = ev[c - 1], ru = ev[c];                                   // P - U, R - UR
-        const bool zP = vP != 0, zU = vU != 0, zUR = vUR != 0, zR = vR != 0;            // :22-23
-        const unsigned int sPR = vP + vR, sUUR = vU + vUR;
-        const bool t0 = zR & zU & zP & edges_pass(d1, pu, hP, sPR + vU);                // R,U,P   (:117)
-        const bool t1 = zR & zUR & zU & edges_pass(ru, hU, d1, sUUR + vR);              // R,UR,U  (:118)
-        const bool alt = !(t0 | t1);                                                    // :120
-        const bool t2 = alt & zP & zUR & zU & edges_pass(d2, hU, pu, sUUR + vP);        // P,UR,U (:122)
-        const bool t3 = alt & zP & zR & zUR & edges_pass(hP, ru, d2, sPR + vUR);        // P,R,UR (:123)
-        const bool mP = (mP9 >> k) & 1u, mU = (mU9 >> k) & 1u, mUR = (mU9 >> (k + 1)) & 1u, mR = (mP9 >> (k + 1)) & 1u;
-        const bool in_cols = (x >= 1) & (x < w - 2);                                    // :87-90
-        unsigned int m = 0;
-        m |= (t0 & mR & mU) ? 1u : 0u;                                                  // :133-134
-        m |= (t1 & mR & mUR & mU) ? 2u : 0u;
-        m |= (t2 & mUR & mU) ? 4u : 0u;
-        m |= (t3 & mR & mUR) ? 8u : 0u;
-        code |= ((in_cols & mP) ? m : 0u) << (4 * k);                                   // :113-114
+        const int c = k + 1;
+        const unsigned int zP = Z[2][c], zU = Z[1][c], zUR = Z[1][c + 1], zR = Z[2][c + 1];
+        const unsigned int hP = edge_metric_z(zP, zR, Pz[2][c + 2], Pz[2][c - 1]);    // P - R
+        const unsigned int hU = edge_metric_z(zU, zUR, Pz[1][c + 2], Pz[1][c - 1]);   // U - UR
+        const unsigned int d1 = edge_metric_z(zU, zR, Pz[3][c + 2], Pz[0][c - 1]);    // U - R   (down-right)
+        const unsigned int d2 = edge_metric_z(zP, zUR, Pz[0][c + 2], Pz[3][c - 1]);   // P - UR  (up-right)
+        const unsigned int pu = ev[c - 1], ru = ev[c];                                 // P - U, R - UR
+        const bool vP = ok[2][c], vU = ok[1][c], vUR = ok[1][c + 1], vR = ok[2][c + 1];   // :22-23
+        const bool t0 = vR & vU & vP & edges_pass_z(d1, pu, hP, add3(zP, zR, zU));     // R,U,P   (:117)
+        const bool t1 = vR & vUR & vU & edges_pass_z(ru, hU, d1, add3(zU, zUR, zR));   // R,UR,U  (:118)
+        const bool t2 = vP & vUR & vU & edges_pass_z(d2, hU, pu, add3(zU, zUR, zP));   // P,UR,U  (:122; "only when neither 0 nor 1": below)
+        const bool t3 = vP & vR & vUR & edges_pass_z(hP, ru, d2, add3(zP, zR, zUR));   // P,R,UR  (:123)
+        T0 |= t0 ? (1u << k) : 0u;
+        T1 |= t1 ? (1u << k) : 0u;
+        T2 |= t2 ? (1u << k) : 0u;
+        T3 |= t3 ? (1u << k) : 0u;
     }
-    return code;
+    // which of the lane's columns count (:87-90: 1 <= x < w - 2), which pixels have a vertex (:113-114)
+    const int lo = x0 < 1 ? 1 - x0 : 0, hi = min(kPxPerLane, w - 2 - x0);
+    const unsigned int cols = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    const unsigned int P8 = mP9 & cols & 0xFFu, R8 = (mP9 >> 1) & 0xFFu, U8 = mU9 & 0xFFu, UR8 = (mU9 >> 1) & 0xFFu;
+    const unsigned int alt = ~(T0 | T1);                                                // :120, on the verdicts themselves (before :133-134)
+    const unsigned int V0 = T0 & P8 & R8 & U8;                                          // :133-134
+    const unsigned int V1 = T1 & P8 & R8 & UR8 & U8;
+    const unsigned int V2 = T2 & alt & P8 & UR8 & U8;
+    const unsigned int V3 = T3 & alt & P8 & R8 & UR8;
+    return spread_to_nibbles(V0) | (spread_to_nibbles(V1) << 1) | (spread_to_nibbles(V2) << 2) | (spread_to_nibbles(V3) << 3);
 }
 
+#ifndef LSN_TRI_MIN_WAVES
+#define LSN_TRI_MIN_WAVES 5   // waves per SIMD the count pass is compiled for (build-time, A/B: 5 = 102 VGPRs allowed, 7 = 73; it needs 71)
+#endif
 // MODE 0 = count triangles per tile, 1 = write them at the scanned offsets.
 // HOST (write pass): `tri` is pinned host memory -- plain stores, rounds aligned to the destination (stage_and_store's note).  A template
 // parameter, not a run-time flag: a run-time choice between a streaming and a plain store of the same value to the same address is
 // folded into ONE plain store by the compiler, and the device-resident path loses its streaming stores (65.8 against 71.7 k ticks/s).
 template <int MODE, bool VEC, bool HOST = false>
-__global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const TriArgs a)
+__global__ __launch_bounds__(kThreads, MODE == 0 ? LSN_TRI_MIN_WAVES : 1) void tri_kernel(const TriArgs a)
 {
     extern __shared__ int stage[];   // write pass: stage_ints(a.win) + 3 * 64 ints
     const int kTriWin = a.win;
@@ -230,21 +298,16 @@ __global__ __launch_bounds__(kThreads, MODE == 0 ? 5 : 1) void tri_kernel(const 
             any_vertex = (mask9[1] & 0xFFu) != 0;
         }
         if (any_vertex) {
-            int D[4][kPxPerLane + 3];
+            DepthRow rows[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const unsigned short *row = dep + (long long)(y0 - 2 + r) * w;
                 const uint4 c = *reinterpret_cast<const uint4 *>(row + x0);
-                const unsigned int cw[4] = {c.x, c.y, c.z, c.w};
-                D[r][0] = x0 > 0 ? row[x0 - 1] : 0;
-#pragma unroll
-                for (int k = 0; k < kPxPerLane; k++) D[r][1 + k] = (cw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-                unsigned int right = 0;
-                if (x0 + 8 < w) right = *reinterpret_cast<const unsigned int *>(row + x0 + 8);
-                D[r][9] = right & 0xFFFFu;
-                D[r][10] = right >> 16;
+                rows[r].left = x0 > 0 ? row[x0 - 1] : 0;
+                rows[r].mid[0] = c.x; rows[r].mid[1] = c.y; rows[r].mid[2] = c.z; rows[r].mid[3] = c.w;
+                rows[r].right = x0 + 8 < w ? *reinterpret_cast<const unsigned int *>(row + x0 + 8) : 0u;
             }
-            code = lane_triangles(D, mask9[0], mask9[1], x0, w);
+            code = lane_triangles(rows, mask9[0], mask9[1], x0, w);
         }
     } else {
         // general widths: a lane's pixels may span rows; every pixel fetches its own 4 x 4 window
