@@ -213,6 +213,9 @@ int lsnFusionRadialCorrect(LsnFusion *plan, const float *intr_params, void *d_de
  * may lie in rows another workgroup is already overwriting).  Both pointers equal to the inputs = lsnFusionRadialCorrect. */
 int lsnFusionRadialCorrectTo(LsnFusion *plan, const float *intr_params, const void *d_depth_maps, const void *d_depth_colors,
                              void *d_depth_out, void *d_colors_out, void *stream);
+/* Test hook: the number of work counters of the hole-closing chain that are NOT zero once `stream` has drained (0 after every complete
+ * chain: the chain clears them itself, which is why the next call on the same stream needs no memset); -1 on error. */
+int lsnFusionRadialCountersLeft(LsnFusion *plan, void *stream);
 
 /* Name and average duration (ms, HIP events on the plan's stream) of the dominant kernel over the launches
  * since the last call with reset != 0; used by bench.py's roofline block.  Enable with lsnFusionProfile(plan,1). */
@@ -385,10 +388,14 @@ long long lsnPlyPack(int device, const void *d_vertices, int n_vertices, const i
                      long long out_cap, void *stream);
 
 /* Host callers (LiveScanServer): the mesh the last generateMeshFromDepthMaps / generateVerticesFromDepthMap /
- * lsnCorrectAndGenerateMesh call of the process returned is still in HBM -- or its frames are, and it is rebuilt there on demand;
- * these build its SendFrame stream / binary PLY image on the device and copy the bytes to `out` (host).  With
- * out == NULL they return an upper bound on (stream) / the exact (PLY) length.  Return the length, -1 on error.
- * "Last" means last: a thread that wants the bytes of ITS mesh must not let another thread make a mesh call in between. */
+ * lsnCorrectAndGenerateMesh call OF THE CALLING THREAD returned is still in HBM -- or its frames are, and it is rebuilt there on demand
+ * (a call sharded over $LSN_HOST_DEVICES: its frames are gathered from the devices first); these build its SendFrame stream / binary
+ * PLY image on the device and copy the bytes to `out` (host).  With out == NULL they return an upper bound on (stream) / the exact (PLY)
+ * length.  Return the length, -1 on error.
+ * Which mesh: the one of the calling thread's own last mesh call (merge calls and single-sensor calls run on different workers in
+ * LiveScanServer, MainWindowForm.cs:238,304: the refine thread's single-sensor call does not change what the update thread gets);
+ * a thread that has made no mesh call gets the process's last one.  A LATER call of the same family from another thread still
+ * replaces the mesh -- one thread per family, as in LiveScanServer. */
 long long lsnLastMeshTransferFrame(unsigned char *out, long long out_cap);
 long long lsnLastMeshPly(unsigned char *out, long long out_cap);
 

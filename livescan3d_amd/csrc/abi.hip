@@ -339,6 +339,9 @@ struct Ctx {
     bool warned_flags = false;
 };
 
+// the lane of the calling thread's own last mesh call (lsnLastMesh* read that lane's mesh; include/NativeUtils.h)
+thread_local Lane *t_last_lane = nullptr;
+
 Ctx &ctx()
 {
     static Ctx *c = new Ctx();   // never destroyed: its HIP objects must not be released from a static destructor after the runtime is gone
@@ -800,6 +803,7 @@ struct HostCall {
         out->triangles = nt > 0 ? static_cast<int *>(host_tri) : g_no_triangles;
         committed = true;
         c.last_lane.store(&l);
+        t_last_lane = &l;
         tr.mark("done");
         tr.print();
     }
@@ -975,6 +979,7 @@ struct ShardedCall {
     const float *intr, *wt, *bounds6;
     int count = 0, D = 0;
     bool with_triangles = false, radial = false, back = false;
+    bool only_radial = false;                          // depthMapAndColorSetRadialCorrection: correct and write back, no mesh
     unsigned char *back_d = nullptr, *back_c = nullptr;
     int first[kMaxShards + 1] = {};                    // device d owns sensors [first[d], first[d + 1])
     void *host = nullptr, *host_tri = nullptr;
@@ -1037,6 +1042,18 @@ int shard_part(ShardedCall &sc, int d)
     l.groups.clear();
     LsnFusion *plan = get_plan(c, l, sc.widths, sc.heights, f0, n);
     if (!plan) return -1;
+    if (sc.only_radial) {
+        // the radial export alone: this block up over this device's link, corrected out of place, home again (both ways pageable copies
+        // that keep this thread -- which is why every device has one)
+        if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_depth2.reserve(dbytes + 16) || l.d_colors2.reserve(cbytes + 16)) return -1;
+        LSN_HIP(hipMemcpyWithStream(l.d_depth.p, sc.depth_maps + d_src, dbytes, hipMemcpyHostToDevice, l.up));
+        LSN_HIP(hipMemcpyWithStream(l.d_colors.p, sc.depth_colors + c_src, cbytes, hipMemcpyHostToDevice, l.up));
+        if (lsnFusionRadialCorrectTo(plan, sc.intr + 7 * f0, l.d_depth.p, l.d_colors.p, l.d_depth2.p, l.d_colors2.p, l.stream)) return -1;
+        LSN_HIP(hipStreamSynchronize(l.stream));
+        LSN_HIP(hipMemcpyWithStream(sc.back_d + d_src, l.d_depth2.p, dbytes, hipMemcpyDeviceToHost, l.back));
+        LSN_HIP(hipMemcpyWithStream(sc.back_c + c_src, l.d_colors2.p, cbytes, hipMemcpyDeviceToHost, l.back));
+        return 0;
+    }
     const long long cap = lsnFusionTickCapacity(plan);
     if (l.d_depth.reserve(dbytes + 16) || l.d_colors.reserve(cbytes + 16) || l.d_off.reserve(sizeof(int) * (size_t)(n + 1)) ||
         l.d_tri_off.reserve(sizeof(int) * (size_t)(n + 1)) || ensure_tables(l, n + 2))
@@ -1120,6 +1137,54 @@ void shard_job(void *arg, int d)
     }
 }
 
+// Runs the D parts of a sharded call -- part 0 on the calling thread, the others on their devices' workers -- and waits for all of them.
+// 0, or -1 with the first failure's text in the caller's error channel and nothing of any part left in flight.
+int run_parts(Ctx &c, ShardedCall &sc)
+{
+    struct Join {   // the workers hold pointers into the caller's frame: nothing leaves it before they have finished
+        Ctx &c;
+        int started = 0;
+        explicit Join(Ctx &c_) : c(c_) {}
+        ~Join()
+        {
+            for (int d = 1; d <= started; d++) c.shards[d]->worker.wait();
+        }
+    } join(c);
+    for (int d = 1; d < sc.D; d++) {
+        c.shards[d]->worker.submit(shard_job, &sc, d);
+        join.started = d;
+    }
+    shard_job(&sc, 0);
+    for (int d = 1; d < sc.D; d++) c.shards[d]->worker.wait();
+    join.started = 0;
+    (void)hipSetDevice(c.device);
+    if (sc.failed.load()) {
+        for (int d = 0; d < sc.D; d++) drain(c.shards[d]->lane);   // every device's part has ended; nothing may store into a returned block
+        lsn::set_error("%s", sc.error);
+        return -1;
+    }
+    return 0;
+}
+
+// depthMapAndColorSetRadialCorrection over the devices of $LSN_HOST_DEVICES: every device corrects its block of sensors and writes it back
+// into the caller's arrays.  The merge lane's lock is held.
+int radial_sharded(Ctx &c, Lane &ml, int n_maps, unsigned char *depth_maps, unsigned char *depth_colors, const int *widths, const int *heights,
+                   const float *intr)
+{
+    ml.last_nv = -1;
+    ml.last_plan = nullptr;
+    ml.last_sharded = false;
+    ShardedCall sc(c);
+    sc.depth_maps = depth_maps; sc.depth_colors = depth_colors;
+    sc.widths = widths; sc.heights = heights;
+    sc.intr = intr;
+    sc.count = n_maps;
+    sc.only_radial = true;
+    sc.back_d = depth_maps; sc.back_c = depth_colors;
+    plan_shards(n_maps, (int)c.shards.size(), sc.first, sc.D);
+    return run_parts(c, sc);
+}
+
 // The merge lane's lock is held (it serialises the calls; the shards' lanes are only ever used under it).
 int fuse_host_sharded(Ctx &c, Lane &ml, const unsigned char *depth_maps, const unsigned char *depth_colors, const int *widths, const int *heights,
                       const float *intr, const float *wt, Mesh *out, const float *bounds6, int count, bool with_triangles, bool radial,
@@ -1161,28 +1226,7 @@ int fuse_host_sharded(Ctx &c, Lane &ml, const unsigned char *depth_maps, const u
     if (with_triangles && !(blocks.host_tri = pinned_get(c, (size_t)cap * 2 * 12))) return -1;
     sc.host = blocks.host;
     sc.host_tri = blocks.host_tri;
-    struct Join {   // the workers hold pointers into this frame: nothing leaves it before they have finished
-        Ctx &c;
-        int started = 0;
-        explicit Join(Ctx &c_) : c(c_) {}
-        ~Join()
-        {
-            for (int d = 1; d <= started; d++) c.shards[d]->worker.wait();
-        }
-    } join(c);
-    for (int d = 1; d < sc.D; d++) {
-        c.shards[d]->worker.submit(shard_job, &sc, d);
-        join.started = d;
-    }
-    shard_job(&sc, 0);
-    for (int d = 1; d < sc.D; d++) c.shards[d]->worker.wait();
-    join.started = 0;
-    (void)hipSetDevice(c.device);
-    if (sc.failed.load()) {
-        for (int d = 0; d < sc.D; d++) drain(c.shards[d]->lane);   // every device's part has ended; nothing may store into a returned block
-        lsn::set_error("%s", sc.error);
-        return -1;
-    }
+    if (run_parts(c, sc)) return -1;
     long long nv = 0, nt = 0;
     for (int d = 0; d < sc.D; d++) {
         nv += sc.nv[d].load();
@@ -1210,6 +1254,7 @@ int fuse_host_sharded(Ctx &c, Lane &ml, const unsigned char *depth_maps, const u
     out->triangles = nt > 0 ? static_cast<int *>(blocks.host_tri) : g_no_triangles;
     blocks.committed = true;
     c.last_lane.store(&ml);
+    t_last_lane = &ml;
     return 0;
 }
 
@@ -1401,6 +1446,10 @@ static void depthMapAndColorSetRadialCorrection_impl(int n_maps, unsigned char *
     Lane &l = c.merge;
     std::lock_guard<std::mutex> g(l.mu);
     if (ensure_ready(c)) return;
+    if (c.shards.size() >= 2 && n_maps >= 2) {
+        (void)radial_sharded(c, l, n_maps, depth_maps, depth_colors, widths, heights, intr_params);
+        return;
+    }
     l.last_nv = -1;   // the lane's buffers are about to be reused
     l.last_plan = nullptr;
     l.groups.clear();
@@ -1698,7 +1747,7 @@ static long long lsnLastMeshTransferFrame_impl(unsigned char *out, long long out
 {
     lsn::clear_error();
     Ctx &c = ctx();
-    Lane *l = c.last_lane.load();
+    Lane *l = t_last_lane ? t_last_lane : c.last_lane.load();   // this thread's own last mesh call, else the process's
     if (!l) l = &c.merge;
     std::lock_guard<std::mutex> g(l->mu);
     return last_mesh_bytes(c, *l, 0, out, out_cap);
@@ -1713,7 +1762,7 @@ static long long lsnLastMeshPly_impl(unsigned char *out, long long out_cap)
 {
     lsn::clear_error();
     Ctx &c = ctx();
-    Lane *l = c.last_lane.load();
+    Lane *l = t_last_lane ? t_last_lane : c.last_lane.load();   // this thread's own last mesh call, else the process's
     if (!l) l = &c.merge;
     std::lock_guard<std::mutex> g(l->mu);
     return last_mesh_bytes(c, *l, 1, out, out_cap);

@@ -5,7 +5,8 @@
 // (:34-73,:128), and an uncentred Kabsch step through OpenCV (mean difference, 3x3 SVD, apply; :138-168).
 //
 // Here (everything stays in HBM, no host synchronisation inside the iteration loop):
-//   * exact nearest neighbour -- either an LDS-tiled brute force (nn_mode 0) or a voxel grid over the target built
+//   * exact nearest neighbour -- either a brute force (nn_mode 0: one query per lane, the targets streamed through scalar loads /
+//     SGPRs, no LDS) or a voxel grid over the target built
 //     ONCE per call (the target never moves): counting sort by cell, cells ordered super-block (16^3 cells) ->
 //     block (4^3 cells) -> cell so that every block and super-block is one contiguous range of the sorted points,
 //     tight AABBs per block and super-block.  The source cloud is sorted the same way once per call, so 64 consecutive

@@ -1219,8 +1219,11 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
         if (p->work_cnt.reserve(cnt_bytes)) return -1;
         p->work_cnt_clean = false;
     }
+    // ... and on the same stream as this call: behind another stream's chain the counters may still be counting
+    if (p->work_cnt_stream != s) p->work_cnt_clean = false;
     if (!p->work_cnt_clean) LSN_HIP(hipMemsetAsync(p->work_cnt.p, 0, p->work_cnt.bytes, s));
     p->work_cnt_clean = false;
+    p->work_cnt_stream = s;
     if (!vec) LSN_HIP(hipMemsetAsync(p->holes.p, 0, (size_t)holes_tick_bytes * p->n_ticks, s));   // the pixel-by-pixel pass only sets bits
     BandArgs ba;
     ba.frames = p->frames.as<FrameDesc>();
@@ -1283,6 +1286,28 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
     LSN_HIP(hipGetLastError());
     p->work_cnt_clean = true;
     return 0;
+}
+
+// Test hook: how many of the closing chain's work counters are not zero once `stream` has drained.  The chain leaves them all cleared when
+// it has run to its end (that is what lets the next call skip its memset); tests/test_radial_gpu.py holds it to that on every closing route.
+static int lsnFusionRadialCountersLeft_impl(LsnFusion *p, void *stream)
+{
+    lsn::clear_error();
+    if (!p) return -1;
+    std::lock_guard<std::mutex> g(p->mu);
+    LSN_HIP(hipSetDevice(p->device));
+    LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
+    if (!p->work_cnt.p || p->work_cnt.bytes == 0) return 0;
+    std::vector<int> host(p->work_cnt.bytes / sizeof(int));
+    LSN_HIP(hipMemcpy(host.data(), p->work_cnt.p, host.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int left = 0;
+    for (int v : host) left += v != 0;
+    return left;
+}
+
+extern "C" int lsnFusionRadialCountersLeft(LsnFusion *p, void *stream)
+{
+    return lsn::guarded<int>("lsnFusionRadialCountersLeft", static_cast<int>(-1), [&]() { return lsnFusionRadialCountersLeft_impl(p, stream); });
 }
 
 static int lsnFusionRadialCorrect_impl(LsnFusion *p, const float *intr_params, void *d_depth, void *d_colors, void *stream)

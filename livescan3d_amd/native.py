@@ -23,7 +23,7 @@ EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
     "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh", "lsnHostScheduleDescribe", "lsnHostShardDescribe", "lsnTestFaultPoints", "lsnHostPoolStats",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnPackSensorParams", "lsnFusionSetMode",
-    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
+    "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRadialCountersLeft", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
     "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
     "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardPrepare", "lsnShardConnect", "lsnShardRcclPath", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent", "lsnShardRanksSeen",
@@ -85,6 +85,8 @@ def lib():
     L.depthMapAndColorSetRadialCorrection.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     L.lsnFusionRadialCorrect.restype = C.c_int
     L.lsnFusionRadialCorrect.argtypes = [vp, vp, vp, vp, vp]
+    L.lsnFusionRadialCountersLeft.restype = C.c_int
+    L.lsnFusionRadialCountersLeft.argtypes = [vp, vp]
     L.lsnFusionRadialCorrectTo.restype = C.c_int
     L.lsnFusionRadialCorrectTo.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.createMesh.restype = C.POINTER(Mesh)
@@ -472,6 +474,13 @@ class FusionPlan:
         assert intr.size == 7 * self.n_maps
         _check(lib().lsnFusionRadialCorrectTo(self._h, _ptr(intr), d_depth, d_colors, d_depth_out, d_colors_out, stream),
                "lsnFusionRadialCorrectTo")
+
+    def radial_counters_left(self, stream=0):
+        """Work counters of the hole-closing chain that are not zero once `stream` has drained (test hook; 0 after a complete chain)."""
+        n = lib().lsnFusionRadialCountersLeft(self._h, stream)
+        if n < 0:
+            raise NativeUtilsError(f"lsnFusionRadialCountersLeft failed: {last_error()}")
+        return n
 
     def run_mesh(self, d_depth, d_colors, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream=0):
         """Vertices + triangles (the reference's complete merge call); d_triangles: n_ticks x 2*capacity x 3 int32."""

@@ -475,9 +475,11 @@ for name, kind, n, w, h in {cases!r}:
     assert v.tobytes() == v2.tobytes() and t.tobytes() == t2.tobytes(), name + ": the second call differs from the first"
     v1, t1, d1, c1 = native.correct_and_generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, write_back=True)
     frame = native.last_mesh_transfer_frame()      # the mesh of the last call, rebuilt in / read from HBM
+    rd, rc = native.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)   # the radial export on its own
     out[name] = [len(v), len(t), hashlib.sha256(v.tobytes() + t.tobytes()).hexdigest(),
                  len(v1), len(t1), hashlib.sha256(v1.tobytes() + t1.tobytes() + np.asarray(d1).tobytes() + np.asarray(c1).tobytes()).hexdigest(),
-                 hashlib.sha256(frame).hexdigest()]
+                 hashlib.sha256(frame).hexdigest(),
+                 hashlib.sha256(np.ascontiguousarray(np.asarray(rd)).view(np.uint8).tobytes() + np.ascontiguousarray(np.asarray(rc)).tobytes()).hexdigest()]
 print(json.dumps(out))
 """
 
@@ -520,3 +522,22 @@ def test_every_host_flow_returns_the_oracles_mesh(gpu, orc, env):
         assert g[3:5] == [len(v1), len(t1)], (name, env, g[3:5])
         assert g[5] == hashlib.sha256(v1.tobytes() + t1.tobytes() + cd.tobytes() + cc.tobytes()).hexdigest(), (name, env, "tick as one call")
         assert g[6] == hashlib.sha256(orc.transfer_frame(v1, t1)).hexdigest(), (name, env, "stream of the last mesh")
+        assert g[7] == hashlib.sha256(cd.tobytes() + cc.tobytes()).hexdigest(), (name, env, "radial export")
+
+
+def test_last_mesh_is_the_calling_threads_own(gpu, orc):
+    """lsnLastMesh* return the mesh of the CALLING thread's last mesh call: a single-sensor call made on another thread (LiveScanServer's refine
+    worker) between this thread's merge call and its lsnLastMeshTransferFrame does not change what this thread gets."""
+    import threading
+    rig = synth.make_rig("scene", 3, 256, 212, seed=23, bounds=synth.CROP_BOUNDS)
+    v, t = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    other = {}
+
+    def refine_worker():
+        other["v"] = native.generate_vertices_from_depth_map(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, 1)
+        other["frame"] = native.last_mesh_transfer_frame()
+    th = threading.Thread(target=refine_worker)
+    th.start()
+    th.join()
+    assert native.last_mesh_transfer_frame() == orc.transfer_frame(v, t)                                   # this thread: its merge call's mesh
+    assert other["frame"] == orc.transfer_frame(other["v"], np.zeros((0, 3), dtype=np.int32))              # that thread: its single-sensor cloud

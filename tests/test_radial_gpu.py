@@ -220,3 +220,31 @@ def test_partly_overlapping_buffers_are_refused_and_route_switches_leave_no_stal
     run_and_check("wavefront")
     monkeypatch.delenv("LSN_RADIAL_CLOSE")
     run_and_check("two-pass after the wavefront route")
+
+
+@pytest.mark.parametrize("ticks,env", [(2, {}), (2, {"LSN_RADIAL_TINY_LISTS": "1"}), (80, {}), (80, {"LSN_RADIAL_TINY_LISTS": "1"})])
+def test_closing_chain_leaves_its_counters_cleared(gpu, orc, monkeypatch, ticks, env):
+    """The next call skips the memset of the closing chain's work counters when the previous chain has run to its end on the same stream -- valid
+    only if the chain really leaves all three counter blocks at zero.  Both routes (<= 128 frames: two grid-wide rounds + per-frame kernel;
+    more: the per-frame kernel alone) with ordinary lists and with lists that overflow at once (full sweeps): no counter is left after a
+    call, the second call -- which skipped the memset -- is as right as the first, and a call on ANOTHER stream (which clears the counters
+    again: they might still be counting behind the first stream) is right as well."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    N, w, h = 2, 128, 96
+    rigs = [synth.make_rig("scene", N, w, h, seed=13, tick=k % 4) for k in range(ticks)]
+    plan = native.FusionPlan(0, ticks, rigs[0].widths, rigs[0].heights)
+    src_d = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda()
+    src_c = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()
+    want = [orc.radial_correction(r.depth_maps, r.depth_colors, r.widths, r.heights, rigs[0].intr) for r in rigs[:4]]
+    other = torch.cuda.Stream()
+    st0 = int(torch.cuda.current_stream().cuda_stream)
+    for rep, st in enumerate((st0, st0, int(other.cuda_stream), st0)):
+        d, c = src_d.clone(), src_c.clone()
+        torch.cuda.synchronize()
+        plan.radial_correct(rigs[0].intr, d.data_ptr(), c.data_ptr(), st)
+        assert plan.radial_counters_left(st) == 0, f"call {rep}: the chain left counters behind"
+        for k in (0, 1, ticks - 1):
+            assert np.array_equal(d[k].cpu().numpy().view(np.uint8), np.asarray(want[k % 4][0]).view(np.uint8).ravel()), f"call {rep}: tick {k} depth"
+            assert np.array_equal(c[k].cpu().numpy(), np.asarray(want[k % 4][1]).ravel()), f"call {rep}: tick {k} colours"
