@@ -541,3 +541,46 @@ def test_last_mesh_is_the_calling_threads_own(gpu, orc):
     th.join()
     assert native.last_mesh_transfer_frame() == orc.transfer_frame(v, t)                                   # this thread: its merge call's mesh
     assert other["frame"] == orc.transfer_frame(other["v"], np.zeros((0, 3), dtype=np.int32))              # that thread: its single-sensor cloud
+
+
+_EMPTY_PART_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from livescan3d_amd import native, synth
+rig = synth.make_rig("scene", 5, 256, 212, seed=19, bounds=synth.CROP_BOUNDS)
+d = rig.depth_maps.view(np.uint16).reshape(5, -1).copy()
+d[[0, 1, 4]] = 0                                      # sensors without a single valid pixel
+dm = d.view(np.uint8).ravel()
+out = []
+for _ in range(2):
+    v, t = native.generate_mesh_from_depth_maps(dm, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    out.append([len(v), len(t), hashlib.sha256(v.tobytes() + t.tobytes()).hexdigest()])
+d[:] = 0                                              # ... and a tick without any
+v, t = native.generate_mesh_from_depth_maps(d.view(np.uint8).ravel(), rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+out.append([len(v), len(t), native.host_shards(5, 0)[1]])
+print(json.dumps(out))
+"""
+
+
+def test_sharded_call_with_empty_parts(gpu, orc):
+    """A call sharded over three "devices" whose first part has no vertex at all and whose last part has some in one of its two sensors: the
+    bases the parts derive from each other's counts (0 for an empty part) and the triangle index rebase must still give the oracle's mesh;
+    and a tick without a single valid pixel gives an empty mesh, not an error."""
+    import hashlib
+    import json
+    import subprocess
+    import sys as _sys
+    from livescan3d_amd import synth
+    e = dict(os.environ, LSN_HOST_DEVICES="0,0,0")
+    r = subprocess.run([_sys.executable, "-c", _EMPTY_PART_SCRIPT.format(root=ROOT)], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    rig = synth.make_rig("scene", 5, 256, 212, seed=19, bounds=synth.CROP_BOUNDS)
+    d = rig.depth_maps.view(np.uint16).reshape(5, -1).copy()
+    d[[0, 1, 4]] = 0
+    want_v, counts, want_t = orc.generate_mesh(d.view(np.uint8).ravel(), rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    assert list(counts)[0] == 0 and list(counts)[1] == 0 and list(counts)[4] == 0 and len(want_v) > 1000 and len(want_t) > 1000
+    want = [len(want_v), len(want_t), hashlib.sha256(want_v.tobytes() + want_t.tobytes()).hexdigest()]
+    assert got[0] == want and got[1] == want, (got, want)
+    assert got[2] == [0, 0, "0:[0] 1:[1-2] 2:[3-4]"], got[2]
