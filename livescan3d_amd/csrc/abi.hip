@@ -1143,13 +1143,17 @@ int run_parts(Ctx &c, ShardedCall &sc)
 {
     struct Join {   // the workers hold pointers into the caller's frame: nothing leaves it before they have finished
         Ctx &c;
+        ShardedCall &sc;
         int started = 0;
-        explicit Join(Ctx &c_) : c(c_) {}
+        Join(Ctx &c_, ShardedCall &sc_) : c(c_), sc(sc_) {}
         ~Join()
         {
+            // only reached with workers outstanding when something threw on the way (a thread that could not be started): the parts that did
+            // start may be waiting for the counts of one that never will -- tell them before waiting for them
+            if (started > 0) sc.fail("a device part could not be started");
             for (int d = 1; d <= started; d++) c.shards[d]->worker.wait();
         }
-    } join(c);
+    } join(c, sc);
     for (int d = 1; d < sc.D; d++) {
         c.shards[d]->worker.submit(shard_job, &sc, d);
         join.started = d;
