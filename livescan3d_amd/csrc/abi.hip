@@ -1088,14 +1088,15 @@ int shard_part(ShardedCall &sc, int d)
         return -1;
     }
     if (lsn::run_write(plan, run_d, run_c, static_cast<char *>(sc.host) + (size_t)base * 16, l.d_off.as<int>(), sc.with_triangles, true, l.stream)) return -1;
+    if (sc.with_triangles && lsn::run_triangles_count(plan, run_d, l.d_tri_off.as<int>(), l.h_toff, l.ev_tri, l.stream)) return -1;
     if (sc.back) {
-        // the corrected maps of this block go home (pageable destination: the copies keep this thread) while the write pass stores
+        // the corrected maps of this block go home (pageable destination: the copies keep this thread) while the write pass stores and the
+        // triangle count pass, already queued, runs behind it
         LSN_HIP(hipStreamWaitEvent(l.back, ev_corrected, 0));
         LSN_HIP(hipMemcpyWithStream(sc.back_d + d_src, l.d_depth2.p, dbytes, hipMemcpyDeviceToHost, l.back));
         LSN_HIP(hipMemcpyWithStream(sc.back_c + c_src, l.d_colors2.p, cbytes, hipMemcpyDeviceToHost, l.back));
     }
     if (sc.with_triangles) {
-        if (lsn::run_triangles_count(plan, run_d, l.d_tri_off.as<int>(), l.h_toff, l.ev_tri, l.stream)) return -1;
         LSN_HIP(hipEventSynchronize(l.ev_tri));
         const int nt = l.h_toff[n];
         if (nt < 0 || nt > 2 * cap) {
