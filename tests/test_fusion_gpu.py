@@ -584,3 +584,61 @@ def test_sharded_call_with_empty_parts(gpu, orc):
     want = [len(want_v), len(want_t), hashlib.sha256(want_v.tobytes() + want_t.tobytes()).hexdigest()]
     assert got[0] == want and got[1] == want, (got, want)
     assert got[2] == [0, 0, "0:[0] 1:[1-2] 2:[3-4]"], got[2]
+
+
+_RAGGED_SHARD_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from livescan3d_amd import native, synth
+sizes = {sizes!r}
+out = []
+for seed in (11, 12):
+    depths, rgbs, intr, wt = [], [], [], []
+    for s, (w, h) in enumerate(sizes):
+        d, c = synth.scene_frame(seed, 0, s, len(sizes), w, h) if w >= 64 and h >= 48 else synth.noise_frame(seed, 0, s, w, h)
+        depths.append(d); rgbs.append(c)
+        intr.append(synth.kinect_intrinsics(w, h))
+        wt.append(synth.pack_pose(*synth.ring_pose(s, len(sizes))))
+    rig = synth.Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), synth.CROP_BOUNDS)
+    v, t = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    v1, t1, d1, c1 = native.correct_and_generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, write_back=True)
+    out.append([len(v), len(t), hashlib.sha256(v.tobytes() + t.tobytes()).hexdigest(),
+                hashlib.sha256(v1.tobytes() + t1.tobytes() + np.asarray(d1).tobytes() + np.asarray(c1).tobytes()).hexdigest()])
+print(json.dumps(out))
+"""
+
+_RAGGED_SIZES = [(61, 37), (512, 424), (100, 30), (256, 212), (7, 5), (640, 48), (250, 121)]
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0", "0,0,0,0,0"])
+def test_sharded_call_on_a_ragged_rig(gpu, orc, devices):
+    """Seven sensors of seven sizes (widths that are not multiples of 8 among them: the pixel-by-pixel vertex map and its index rebase, parts
+    whose blocks differ in every dimension) cut over 2, 3 and 5 "devices": merge call and tick-as-one-call must return the oracle's meshes
+    and corrected maps."""
+    import hashlib
+    import json
+    import subprocess
+    import sys as _sys
+    from livescan3d_amd import synth
+    e = dict(os.environ, LSN_HOST_DEVICES=devices)
+    r = subprocess.run([_sys.executable, "-c", _RAGGED_SHARD_SCRIPT.format(root=ROOT, sizes=_RAGGED_SIZES)], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    n = len(_RAGGED_SIZES)
+    for k, seed in enumerate((11, 12)):
+        depths, rgbs, intr, wt = [], [], [], []
+        for s, (w, h) in enumerate(_RAGGED_SIZES):
+            d, c = synth.scene_frame(seed, 0, s, n, w, h) if w >= 64 and h >= 48 else synth.noise_frame(seed, 0, s, w, h)
+            depths.append(d); rgbs.append(c)
+            intr.append(synth.kinect_intrinsics(w, h))
+            wt.append(synth.pack_pose(*synth.ring_pose(s, n)))
+        rig = synth.Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), synth.CROP_BOUNDS)
+        want_v, _, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        cd, cc = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+        cd = np.ascontiguousarray(np.asarray(cd)).view(np.uint8).ravel()
+        cc = np.ascontiguousarray(np.asarray(cc)).ravel()
+        v1, _, t1 = orc.generate_mesh(cd, cc, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+        assert len(want_v) > 1000
+        assert got[k][:3] == [len(want_v), len(want_t), hashlib.sha256(want_v.tobytes() + want_t.tobytes()).hexdigest()], (devices, seed, "merge call")
+        assert got[k][3] == hashlib.sha256(v1.tobytes() + t1.tobytes() + cd.tobytes() + cc.tobytes()).hexdigest(), (devices, seed, "tick as one call")
