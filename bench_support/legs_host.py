@@ -144,94 +144,34 @@ def bench_host_path(native, synth, S, w, h, bounds, only=None, seconds=1.5, rehe
     return out
 
 
-# Predicted time of a call sharded over D devices, from the probes of tools/link_probe.hip (profiles/r04_link_probe.txt): pageable uploads
-# >= 1 MiB at 52 GB/s + 10 us each, smaller ones staged at 15 GB/s; kernel stores to pinned memory at 55 GB/s + 8 us of ramp per storing
-# launch; ~10 us per count round trip (event + atomics + launch), ~20 us to hand the parts to their threads and join them; the radial
-# correction ~100 us of latency-bound closing rounds per part.  DESIGN.md section 7 walks through the sums.
-def predicted_sharded_ms(n_sensors, w, h, vertices, triangles, n_devices, radial):
-    px = w * h
-    per = -(-n_sensors // n_devices)                      # the largest part
-    def up_us(nbytes):
-        return nbytes / 52e3 + 10 if nbytes >= (1 << 20) else nbytes / 15e3
-    t = up_us(per * px * 2) + up_us(per * px * 3) + 10 + (16.0 * vertices / n_devices) / 55e3 + 8
-    if radial:
-        t += 100 + 0      # the corrected maps go home beside the stores
-    if triangles:
-        t += 25 + (12.0 * triangles / n_devices) / 55e3 + 8
-    return (t + 20) / 1e3
-
-
 def sharded_rehearsal(S, w, h):
-    """The merge calls sharded over "two devices": this box's one GPU listed twice ($LSN_HOST_DEVICES=0,0, read once per process: a child
-    process runs tools/host_path.py).  It shows that the flow runs and what its fixed costs are when the parts share one link; it says
-    NOTHING about several links.  Beside it: the time the link-probe numbers predict for 2 / 4 / 8 real devices."""
+    """The merge calls sharded over "several devices" on a box that has one GPU ($LSN_HOST_DEVICES lists it several times; the list is read
+    once per process, so child processes run tools/host_path.py / tools/shard_parts.py).  Two things a one-GPU box CAN measure:
+      (1) the flow as it runs, two parts sharing the one link: its control flow and its fixed costs, nothing about several links;
+      (2) every part of a call ALONE on the link ($LSN_HOST_SHARD_SOLO=1: the parts run one after the other), for 2 / 4 / 8 parts -- what a
+          part would cost on a device and link of its own.  Side by side on real devices a call takes about as long as its slowest part
+          plus the hand-over to the worker threads (~20 us); host memory bandwidth and root-complex contention of concurrent transfers are
+          NOT in that estimate.
+    Neither is a multi-device measurement."""
     import subprocess
-    env = dict(os.environ, LSN_HOST_DEVICES="0,0", LSN_HOST_PATH_ROWS="merge_noise,merge_scene,tick_one_call_scene", LSN_HOST_PATH_SECONDS="0.6")
-    res = {"status": "UNMEASURED ON HARDWARE: a one-GPU box; both parts share its GPU and its one PCIe link (a control-flow rehearsal with timings of "
-                     "its fixed costs, not a multi-device measurement)", "devices": "0,0"}
+    res = {"status": "UNMEASURED ON MULTI-DEVICE HARDWARE: a one-GPU box; (1) both parts share its GPU and its one PCIe link, (2) the parts of a call "
+                     "one after the other, each alone on that link", "devices": "0,0"}
     try:
+        env = dict(os.environ, LSN_HOST_DEVICES="0,0", LSN_HOST_PATH_ROWS="merge_noise,merge_scene,tick_one_call_scene", LSN_HOST_PATH_SECONDS="0.6")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_path.py"), str(S), str(w), str(h)], env=env, capture_output=True, text=True, timeout=180)
         rows = json.loads(r.stdout.strip().splitlines()[-1])
         for k in ("merge_noise", "merge_scene", "tick_one_call_scene"):
-            row = rows[k]
-            res[k] = {"ms_per_call_two_parts_one_link": row["ms_per_call"], "vertices": row["vertices"], "triangles": row["triangles"],
-                      "predicted_ms_per_call": {f"{d}_devices": predicted_sharded_ms(S, w, h, row["vertices"], row["triangles"], d, k.startswith("tick"))
-                                                for d in (2, 4, 8)}}
+            res[k] = {"ms_per_call_two_parts_one_link": rows[k]["ms_per_call"], "vertices": rows[k]["vertices"], "triangles": rows[k]["triangles"],
+                      "slowest_part_alone_ms": {}, "estimated_ms_per_call_on_own_links": {}}
+        if (S, w, h) == (8, 512, 424):
+            for D in (2, 4, 8):
+                env = dict(os.environ, LSN_HOST_DEVICES=",".join(["0"] * D), LSN_HOST_SHARD_SOLO="1", LSN_SHARD_PARTS_REPS="25")
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_parts.py"), str(D)], env=env, capture_output=True, text=True, timeout=180)
+                row = json.loads(r.stdout.strip().splitlines()[-1])
+                for k in ("merge_noise", "merge_scene", "tick_one_call_scene"):
+                    ms = row[k]["slowest_part_us_median"] / 1e3
+                    res[k]["slowest_part_alone_ms"][f"{D}_parts"] = ms
+                    res[k]["estimated_ms_per_call_on_own_links"][f"{D}_devices"] = ms + 0.02
     except Exception as ex:  # noqa: BLE001
         res["error"] = f"{type(ex).__name__}: {ex}"
     return res
-
-
-def bench_wire(args, torch, native, synth, dev, stream, S, w, h, bounds, with_cpu):
-    """TransferSocket.SendFrame stream (with TransferServer's chunking) and binary PLY image of one tick's
-    merged mesh (scene frames: a real triangulated surface), device resident in and out."""
-    from livescan3d_amd.fusion import DeviceFusion
-    rig = synth.make_rig("scene", S, w, h, seed=3, bounds=bounds)
-    fus = DeviceFusion(1, rig.widths, rig.heights, device=dev.index)
-    fus.set_params(rig.intr, rig.wt, rig.bounds)
-    P = w * h
-    depth = torch.from_numpy(rig.depth_maps.view(np.int16).copy()).to(dev).view(1, S * P)
-    rgb = torch.from_numpy(rig.depth_colors.copy()).to(dev).view(1, S * P * 3)
-    cap = fus.capacity
-    tri = torch.empty((1, 2 * cap, 3), dtype=torch.int32, device=dev)
-    toff = torch.zeros((1, S + 1), dtype=torch.int32, device=dev)
-    fus.plan.run_mesh(depth.data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(), tri.data_ptr(), toff.data_ptr(), stream)
-    torch.cuda.synchronize()
-    nv, nt = int(fus.offsets[0, -1].item()), int(toff[0, -1].item())
-    bound = native.transfer_frame_bound(nv, nt)
-    out = torch.empty(bound + 64, dtype=torch.uint8, device=dev)
-    packer = native.TransferPacker(dev.index, nv, nt)
-    reps = 10
-    n = packer.pack(fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), bound, stream)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        n = packer.pack(fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), bound, stream)
-    t_stream = (time.perf_counter() - t0) / reps
-    n_chunks = int(out[8:12].view(torch.int32).item())
-    pb = native.ply_binary_bytes(nv, nt)
-    native.ply_pack(dev.index, fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), pb, stream)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        native.ply_pack(dev.index, fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), pb, stream)
-    torch.cuda.synchronize()
-    t_ply = (time.perf_counter() - t0) / reps
-    res = {"workload": f"one tick of {S} x {w}x{h} scene frames: {nv} vertices, {nt} triangles",
-           "transfer_stream": {"ms": 1e3 * t_stream, "bytes": n, "chunks": n_chunks,
-                               "note": "lsnTransferPack: formMeshChunks re-indexing + SendFrame layout on the device, incl. its host synchronisations"},
-           "ply": {"ms": 1e3 * t_ply, "bytes": pb, "GBps": (16 * nv + 12 * nt + pb) / t_ply / 1e9,
-                   "note": "lsnPlyPack: reads 16 B/vertex + 12 B/triangle, writes the 15 B / 13 B records"}}
-    if with_cpu:
-        from oracle import orc
-        v = fus.vertices[0, :nv].cpu().numpy().view(native.VERTEX_DTYPE).reshape(-1)
-        t = tri[0, :nt].cpu().numpy()
-        t0 = time.perf_counter()
-        ref = orc.transfer_frame(v, t)
-        res["transfer_stream"]["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
-        packer.pack(fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), bound, stream)
-        res["transfer_stream"]["identical_to_cpu_port"] = out[:n].cpu().numpy().tobytes() == ref
-        t0 = time.perf_counter()
-        orc.ply_binary(v, t)
-        res["ply"]["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
-    return res
-

@@ -101,6 +101,11 @@ int lsnHostScheduleDescribe(int n_maps, const int *widths, const int *heights, i
  * "0:[0-3] 1:[4-7]" into buf, the block bounds into first_out (n_devices + 1 ints; may be NULL).  Returns the number of shards, -1 on
  * bad arguments. */
 int lsnHostShardDescribe(int n_maps, int n_devices, int *first_out, char *buf, int len);
+/* Measurement aid.  With $LSN_HOST_SHARD_SOLO=1 (read at the first sharded call) the parts of a sharded call run one after the other on
+ * the calling thread, each alone on the link, and lsnHostShardPartMicros returns the wall time of every part of the last such call
+ * (microseconds; `n` = room in `out`; returns the number of parts, 0 if there was no such call).  What a one-GPU box can say about a call
+ * on several devices: each part's own cost on a link of its own; the call would take about as long as its slowest part. */
+int lsnHostShardPartMicros(long long *out, int n);
 
 /* Test hooks (no device needed).  lsnTestFaultPoints: how many fault points of a kind the process has passed (0 = guarded entries,
  * 1 = device / pinned allocations; $LSN_TEST_THROW / $LSN_TEST_FAIL_ALLOC = n make the n-th one throw std::bad_alloc inside the export).

@@ -1140,8 +1140,31 @@ void shard_job(void *arg, int d)
 
 // Runs the D parts of a sharded call -- part 0 on the calling thread, the others on their devices' workers -- and waits for all of them.
 // 0, or -1 with the first failure's text in the caller's error channel and nothing of any part left in flight.
+// $LSN_HOST_SHARD_SOLO=1 (measurement aid, read once): the parts of a sharded call run ONE AFTER THE OTHER on the calling thread and the
+// wall time of each is kept (lsnHostShardPartMicros).  On a box with one GPU the parts of a rehearsal share its one link; alone, a part
+// shows what it costs on a link of its own -- upload, count, exchange, stores, triangles -- which is what it would have on its own device.
+// (In order 0, 1, ...: every part finds the counts of the parts before it already published.)
+std::atomic<long long> g_part_micros[kMaxShards];
+std::atomic<int> g_part_count{0};
+
 int run_parts(Ctx &c, ShardedCall &sc)
 {
+    static const bool solo = getenv("LSN_HOST_SHARD_SOLO") && atoi(getenv("LSN_HOST_SHARD_SOLO")) != 0;
+    if (solo) {
+        for (int d = 0; d < sc.D; d++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            shard_job(&sc, d);
+            g_part_micros[d].store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() / 1000);
+        }
+        g_part_count.store(sc.D);
+        (void)hipSetDevice(c.device);
+        if (sc.failed.load()) {
+            for (int d = 0; d < sc.D; d++) drain(c.shards[d]->lane);
+            lsn::set_error("%s", sc.error);
+            return -1;
+        }
+        return 0;
+    }
     struct Join {   // the workers hold pointers into the caller's frame: nothing leaves it before they have finished
         Ctx &c;
         ShardedCall &sc;
@@ -1547,6 +1570,15 @@ static int lsnHostShardDescribe_impl(int n_maps, int n_devices, int *first_out, 
 extern "C" int lsnHostShardDescribe(int n_maps, int n_devices, int *first_out, char *buf, int len)
 {
     return lsn::guarded<int>("lsnHostShardDescribe", static_cast<int>(-1), [&]() { return lsnHostShardDescribe_impl(n_maps, n_devices, first_out, buf, len); });
+}
+
+// Measurement aid: the wall time (microseconds) every part of the LAST sharded call took when the parts ran one after the other
+// ($LSN_HOST_SHARD_SOLO=1); returns the number of parts, 0 when no such call has been made.
+extern "C" int lsnHostShardPartMicros(long long *out, int n)
+{
+    const int D = g_part_count.load();
+    for (int d = 0; out && d < D && d < n; d++) out[d] = g_part_micros[d].load();
+    return D;
 }
 
 // Test hooks (tests/test_abi.py): how many fault points of a kind (0 = guarded entries, 1 = device / pinned allocations) the process has

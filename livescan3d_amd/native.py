@@ -21,7 +21,7 @@ VERTEX_DTYPE = np.dtype([("R", "u1"), ("G", "u1"), ("B", "u1"), ("A", "u1"),
 # every symbol include/NativeUtils.h declares
 EXPORTS = [
     "generateVerticesFromDepthMap", "generateMeshFromDepthMaps", "depthMapAndColorSetRadialCorrection", "createMesh", "deleteMesh", "ICP",
-    "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh", "lsnHostScheduleDescribe", "lsnHostShardDescribe", "lsnTestFaultPoints", "lsnHostPoolStats",
+    "lsnGetLastError", "lsnDeviceCount", "lsnCorrectAndGenerateMesh", "lsnHostScheduleDescribe", "lsnHostShardDescribe", "lsnHostShardPartMicros", "lsnTestFaultPoints", "lsnHostPoolStats",
     "lsnFusionCreate", "lsnFusionDestroy", "lsnFusionTickCapacity", "lsnFusionSetParams", "lsnPackSensorParams", "lsnFusionSetMode",
     "lsnFusionRun", "lsnFusionRunStreamed", "lsnFusionSetPipelined", "lsnFusionRadialCorrect", "lsnFusionRadialCorrectTo", "lsnFusionRadialCountersLeft", "lsnFusionRunMesh", "lsnFusionTickTriangleCapacity", "lsnFusionProfile", "lsnFusionKernelStats", "lsnFusionLookbackFailed", "lsnFusionCheck", "lsnFusionThresholds", "lsnMergeShards",
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
@@ -111,6 +111,8 @@ def lib():
     L.lsnPackSensorParams.argtypes = [vp, vp, vp]
     L.lsnHostShardDescribe.restype = C.c_int
     L.lsnHostShardDescribe.argtypes = [C.c_int, C.c_int, vp, C.c_char_p, C.c_int]
+    L.lsnHostShardPartMicros.restype = C.c_int
+    L.lsnHostShardPartMicros.argtypes = [vp, C.c_int]
     L.lsnTestFaultPoints.restype = C.c_longlong
     L.lsnTestFaultPoints.argtypes = [C.c_int]
     L.lsnHostPoolStats.restype = C.c_int
@@ -319,6 +321,13 @@ def host_shards(n_maps, n_devices=0):
     if d < 0:
         raise NativeUtilsError(last_error())
     return [int(first[i]) for i in range(d + 1)], buf.value.decode()
+
+
+def host_shard_part_micros():
+    """Wall time (us) of every part of the last sharded call when the parts ran one after the other ($LSN_HOST_SHARD_SOLO=1); [] if none."""
+    out = (C.c_longlong * 16)()
+    d = lib().lsnHostShardPartMicros(out, 16)
+    return [int(out[i]) for i in range(max(0, d))]
 
 
 def host_pool_stats():
