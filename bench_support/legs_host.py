@@ -175,3 +175,58 @@ def sharded_rehearsal(S, w, h):
     except Exception as ex:  # noqa: BLE001
         res["error"] = f"{type(ex).__name__}: {ex}"
     return res
+
+
+def bench_wire(args, torch, native, synth, dev, stream, S, w, h, bounds, with_cpu):
+    """TransferSocket.SendFrame stream (with TransferServer's chunking) and binary PLY image of one tick's
+    merged mesh (scene frames: a real triangulated surface), device resident in and out."""
+    from livescan3d_amd.fusion import DeviceFusion
+    rig = synth.make_rig("scene", S, w, h, seed=3, bounds=bounds)
+    fus = DeviceFusion(1, rig.widths, rig.heights, device=dev.index)
+    fus.set_params(rig.intr, rig.wt, rig.bounds)
+    P = w * h
+    depth = torch.from_numpy(rig.depth_maps.view(np.int16).copy()).to(dev).view(1, S * P)
+    rgb = torch.from_numpy(rig.depth_colors.copy()).to(dev).view(1, S * P * 3)
+    cap = fus.capacity
+    tri = torch.empty((1, 2 * cap, 3), dtype=torch.int32, device=dev)
+    toff = torch.zeros((1, S + 1), dtype=torch.int32, device=dev)
+    fus.plan.run_mesh(depth.data_ptr(), rgb.data_ptr(), fus.vertices.data_ptr(), fus.offsets.data_ptr(), tri.data_ptr(), toff.data_ptr(), stream)
+    torch.cuda.synchronize()
+    nv, nt = int(fus.offsets[0, -1].item()), int(toff[0, -1].item())
+    bound = native.transfer_frame_bound(nv, nt)
+    out = torch.empty(bound + 64, dtype=torch.uint8, device=dev)
+    packer = native.TransferPacker(dev.index, nv, nt)
+    reps = 10
+    n = packer.pack(fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), bound, stream)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        n = packer.pack(fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), bound, stream)
+    t_stream = (time.perf_counter() - t0) / reps
+    n_chunks = int(out[8:12].view(torch.int32).item())
+    pb = native.ply_binary_bytes(nv, nt)
+    native.ply_pack(dev.index, fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), pb, stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        native.ply_pack(dev.index, fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), pb, stream)
+    torch.cuda.synchronize()
+    t_ply = (time.perf_counter() - t0) / reps
+    res = {"workload": f"one tick of {S} x {w}x{h} scene frames: {nv} vertices, {nt} triangles",
+           "transfer_stream": {"ms": 1e3 * t_stream, "bytes": n, "chunks": n_chunks,
+                               "note": "lsnTransferPack: formMeshChunks re-indexing + SendFrame layout on the device, incl. its host synchronisations"},
+           "ply": {"ms": 1e3 * t_ply, "bytes": pb, "GBps": (16 * nv + 12 * nt + pb) / t_ply / 1e9,
+                   "note": "lsnPlyPack: reads 16 B/vertex + 12 B/triangle, writes the 15 B / 13 B records"}}
+    if with_cpu:
+        from oracle import orc
+        v = fus.vertices[0, :nv].cpu().numpy().view(native.VERTEX_DTYPE).reshape(-1)
+        t = tri[0, :nt].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = orc.transfer_frame(v, t)
+        res["transfer_stream"]["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
+        packer.pack(fus.vertices.data_ptr(), nv, tri.data_ptr(), nt, out.data_ptr(), bound, stream)
+        res["transfer_stream"]["identical_to_cpu_port"] = out[:n].cpu().numpy().tobytes() == ref
+        t0 = time.perf_counter()
+        orc.ply_binary(v, t)
+        res["ply"]["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
+    return res
+
