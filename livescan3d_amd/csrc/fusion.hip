@@ -1221,7 +1221,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
 // its count and resolves its offset by look-back over the tiles before it -- fuse_kernel<4>, the mode-2 kernel), so the groups of
 // a tick can be launched one after the other as their frames arrive, each continuing where the previous one stopped: the tiles of
 // a later launch find the inclusive prefixes of the earlier launches' tiles in place (same epoch).  This is the form the host
-// exports use (abi.hip): their output block is pinned host memory, the launch is bound by the PCIe link, and any further kernel
+// exports use (host_flows.hip): their output block is pinned host memory, the launch is bound by the PCIe link, and any further kernel
 // boundary -- a separate count, a scan -- is time in which nothing crosses it.  first_of_tick starts a tick (new epoch).
 // offsets_mirror (optional, pinned host memory, n_maps + 2 ints): the offset table as the tiles resolve it, then a give-up flag;
 // group_end_mirror (optional, pinned): where this launch's vertices end inside the tick; host_out: d_vertices is pinned host memory.
@@ -1271,7 +1271,7 @@ int lsn::run_frames(LsnFusion *p, const void *d_depth, const void *d_colors, voi
 }
 
 // The two halves of the two-pass form of a ONE-TICK plan, for a caller that has to know the tick's vertex count before it can say where
-// the vertices go: the sensor blocks of a call sharded over several devices (abi.hip) -- device d's vertices start where the devices
+// the vertices go: the sensor blocks of a call sharded over several devices (host_flows.hip) -- device d's vertices start where the devices
 // before it end, inside ONE pinned host block.  run_count: count pass (depth only: it can run while the colours are still on their
 // way up) + scan, the offset table also stored to `offsets_mirror` (pinned), `counted` recorded behind it.  run_write: the write pass
 // at the scanned offsets, vertices to `vertices` -- pinned host memory when host_out (plain, destination-aligned stores).  The two

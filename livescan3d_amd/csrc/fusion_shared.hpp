@@ -84,7 +84,7 @@ struct TriArgs {
     int win;                    // triangles staged per LDS round of the write pass
     int host_out;               // `tri` is pinned host memory: the launch picks the HOST form of the write pass
     int index_base;             // added to every vertex index a triangle names: the tick's vertices start there in the caller's cloud (a call
-                                // sharded over devices, abi.hip: formMesh's rebase across devices); 0 everywhere else
+                                // sharded over devices, host_flows.hip: formMesh's rebase across devices); 0 everywhere else
     long long tick_pix_stride;  // pixels per tick
     long long tick_tri_stride;  // triangles per tick (capacity)
 };
@@ -401,7 +401,7 @@ constexpr int kStageSlots = kWin + (kWin >> LSN_STAGE_PAD_SHIFT) + 1;
 // 8-way conflict).  A typical tile (crop + invalid pixels) fits in one window of kWin; the 20.7 KB footprint (instead of
 // 36.9 KB for a whole tile) lets 7 workgroups share a CU.  Every thread must call this (barriers inside); rank0 is the
 // lane's first rank inside the tile, tile_tot is uniform.  On return the LDS window is free again.
-// host_dst: the destination is pinned host memory (the exports' output block, abi.hip) -- the stores cross PCIe, where plain stores
+// host_dst: the destination is pinned host memory (the exports' output block, host_flows.hip) -- the stores cross PCIe, where plain stores
 // move ~5 % more than streaming ones and a wave whose 1 KB starts on a 1 KB boundary ~3 % more than one that straddles lines
 // (tools/link_probe.hip), so the copy-out is shifted to the destination's alignment.
 __device__ __forceinline__ void stage_and_store(uint4 *stage, const bool (&keep)[kPxPerLane], const uint4 (&vert)[kPxPerLane], int rank0,

@@ -99,7 +99,7 @@ struct DevBuf {
 
 inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
-// Optional extras of one run, for hosts that overlap copies with the passes (abi.hip): all members may be null.
+// Optional extras of one run, for hosts that overlap copies with the passes (host_flows.hip): all members may be null.
 struct RunHooks {
     hipEvent_t colours_ready = nullptr;   // the write pass waits for it (the count pass only reads depth)
     int *h_offsets = nullptr;             // pinned host copy of the offset table, issued right after the scan ...
@@ -128,7 +128,7 @@ int run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int *d_t
                   hipEvent_t tri_counted = nullptr);
 
 // The two halves of the two-pass form of a one-tick plan (fusion.hip) and of its triangle passes (mesh.hip), for a caller that places
-// the tick's vertices / triangles behind somebody else's: abi.hip's calls sharded over devices.  index_base: added to every vertex index a
+// the tick's vertices / triangles behind somebody else's: host_flows.hip's calls sharded over devices.  index_base: added to every vertex index a
 // triangle names (formMesh's rebase, depthprocessing.cpp:1614-1626, across devices).
 int run_count(LsnFusion *p, const void *d_depth, const void *d_colors, int *d_offsets, int *offsets_mirror, hipEvent_t counted, hipStream_t s);
 int run_write(LsnFusion *p, const void *d_depth, const void *d_colors, void *vertices, int *d_offsets, bool with_pixmap, bool host_out, hipStream_t s);

@@ -578,7 +578,7 @@ int lsn::run_triangles(LsnFusion *p, const void *d_depth, void *d_triangles, int
 }
 
 
-// The same in two calls, for a caller that has to know the tick's triangle count before it can say where the triangles go (abi.hip: the
+// The same in two calls, for a caller that has to know the tick's triangle count before it can say where the triangles go (host_flows.hip: the
 // sensor blocks of a call sharded over devices).  Nothing else may run on the plan in between (the lane's lock).
 int lsn::run_triangles_count(LsnFusion *p, const void *d_depth, int *d_tri_offsets, int *tri_mirror, hipEvent_t tri_counted, hipStream_t s)
 {

@@ -1,4 +1,4 @@
-// fake_hip.cpp -- TEST DOUBLE of the HIP runtime, not a product path.  It exists so that the HOST side of libNativeUtils (abi.hip's call
+// fake_hip.cpp -- TEST DOUBLE of the HIP runtime, not a product path.  It exists so that the HOST side of libNativeUtils (abi.hip and host_flows.hip's call
 // flows, lanes, pinned pool, worker threads; the plans' buffer management in fusion.hip / mesh.hip / radial.hip / exchange.hip / icp.hip /
 // wire.hip) can be compiled for the host alone (clang -x hip --cuda-host-only) with -fsanitize=address,undefined or -fsanitize=thread and
 // run in a container without a GPU: GPU sanitizers are not available on the pool, and the host glue is where the races and the leaks live.

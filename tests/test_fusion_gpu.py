@@ -460,7 +460,7 @@ def test_soak_of_mixed_export_calls(gpu, orc):
                 del expect[k]
 
 
-# ---- the host flows of the exports (abi.hip): upload schedule, groups, kernel stores / copy engine ------------------------------------
+# ---- the host flows of the exports (host_flows.hip): upload schedule, groups, kernel stores / copy engine ------------------------------------
 
 _FLOW_SCRIPT = r"""
 import hashlib, json, sys
