@@ -83,8 +83,9 @@ void lsnCorrectAndGenerateMesh(int n_maps, unsigned char *depth_maps, unsigned c
                                float *intr_params, float *wtransform_params, Mesh *out_mesh, float minX, float minY, float minZ,
                                float maxX, float maxY, float maxZ, int write_back_corrected);
 
-/* Host-only (no device needed), for tests and for operators who want to see it: the upload schedule a merge call (radial = 0) or a
- * call that starts with the radial correction (radial != 0) follows for sensors [first, first + count) of these frames, written to buf
+/* Host-only (no device needed), for tests and for operators who want to see it: the upload schedule a merge call (radial = 0), a
+ * call that starts with the radial correction and goes on to the fusion (radial = 1: lsnCorrectAndGenerateMesh) or the radial export alone
+ * (radial = 2: depthMapAndColorSetRadialCorrection) follows for sensors [first, first + count) of these frames, written to buf
  * as text -- e.g. "D[0-2] C[0-2] | D[3-7] C[3-5] | C[6-7]": runs of the depth / colour arrays in upload order (a pageable copy of
  * >= 1 MiB is pinned in place by the runtime, a smaller one staged at a quarter of the rate), `|` where a group of sensors is complete on
  * the device and launched.  sensors_per_group = 0: by size (the default); > 0: forced, like $LSN_HOST_GROUP.  Returns the number of

@@ -160,7 +160,7 @@ void empty_mesh(Mesh *m) noexcept;
 
 // The upload schedule of a call (pure host logic: lsnHostScheduleDescribe) and the split of a call over devices (lsnHostShardDescribe).
 void plan_schedule(std::vector<Group> &groups, std::vector<Copy> &copies, const int *widths, const int *heights, int first, int count, bool radial,
-                   int group_override);
+                   int group_override, bool small_first);
 void plan_shards(int count, int n_devices, int *first, int &D);
 int parse_device_list(const char *text, int n_visible, std::vector<int> &out);
 

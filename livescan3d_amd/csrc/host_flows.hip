@@ -149,9 +149,16 @@ void pinned_put(Ctx &c, void *p)
     if (it == c.live.end()) return;  // not ours: leave it alone
     size_t cap = it->second;
     c.live.erase(it);
-    // keep a handful of blocks around, free the rest
-    if (c.pool.size() >= 8) (void)hipHostFree(p);
-    else c.pool.emplace(cap, p);
+    // keep a handful of blocks around, free the rest (and a block the table cannot take -- its node allocation failed -- is freed, not lost)
+    if (c.pool.size() >= 8) {
+        (void)hipHostFree(p);
+        return;
+    }
+    try {
+        c.pool.emplace(cap, p);
+    } catch (...) {
+        (void)hipHostFree(p);
+    }
 }
 
 // The reference hands out `new int[0]` when a mesh has no triangles (depthprocessing.cpp:1640): a valid pointer that is never
@@ -228,14 +235,16 @@ int ensure_tables(Lane &l, int n)
 //     groups are the >= 1 MiB runs of the DEPTH array (three sensors): 0.417-0.420 / 0.740 ms against 0.429-0.432 / 0.753 for
 //     groups of two (the runs of the colour array) and 0.427 / 0.752 for groups of four.  D[0-2] C[0-2] | D[3-7] C[3-5] | C[6-7];
 //   * calls that start with the radial correction: a group pays ~100 us of latency-bound closing rounds whatever its size --
-//     groups of >= 2.5 MB of colours (four sensors): 1.05 ms against 1.10 (three) and 1.16 (two).  D[0-3] C[0-3] | D[4-7] C[4-7].
+//     groups of >= 2.5 MB of colours (four sensors): 1.05 ms against 1.10 (three) and 1.16 (two); the first group three (round 5: 1.03).
+//     D[0-2] C[0-2] | D[3-7] C[3-7].
 void plan_schedule(std::vector<Group> &groups, std::vector<Copy> &copies, const int *widths, const int *heights, int first, int count, bool radial,
-                   int group_override)
+                   int group_override, bool small_first)
 {
     groups.clear();
     copies.clear();
     constexpr size_t kPinnedCopy = (size_t)1 << 20;
     constexpr size_t kRadialGroup = 2500000;   // colours per group of a call that starts with the radial correction: four 512x424 sensors
+    constexpr size_t kRadialFirstGroup = 1900000;   // ... and of its first group: three
     const int end = first + count;
     auto dsz = [&](int i) { return (size_t)widths[i] * heights[i] * 2; };
     auto csz = [&](int i) { return (size_t)widths[i] * heights[i] * 3; };
@@ -258,7 +267,15 @@ void plan_schedule(std::vector<Group> &groups, std::vector<Copy> &copies, const 
         g.d_src = d_src0 + d_off; g.c_src = c_src0 + c_off;
         auto weight = [&](const Group &q) { return radial ? q.cbytes : q.dbytes; };   // what a group is sized by
         const size_t full = radial ? kRadialGroup : kPinnedCopy;
-        while (i < end && (per > 0 ? g.count < per : (g.count == 0 || weight(g) < full))) {
+        // small_first: the FIRST group of a call that starts with the radial correction AND goes on to the fusion is a little smaller (>= 1.9 MB of colours: three 512x424 sensors):
+        // nothing leaves for the host before the first group is up, corrected and fused, and the groups behind it hide their ~100 us of closing
+        // rounds behind its download anyway (8 x 512x424, tick as one call: 3 | 5 sensors 1.025-1.034 ms against 4 | 4 1.041-1.050; 2 | 4 | 2
+        // 1.08, 1 | 4 | 3 1.14 -- $LSN_HOST_FIRST_GROUP=n forces n sensors for the A/B).  The radial export ALONE keeps equal groups: nothing
+        // leaves before a group is corrected there either, but its way home is as long as its way up (0.445 ms with 4 | 4, 0.454 with 3 | 5)
+        static const int first_n = getenv("LSN_HOST_FIRST_GROUP") ? atoi(getenv("LSN_HOST_FIRST_GROUP")) : 0;
+        const int cut = (radial && small_first && first_n > 0 && groups.empty()) ? first_n : 0;
+        const size_t want = (radial && small_first && groups.empty()) ? kRadialFirstGroup : full;
+        while (i < end && (cut > 0 ? g.count < cut : per > 0 ? g.count < per : (g.count == 0 || weight(g) < want))) {
             g.dbytes += dsz(i);
             g.cbytes += csz(i);
             g.count++;
@@ -319,9 +336,9 @@ void plan_schedule(std::vector<Group> &groups, std::vector<Copy> &copies, const 
     }
 }
 
-int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int first, int count, bool radial)
+int make_schedule(Ctx &c, Lane &l, const int *widths, const int *heights, int first, int count, bool radial, bool small_first)
 {
-    plan_schedule(l.groups, l.copies, widths, heights, first, count, radial, c.group_override);
+    plan_schedule(l.groups, l.copies, widths, heights, first, count, radial, c.group_override, small_first);
     if (radial)
         for (Group &g : l.groups) {
             g.radial_plan = get_plan(c, l, widths, heights, g.first, g.count);
@@ -412,7 +429,7 @@ struct HostCall {
         plan = get_plan(c, l, widths, heights, first, count);
         if (!plan) return -1;
         l.last_plan = plan;
-        if (make_schedule(c, l, widths, heights, first, count, radial)) return -1;
+        if (make_schedule(c, l, widths, heights, first, count, radial, radial)) return -1;
         G = l.groups.size();
         size_t dbytes = 0, cbytes = 0;
         for (const Group &g : l.groups) {
@@ -1068,7 +1085,7 @@ void radial_host(Ctx &c, Lane &l, int n_maps, unsigned char *depth_maps, unsigne
     l.last_plan = nullptr;
     l.groups.clear();
     // the upload schedule of a call that starts with the correction: groups of >= 2.5 MB of colours, each with a plan for its warp tables
-    if (make_schedule(c, l, widths, heights, 0, n_maps, true)) return;
+    if (make_schedule(c, l, widths, heights, 0, n_maps, true, false)) return;
     const size_t G = l.groups.size();
     size_t dbytes = 0, cbytes = 0;
     for (const Group &q : l.groups) {
@@ -1198,7 +1215,7 @@ static int lsnHostScheduleDescribe_impl(int n_maps, const int *widths, const int
     }
     std::vector<Group> groups;
     std::vector<Copy> copies;
-    plan_schedule(groups, copies, widths, heights, first, count, radial != 0, sensors_per_group);
+    plan_schedule(groups, copies, widths, heights, first, count, radial != 0, sensors_per_group, radial == 1);
     auto sensor_at = [&](bool colours, size_t off) {   // which sensor starts at byte `off` of the lane's (packed) buffer
         size_t at = 0;
         for (int i = first; i < first + count; i++) {

@@ -343,7 +343,7 @@ def host_schedule(widths, heights, first=0, count=None, radial=False, sensors_pe
     widths, heights = _as(widths, np.int32), _as(heights, np.int32)
     n = len(widths)
     buf = C.create_string_buffer(4096)
-    g = lib().lsnHostScheduleDescribe(n, _ptr(widths), _ptr(heights), int(first), int(n - first if count is None else count), int(bool(radial)),
+    g = lib().lsnHostScheduleDescribe(n, _ptr(widths), _ptr(heights), int(first), int(n - first if count is None else count), int(radial),
                                       int(sensors_per_group), buf, len(buf))
     if g < 0:
         raise NativeUtilsError(last_error())

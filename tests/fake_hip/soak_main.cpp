@@ -66,6 +66,14 @@ struct Rig {
     }
 };
 
+// deleteMesh as a caller that checks would use it: the call nulls the pointers it has released, so pointers that are still there mean the call
+// itself did not run -- which only the fault hooks can make happen ($LSN_TEST_THROW hitting deleteMesh's own entry) -- and it is made again.
+void release(Mesh &m)
+{
+    deleteMesh(&m);
+    if (m.vertices) deleteMesh(&m);
+}
+
 bool failed_call(const Mesh &m)   // a call that a fault hook hit: empty mesh + a message
 {
     char msg[256];
@@ -94,7 +102,7 @@ void merge_thread(int iters)
         generateMeshFromDepthMaps(rig.n, rig.depth.data(), rig.colours.data(), rig.widths.data(), rig.heights.data(), rig.intr.data(), rig.wt.data(), &m, false,
                                   rig.b[0], rig.b[1], rig.b[2], rig.b[3], rig.b[4], rig.b[5], false);
         check_mesh(m, rig.total(), true, "merge 8x512x424");
-        deleteMesh(&m);
+        release(m);
         generateMeshFromDepthMaps(small.n, small.depth.data(), small.colours.data(), small.widths.data(), small.heights.data(), small.intr.data(),
                                   small.wt.data(), &m, false, small.b[0], small.b[1], small.b[2], small.b[3], small.b[4], small.b[5], false);
         check_mesh(m, small.total(), true, "merge 3x250x121");
@@ -103,14 +111,14 @@ void merge_thread(int iters)
             std::vector<unsigned char> frame((size_t)bound);
             (void)lsnLastMeshTransferFrame(frame.data(), bound);
         }
-        deleteMesh(&m);
+        release(m);
         // the tick as one call: the radial kernels are not emulated, the corrected maps read as zeros -> an empty cloud, through every copy
         // and event of the flow; the caller's arrays are overwritten with the (zero) corrected maps, so they are copies
         std::vector<unsigned char> d2 = rig.depth, c2 = rig.colours;
         lsnCorrectAndGenerateMesh(rig.n, d2.data(), c2.data(), rig.widths.data(), rig.heights.data(), rig.intr.data(), rig.wt.data(), &m, rig.b[0], rig.b[1],
                                   rig.b[2], rig.b[3], rig.b[4], rig.b[5], it & 1);
         check_mesh(m, 0, false, "tick as one call");
-        deleteMesh(&m);
+        release(m);
     }
 }
 
@@ -124,7 +132,7 @@ void single_thread(int iters)
             generateVerticesFromDepthMap(rig.depth.data(), rig.colours.data(), rig.widths.data(), rig.heights.data(), rig.intr.data(), rig.wt.data(), &m, rig.b[0],
                                          rig.b[1], rig.b[2], rig.b[3], rig.b[4], rig.b[5], s);
             check_mesh(m, rig.valid[s], false, "single sensor");
-            deleteMesh(&m);
+            release(m);
         }
 }
 

@@ -360,7 +360,9 @@ def test_host_upload_schedule_known_rigs():
     """lsnHostScheduleDescribe on the rigs the numbers in DESIGN.md section 5 were measured on (and a few corners)."""
     S = native.host_schedule
     assert S([512] * 8, [424] * 8) == (3, "D[0-2] C[0-2] | D[3-7] C[3-5] | C[6-7]")                  # merge call: groups follow the >= 1 MiB depth runs
-    assert S([512] * 8, [424] * 8, radial=True) == (2, "D[0-3] C[0-3] | D[4-7] C[4-7]")              # tick as one call / radial export: >= 2.5 MB of colours
+    assert S([512] * 8, [424] * 8, radial=True) == (2, "D[0-2] C[0-2] | D[3-7] C[3-7]")              # tick as one call / radial export: first group >= 1.9 MB of colours, then >= 2.5 MB
+    assert S([512] * 8, [424] * 8, radial=2) == (2, "D[0-3] C[0-3] | D[4-7] C[4-7]")                 # the radial export alone: equal groups of >= 2.5 MB of colours
+    assert S([512] * 16, [424] * 16, radial=True) == (4, "D[0-2] C[0-2] | D[3-6] C[3-6] | D[7-10] C[7-10] | D[11-15] C[11-15]")
     assert S([512] * 8, [424] * 8, first=3, count=1) == (1, "D[3] C[3]")                             # generateVerticesFromDepthMap(index 3)
     assert S([1024] * 3, [768] * 3) == (3, "D[0] C[0] | D[1] C[1] | D[2] C[2]")                      # big frames: a group per sensor
     assert S([512] * 8, [424] * 8, sensors_per_group=1) == (8, "D[0-2] C[0] | C[1] | C[2] | D[3-7] C[3] | C[4] | C[5] | C[6] | C[7]")
