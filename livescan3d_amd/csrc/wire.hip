@@ -95,6 +95,17 @@ __device__ __forceinline__ int triangle_new_mask(const int *__restrict__ tri, in
     return m;
 }
 
+// What the workgroups of ONE launch tell each other here goes through agent-scope (write-through) atomic stores and loads, and a
+// workgroup counts itself in once those stores have been acknowledged: vmcnt(0).  Not __threadfence(): an agent-scope fence writes back
+// and invalidates the XCD's whole L2 (buffer_wbl2 / buffer_inv), per wave that executes it -- measured on ICP's match step, where two
+// such fences per workgroup made one fused launch cost 44 us against 24 us for the three launches it replaced
+// (profiles/r05_ab_icp_fused_match.txt).  Everything else these kernels write is read by LATER launches.
+__device__ __forceinline__ void stores_acknowledged()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+}
+
 // inclusive scan over the block's 256 threads (4 waves)
 __device__ __forceinline__ int block_inclusive_scan(int v, int *s_wave /* 4 ints */)
 {
@@ -127,12 +138,11 @@ __global__ __launch_bounds__(kTriPerBlock) void chunk_count_kernel(ChunkState *s
     const int incl = block_inclusive_scan(cnt, s_wave);
     if (threadIdx.x == kTriPerBlock - 1) {
         __hip_atomic_store(&bsum[blockIdx.x], incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
+        stores_acknowledged();
         s_flag = atomicAdd(&st->arrive_count, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (!s_flag) return;
-    __threadfence();
     // ---- last block: exclusive offsets of the blocks, and the block in which the running count reaches the limit
     const int carry = st->carry;
     const int nb = gridDim.x;
@@ -195,13 +205,9 @@ __global__ __launch_bounds__(kTriPerBlock) void chunk_emit_kernel(ChunkState *st
             li++;
         }
     }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_flag = atomicAdd(&st->arrive_emit, 1u) == gridDim.x - 1;
-    }
+    if (threadIdx.x == 0) s_flag = atomicAdd(&st->arrive_emit, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!s_flag || threadIdx.x != 0) return;
-    __threadfence();
     st->arrive_emit = 0;
     st->p_first = win;
     st->p_last = e;
