@@ -209,7 +209,13 @@ __device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, lon
     const __amdgpu_buffer_rsrc_t col = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(S.rgb + 3 * fb), 0, 3 * npix, kRsrcWord3);
     const unsigned int last = (unsigned int)npix - 1u;
     auto colour = [&](unsigned int q, bool real) {     // 0x00BBGGRR of the frame's pixel q: one unaligned dword (the byte behind the three belongs
-        const unsigned int adj = q == last ? 1u : 0u;   // to the next pixel; the frame's last pixel is read one byte early instead); !real reads 0
+        if (last == 0u) {                               // to the next pixel; the frame's last pixel is read one byte early instead); !real reads 0
+            // a frame of ONE pixel has no byte in front of its last pixel either (and a dword does not fit its three bytes): byte by byte
+            const unsigned int o = real ? 0u : kNowhere;
+            return (unsigned int)__builtin_amdgcn_raw_buffer_load_b8(col, o, 0, 0) | ((unsigned int)__builtin_amdgcn_raw_buffer_load_b8(col, o + 1u, 0, 0) << 8) |
+                   ((unsigned int)__builtin_amdgcn_raw_buffer_load_b8(col, o + 2u, 0, 0) << 16);
+        }
+        const unsigned int adj = q == last ? 1u : 0u;
         const unsigned int v = __builtin_amdgcn_raw_buffer_load_b32(col, real ? 3u * q - adj : kNowhere, 0, 0);
         return (v >> (8u * adj)) & 0x00FFFFFFu;
     };

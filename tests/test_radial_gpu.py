@@ -70,6 +70,14 @@ def test_warp_edge_cases(gpu, orc):
     intr[2] = 0.0                                              # fx = 0: u = +-inf / NaN -> every destination rejected in x
     _check(orc, _rig([depth], [rgb], [intr]), "fx=0")
     _check(orc, _rig([np.zeros((h, w), np.uint16)], [rgb], [synth.kinect_intrinsics(w, h)]), "all invalid")
+    # frames of one pixel, one row, one column -- alone and between ordinary frames (found by tests/test_fuzz_gpu.py: a 1 x 1 frame's colour
+    # was read "one byte before the last pixel", i.e. in front of the frame, and came back 0)
+    tiny = [(1, 1), (1, 7), (9, 1), (2, 2)]
+    frames = [(np.full((hh, ww), 900 + 10 * k, np.uint16), np.full((hh, ww, 3), 40 + k, np.uint8)) for k, (ww, hh) in enumerate(tiny)]
+    for k, (ww, hh) in enumerate(tiny):
+        _check(orc, _rig([frames[k][0]], [frames[k][1]], [synth.kinect_intrinsics(ww, hh)]), f"{ww} x {hh} alone")
+    _check(orc, _rig([depth] + [f[0] for f in frames] + [depth], [rgb] + [f[1] for f in frames] + [rgb],
+                     [synth.kinect_intrinsics(w, h)] + [synth.kinect_intrinsics(ww, hh) for ww, hh in tiny] + [synth.kinect_intrinsics(w, h)]), "tiny frames between others")
 
 
 def test_device_resident_batch_then_fusion(gpu, orc):
