@@ -73,10 +73,30 @@ def _same_mesh(got_v, got_t, want_v, want_t, what):
     assert np.array_equal(np.asarray(got_t).reshape(-1, 3), np.asarray(want_t).reshape(-1, 3)), f"{what}: triangles differ"
 
 
-@pytest.mark.parametrize("seed", range(N_CASES))
+def _random_large_rig(rng):
+    """2-8 sensors of 0.2-1.8 MB each (widths multiples of 8 or not): the sizes at which a call's frames go up in several groups."""
+    n = int(rng.integers(2, 9))
+    depths, rgbs, intr, wt = [], [], [], []
+    for s in range(n):
+        w, h = int(rng.integers(300, 700)), int(rng.integers(150, 520))
+        if rng.random() < 0.6:
+            w &= ~7
+        d, c = synth.scene_frame(int(rng.integers(1, 100)), 0, s, n, w, h) if rng.random() < 0.7 else synth.noise_frame(int(rng.integers(1, 100)), 0, s, w, h)
+        depths.append(d); rgbs.append(c)
+        k = synth.kinect_intrinsics(w, h).copy()
+        k[4:7] = rng.uniform(-0.2, 0.2, size=3).astype(np.float32)
+        intr.append(k)
+        wt.append(synth.pack_pose(*synth.ring_pose(s, n)))
+    return synth.Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), synth.CROP_BOUNDS)
+
+
+N_LARGE = 10
+
+
+@pytest.mark.parametrize("seed", range(N_CASES + N_LARGE))
 def test_random_rig_matches_the_oracle(gpu, orc, seed):
     rng = np.random.default_rng(1000 + seed)
-    rig = _random_rig(rng)
+    rig = _random_rig(rng) if seed < N_CASES else _random_large_rig(rng)
     what = f"seed {seed}: sizes {list(zip(rig.widths.tolist(), rig.heights.tolist()))} bounds {rig.bounds.tolist()}"
     # the merge call
     want_v, _, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
@@ -197,4 +217,4 @@ def test_random_rigs_in_the_other_host_flows(gpu, env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "random_rig_matches", "-p", "no:cacheprovider"],
                        capture_output=True, text=True, env=e, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
-    assert f"{N_CASES} passed" in r.stdout, r.stdout[-500:]
+    assert f"{N_CASES + N_LARGE} passed" in r.stdout, r.stdout[-500:]
