@@ -383,12 +383,22 @@ def _shard_worker_multi(rank, world, port, sizes, chunks, padded, out):
 UNIFORM4 = [(256, 212)] * 4
 UNIFORM8 = [(128, 96)] * 8
 RAGGED4 = [(61, 37), (250, 120), (250, 120), (61, 37)]               # equal pixel totals per rank for world 2; not for world 4
+# (the ranks' blocks must hold the same number of pixels -- an all-gather moves equal blocks; lsnShardPrepare refuses anything else)
+MIXED8_4 = [(64, 48), (128, 96), (128, 96), (64, 48)]
+MIXED8_6 = [(64, 48), (128, 24), (96, 32), (96, 32), (128, 24), (64, 48)]
+MIXED8_8 = [(64, 48), (128, 24), (96, 32), (96, 32), (128, 24), (64, 48), (192, 16), (24, 128)]
+ODD3 = [(7, 5), (5, 7), (35, 1)]
+ODD8 = [(61, 37), (11, 4), (11, 4), (61, 37), (37, 61), (4, 11), (2257, 1), (2, 22)]
 
 
 @pytest.mark.parametrize("world,sizes,chunks,padded", [
     (2, UNIFORM4, 1, False), (2, UNIFORM4, 3, False), (4, UNIFORM8, 4, False), (4, UNIFORM4, 1, True), (2, UNIFORM8, 5, False),
     (4, UNIFORM4, 4, False), (4, UNIFORM4, 1, False),                 # one sensor per rank (the shape of BASELINE configs[3]), compact: chunked and one shot
-    (2, RAGGED4, 1, False), (2, RAGGED4, 1, True)])
+    (2, RAGGED4, 1, False), (2, RAGGED4, 1, True),
+    # survivor exchange (every width a multiple of 8) on sensors of different sizes, uneven pixel totals per rank, an odd world
+    (2, MIXED8_4, 3, False), (4, MIXED8_8, 2, False), (3, MIXED8_6, 1, False), (3, MIXED8_6, 4, True),
+    # vertex exchange (widths that are not multiples of 8) over three and four ranks
+    (3, ODD3, 1, False), (4, ODD8, 2, False)])
 def test_shard_step_several_ranks_on_one_gpu(gpu, tmp_path, world, sizes, chunks, padded):
     """lsnShardStep with world > 1.  RCCL refuses two ranks on one device, so the library is pointed ($LSN_RCCL_LIBRARY) at
     tests/fake_rccl -- the seven nccl* entry points over a shared-memory segment -- and `world` processes share this GPU:
