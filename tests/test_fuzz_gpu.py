@@ -118,6 +118,13 @@ def test_random_rig_matches_the_oracle(gpu, orc, seed):
     want_v2, _, want_t2 = orc.generate_mesh(cd, cc, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
     got_v2, got_t2 = native.generate_mesh_from_depth_maps(gd, gc, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
     _same_mesh(got_v2, got_t2, want_v2, want_t2, what + " [merge after radial]")
+    # ... and the same tick as ONE call (correction + merge with a single upload), with and without the corrected maps handed back
+    for write_back in (True, False):
+        v3, t3, d3, c3 = native.correct_and_generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds,
+                                                           write_back=write_back)
+        _same_mesh(v3, t3, want_v2, want_t2, what + f" [tick as one call, write_back={write_back}]")
+        if write_back:
+            assert np.asarray(d3).view(np.uint8).ravel().tobytes() == cd.tobytes() and np.asarray(c3).ravel().tobytes() == cc.tobytes(), what + " [maps of the one call]"
 
 
 @pytest.mark.parametrize("seed", range(24))
