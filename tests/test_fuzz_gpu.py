@@ -102,6 +102,9 @@ def test_random_rig_matches_the_oracle(gpu, orc, seed):
     want_v, _, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
     got_v, got_t = native.generate_mesh_from_depth_maps(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
     _same_mesh(got_v, got_t, want_v, want_t, what + " [merge]")
+    # the stream / the file of that same mesh, rebuilt from what the call left on the device(s)
+    assert native.last_mesh_transfer_frame() == orc.transfer_frame(want_v, want_t), what + " [SendFrame stream of the merge call's mesh]"
+    assert native.last_mesh_ply() == orc.ply_binary(want_v, want_t), what + " [PLY of the merge call's mesh]"
     # one sensor alone
     i = int(rng.integers(0, len(rig.widths)))
     sv = native.generate_vertices_from_depth_map(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds, i)
@@ -123,6 +126,7 @@ def test_random_rig_matches_the_oracle(gpu, orc, seed):
         v3, t3, d3, c3 = native.correct_and_generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds,
                                                            write_back=write_back)
         _same_mesh(v3, t3, want_v2, want_t2, what + f" [tick as one call, write_back={write_back}]")
+        assert native.last_mesh_transfer_frame() == orc.transfer_frame(want_v2, want_t2), what + " [SendFrame stream of the one call's mesh]"
         if write_back:
             assert np.asarray(d3).view(np.uint8).ravel().tobytes() == cd.tobytes() and np.asarray(c3).ravel().tobytes() == cc.tobytes(), what + " [maps of the one call]"
 
