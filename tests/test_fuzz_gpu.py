@@ -53,6 +53,8 @@ def _random_rig(rng):
         k = synth.kinect_intrinsics(w, h).copy()
         k[:4] *= (1.0 + rng.uniform(-0.05, 0.05, size=4)).astype(np.float32)
         k[4:7] = rng.uniform(-0.3, 0.3, size=3).astype(np.float32)            # r2, r4, r6: the radial export's lens
+        if rng.random() < 0.15:                                               # a lens that folds the frame onto itself: destinations with many sources
+            k[4:7] = rng.uniform(-4.0, 4.0, size=3).astype(np.float32)
         intr.append(k.astype(np.float32))
         R, t = synth.ring_pose(s, n)
         t = (np.asarray(t, np.float64) + rng.uniform(-0.2, 0.2, size=3)).astype(np.float32)
