@@ -1327,6 +1327,15 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(float4 *src, float *ver
     verts2[o + 2] = q.z;
 }
 
+// What lsnIcpRun clears before its first iteration.
+__global__ __launch_bounds__(kThreads) void run_init_kernel(unsigned long long *keys, int n_keys, int *counters, int n_counters, IcpState *st)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n_keys) keys[i] = ~0ull;
+    if (i < n_counters) counters[i] = 0;
+    if (i == 0) st->v_valid = 0;
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------------------
@@ -1681,9 +1690,10 @@ static int lsnIcpRun_impl(LsnIcp *w, const float *d_verts1, int n1, float *d_ver
     const int nb = capped_blocks(n2);
     unsigned long long *keys = w->keys.as<unsigned long long>();
     IcpState *st = w->state.as<IcpState>();
-    LSN_HIP(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)n1, s));
-    LSN_HIP(hipMemsetAsync(w->counters.p, 0, sizeof(int) * 2 * kBankInts, s));
-    LSN_HIP(hipMemsetAsync(&st->v_valid, 0, sizeof(int), s));   // the first iteration's SVD starts cold
+    // one launch instead of three fills (each a kernel of its own, ~4.5 us): the match keys, the NN step's list counters, and
+    // v_valid -- the first iteration's SVD starts cold
+    hipLaunchKernelGGL(run_init_kernel, dim3(blocks_for(n1 > 2 * kBankInts ? n1 : 2 * kBankInts)), dim3(kThreads), 0, s, keys, n1, w->counters.as<int>(),
+                       2 * kBankInts, st);
     for (int iter = 0; iter < maxIter; iter++) {
         // from the second iteration on idx[] still holds every query's previous neighbour: the search is seeded with it, and
         // its first launch also carries out the previous iteration's motion and clears the match keys
