@@ -209,15 +209,9 @@ __device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, lon
     const __amdgpu_buffer_rsrc_t col = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(S.rgb + 3 * fb), 0, 3 * npix, kRsrcWord3);
     const unsigned int last = (unsigned int)npix - 1u;
     auto colour = [&](unsigned int q, bool real) {     // 0x00BBGGRR of the frame's pixel q: one unaligned dword (the byte behind the three belongs
-        if (last == 0u) {                               // to the next pixel; the frame's last pixel is read one byte early instead); !real reads 0
-            // a frame of ONE pixel has no byte in front of its last pixel either (and a dword does not fit its three bytes): byte by byte
-            const unsigned int o = real ? 0u : kNowhere;
-            return (unsigned int)__builtin_amdgcn_raw_buffer_load_b8(col, o, 0, 0) | ((unsigned int)__builtin_amdgcn_raw_buffer_load_b8(col, o + 1u, 0, 0) << 8) |
-                   ((unsigned int)__builtin_amdgcn_raw_buffer_load_b8(col, o + 2u, 0, 0) << 16);
-        }
-        const unsigned int adj = q == last ? 1u : 0u;
+        const unsigned int adj = q == last ? 1u : 0u;   // to the next pixel; the frame's last pixel is read one byte early instead); !real reads 0
         const unsigned int v = __builtin_amdgcn_raw_buffer_load_b32(col, real ? 3u * q - adj : kNowhere, 0, 0);
-        return (v >> (8u * adj)) & 0x00FFFFFFu;
+        return (v >> (8u * adj)) & 0x00FFFFFFu;         // (a frame of ONE pixel has no byte in front of it either: one_pixel_colour() below)
     };
     unsigned int e[K];
 #pragma unroll
@@ -279,6 +273,16 @@ __device__ __forceinline__ void gather_batch(const WarpSrc &S, long long fb, lon
     }
 }
 
+// gather_batch on a frame of ONE pixel: its colour would be read "one byte before the last pixel", i.e. in front of the frame, and
+// comes back 0 (found by tests/test_fuzz_gpu.py).  The depth it returned is right, and the only source a 1 x 1 frame's pixel can have is
+// itself: its colour is the frame's three bytes if that depth is not zero.  Called once per such frame, outside the gather loops (a
+// test inside colour() cost radial_band_kernel 30 %: 456 -> 590 us per 512 frames).
+__device__ __forceinline__ unsigned int one_pixel_colour(const WarpSrc &S, long long fb, unsigned int depth)
+{
+    const unsigned char *px = S.rgb + 3 * fb;
+    return depth ? ((unsigned int)px[0] | ((unsigned int)px[1] << 8) | ((unsigned int)px[2] << 16)) : 0u;
+}
+
 // The warp alone, to the un-closed scratch maps (the in-place entry point: the closing then reads those).
 __global__ __launch_bounds__(kThreads) void radial_gather_pack_kernel(const FrameDesc *__restrict__ frames, const TileDesc *__restrict__ tiles,
                                                                       const WarpSrc S, unsigned short *__restrict__ map_copy,
@@ -317,6 +321,13 @@ __global__ __launch_bounds__(kThreads) void radial_gather_pack_kernel(const Fram
             c3[1] = (unsigned char)(c[k] >> 8);
             c3[2] = (unsigned char)(c[k] >> 16);
         }
+    }
+    if (fd.npix == 1 && threadIdx.x == 0) {
+        const unsigned int c1 = one_pixel_colour(S, fb, s_d[lead_d / 2]);
+        unsigned char *c3 = s_c + lead_c;
+        c3[0] = (unsigned char)c1;
+        c3[1] = (unsigned char)(c1 >> 8);
+        c3[2] = (unsigned char)(c1 >> 16);
     }
     __syncthreads();
     const int n_px = min(kTile, fd.npix - p0);
@@ -710,6 +721,13 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
                 c3[1] = (unsigned char)(c[k] >> 8);
                 c3[2] = (unsigned char)(c[k] >> 16);
             }
+        }
+        if (fd.npix == 1 && tid == 0) {   // local pixel `lo` is the frame's only pixel, and this thread stored it
+            const unsigned int c1 = one_pixel_colour(a.src, fb, s_d[lo]);
+            unsigned char *c3 = s_c + 3 * lo;
+            c3[0] = (unsigned char)c1;
+            c3[1] = (unsigned char)(c1 >> 8);
+            c3[2] = (unsigned char)(c1 >> 16);
         }
     } else if (VEC) {
         const unsigned short *sd = a.src.depth + fb + pl0;
