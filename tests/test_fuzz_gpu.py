@@ -181,6 +181,20 @@ def test_random_ticks_device_resident(gpu, orc, seed):
         assert verts[k, :len(want_v)].cpu().numpy().tobytes() == want_v.tobytes(), what + " [vertices]"
         assert int(toffs[k, -1].item()) == len(want_t), what
         assert np.array_equal(tris[k, :len(want_t)].cpu().numpy(), np.asarray(want_t).reshape(-1, 3)), what + " [triangles]"
+    # the cloud again through every way the compaction can get its offsets (lsnFusionSetMode), twice each: the second run of a mode counts
+    # from the per-pixel depth thresholds the first one left
+    for mode in (0, 1, 2, 0):
+        plan.set_mode(mode)
+        for rep in range(2):
+            v2 = torch.zeros_like(verts)
+            o2 = torch.zeros_like(offs)
+            plan.run(cd.data_ptr(), cc.data_ptr(), v2.data_ptr(), o2.data_ptr())
+            torch.cuda.synchronize()
+            assert plan.check() == 0, f"seed {seed}: device-side flag after mode {mode}, run {rep}"
+            assert torch.equal(o2, offs), f"seed {seed}: offsets of mode {mode}, run {rep}"
+            for k in range(T):
+                n = int(offs[k, -1].item())
+                assert torch.equal(v2[k, :n], verts[k, :n]), f"seed {seed}: cloud of tick {k}, mode {mode}, run {rep}"
     plan.close()
 
 
