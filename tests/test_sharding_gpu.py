@@ -66,7 +66,8 @@ def test_rccl_exchange_world1(gpu, tmp_path, compact):
     assert open(out).read() == "ok"
 
 
-@pytest.mark.parametrize("S,G,w,h", [(4, 2, 512, 424), (8, 8, 64, 48), (6, 3, 128, 96)])
+@pytest.mark.parametrize("S,G,w,h", [(4, 2, 512, 424), (8, 8, 64, 48), (6, 3, 128, 96),
+                                     (3, 3, 16, 7), (8, 2, 24, 33), (5, 5, 72, 5), (4, 1, 104, 61), (6, 2, 8, 200), (7, 7, 40, 9), (2, 2, 1000, 3)])
 def test_survivor_exchange_kernels_on_one_gpu(gpu, S, G, w, h):
     """The survivor exchange with the all-gather played by hand: every shard packs its sensors (compact depth / colour
     streams + survivor mask), the arrays are laid out like an all-gather result, and the whole-rig plan reconstructs
