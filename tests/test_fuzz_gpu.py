@@ -14,7 +14,9 @@ from livescan3d_amd import native, synth
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = 160
+# $LSN_FUZZ_SCALE=k: k times as many cases of every kind (a campaign run; the suite's default is sized for seconds)
+SCALE = max(1, int(os.environ.get("LSN_FUZZ_SCALE", "1")))
+N_CASES = 160 * SCALE
 
 
 def _random_rig(rng):
@@ -92,7 +94,7 @@ def _random_large_rig(rng):
     return synth.Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), synth.CROP_BOUNDS)
 
 
-N_LARGE = 10
+N_LARGE = 10 * SCALE
 
 
 @pytest.mark.parametrize("seed", range(N_CASES + N_LARGE))
@@ -133,7 +135,7 @@ def test_random_rig_matches_the_oracle(gpu, orc, seed):
             assert np.asarray(d3).view(np.uint8).ravel().tobytes() == cd.tobytes() and np.asarray(c3).ravel().tobytes() == cc.tobytes(), what + " [maps of the one call]"
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_random_ticks_device_resident(gpu, orc, seed):
     """lsnFusionRadialCorrectTo -> lsnFusionRunMesh on 2-5 DIFFERENT ticks of a random rig (the host exports above run one tick per
     call): every tick's corrected maps, cloud, offsets and triangles against the oracle."""
@@ -198,7 +200,7 @@ def test_random_ticks_device_resident(gpu, orc, seed):
     plan.close()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_random_clouds_icp(gpu, orc, seed):
     """The ICP export on random well-conditioned clouds (a bumpy surface patch seen twice, the second copy moved by a small rigid motion,
     resampled, with outliers and duplicated points): sizes from 40 to a few thousand, n2 above and below n1, 1-8 iterations.  1e-4 on
