@@ -365,12 +365,17 @@ def main():
         with leg(result, "cpu_baseline"):
             result["cpu_baseline"] = cpu_baseline(args, synth, S, w, h, bounds)
 
+    abandoned = bool(getattr(cx, "abandoned_thread", False))   # a thread is still inside a library call that never returned (multi.py)
     if multi:
         dist.barrier()
-        dist.destroy_process_group()
+        if not abandoned:
+            dist.destroy_process_group()
     if rank == 0:
         real_stdout.write(json.dumps(result) + "\n")
         real_stdout.flush()
+    if abandoned:
+        sys.stderr.flush()
+        os._exit(0)   # the line is out; an orderly shutdown would wait for that thread
 
 
 if __name__ == "__main__":

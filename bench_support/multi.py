@@ -6,9 +6,30 @@ LSN_BENCH_SHARE_GPU=1 uses when no test double of RCCL is given: RCCL refuses tw
 whose widths are not multiples of 8) all-gather the 16-byte vertices.  cx = the namespace bench.py's main() fills."""
 import os
 import sys
+import threading
 import time
 
 from .exchange import MergedCloudExchange, SurvivorExchange
+
+
+def call_with_timeout(fn, seconds):
+    """fn() on a daemon thread: ("ok", value) | ("error", exception) | ("timeout", None) when it has not returned after `seconds`.  What a
+    blocking call into a library that never comes back (a communicator rendezvous, say) needs: the caller goes on, the thread is left behind
+    and the process must end with os._exit."""
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as ex:  # noqa: BLE001
+            box["error"] = ex
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return "timeout", None
+    return ("error", box["error"]) if "error" in box else ("ok", box.get("value"))
 
 
 class Exchange:
@@ -28,12 +49,25 @@ class Exchange:
             # The library's own RCCL step.  ShardedFusion prepares every rank locally, lets the ranks agree that all are ready and only
             # then enters the blocking communicator set-up, so a rank that cannot prepare (e.g. librccl missing) makes EVERY rank raise
             # here; the flag below turns "any rank failed" into a collective decision to fall back to the Python-driven protocol.
+            # The communicator set-up itself (ncclCommInitRank inside lsnShardConnect) blocks until every rank is in it, and on a node it
+            # has never run on it may not come back at all (bootstrap interface, ...): it runs on a thread of its own, and a rank that has
+            # waited $LSN_BENCH_CONNECT_TIMEOUT_S for it reports that instead (the thread stays behind: the process then ends with os._exit).
             err = None
-            try:
-                self.shard = ShardedFusion(cx.rank, cx.world, B, [w] * S, [h] * S, cx.dev)
-                self.shard.set_params(cx.intr_all, cx.wt_all, cx.bounds)
-            except Exception as ex:  # noqa: BLE001
-                err, self.shard = f"{type(ex).__name__}: {ex}", None
+            limit = float(os.environ.get("LSN_BENCH_CONNECT_TIMEOUT_S", "120"))
+
+            def connect():
+                torch.cuda.set_device(cx.dev)
+                sf = ShardedFusion(cx.rank, cx.world, B, [w] * S, [h] * S, cx.dev)
+                sf.set_params(cx.intr_all, cx.wt_all, cx.bounds)
+                return sf
+            status, val = call_with_timeout(connect, limit)
+            if status == "ok":
+                self.shard = val
+            elif status == "timeout":
+                err = f"the library's communicator set-up did not return within {limit:.0f} s"
+                cx.abandoned_thread = True
+            else:
+                err = f"{type(val).__name__}: {val}"
             flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=flag_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()):

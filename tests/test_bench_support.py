@@ -35,3 +35,15 @@ def test_tools_that_use_the_legs_still_find_them():
         src = open(os.path.join(ROOT, "tools", tool)).read()
         for name in re.findall(r"legs_host\.([A-Za-z_]+)\(", src):
             assert callable(getattr(importlib.import_module("bench_support.legs_host"), name, None)), (tool, name)
+
+
+def test_call_with_timeout_reports_value_error_and_timeout():
+    """bench_support.multi.call_with_timeout: what keeps an N > 1 bench run from waiting for ever inside the library's communicator set-up."""
+    import time
+    from bench_support.multi import call_with_timeout
+    assert call_with_timeout(lambda: 41 + 1, 5.0) == ("ok", 42)
+    status, err = call_with_timeout(lambda: (_ for _ in ()).throw(ValueError("no")), 5.0)
+    assert status == "error" and isinstance(err, ValueError)
+    t0 = time.time()
+    assert call_with_timeout(lambda: time.sleep(30), 0.3) == ("timeout", None)
+    assert time.time() - t0 < 5.0

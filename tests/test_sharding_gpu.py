@@ -583,3 +583,25 @@ def test_a_rank_that_cannot_prepare_does_not_leave_its_peers_waiting(gpu, tmp_pa
     out = str(tmp_path / "result.txt")
     mp.spawn(_shard_worker_prepare_failure, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def test_bench_goes_on_when_the_communicator_setup_never_returns(gpu):
+    """First contact of an N > 1 bench run with a node it has never seen: the library's own communicator rendezvous (ncclCommInitRank inside
+    lsnShardConnect) may simply not come back.  The RCCL test double is told to hang there; `python bench.py --gpus 2` (two ranks sharing
+    this GPU) must notice after $LSN_BENCH_CONNECT_TIMEOUT_S, agree on the Python-driven survivor exchange over torch.distributed instead,
+    print its line -- saying what happened -- and leave with status 0 although a thread is still stuck in the library."""
+    import json
+    import subprocess
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(LSN_RCCL_LIBRARY=FAKE_RCCL, LSN_BENCH_SHARE_GPU="1", FAKE_RCCL_HANG_INIT="1", LSN_BENCH_CONNECT_TIMEOUT_S="5")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-icp", "--no-cpu",
+                        "--no-host-path", "--no-mesh", "--no-tick-parallel"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "did not return within" in str(line["config"].get("shard_preflight")), line["config"]
+    assert "Python over torch.distributed" in line["config"]["parallelism"], line["config"]["parallelism"]
