@@ -224,7 +224,8 @@ int lsnFusionRadialCorrectTo(LsnFusion *plan, const float *intr_params, const vo
 int lsnFusionRadialCountersLeft(LsnFusion *plan, void *stream);
 
 /* Name and average duration (ms, HIP events on the plan's stream) of the dominant kernel over the launches
- * since the last call with reset != 0; used by bench.py's roofline block.  Enable with lsnFusionProfile(plan,1). */
+ * since the last call with reset != 0; used by bench.py's roofline block.  Enable with lsnFusionProfile(plan, 1); lsnFusionProfile(plan, n)
+ * with n > 1 times every n-th launch only (the two event records around a launch cost a few microseconds of stream time each). */
 int lsnFusionProfile(LsnFusion *plan, int enable);
 int lsnFusionKernelStats(LsnFusion *plan, double *avg_ms, long long *launches, char *name, int name_len, int reset);
 

@@ -454,7 +454,7 @@ int lsn::reconstruct(LsnFusion *all, int n_shards, int maps_per_shard, const voi
         hipLaunchKernelGGL(tick_base_kernel, dim3((unsigned)n_shards), dim3(kThreads), 0, lsn::as_stream(stream), d_shard_offsets, all->n_ticks,
                            maps_per_shard, d_tick_base);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (all->profile) {
+    if (timed_launch(all)) {
         if (next_event_pair(all, e0, e1)) return -1;
         all->timed_kernel = "recon_kernel";
         LSN_HIP(hipEventRecord(e0, lsn::as_stream(stream)));

@@ -906,6 +906,8 @@ static int lsnFusionProfile_impl(LsnFusion *p, int enable)
 {
     if (!p) return -1;
     p->profile = enable != 0;
+    p->profile_every = enable > 1 ? enable : 1;
+    p->profile_seq = 0;
     return 0;
 }
 
@@ -1144,7 +1146,7 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
     const size_t off_bytes = sizeof(int) * (size_t)p->n_ticks * (p->n_maps + 1);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (p->profile && next_event_pair(p, e0, e1)) return -1;
+    if (timed_launch(p) && next_event_pair(p, e0, e1)) return -1;
 
     // One-tick plans (what a live device-resident caller holds: one merge per call): count -> scan -> write is three dependent launches
     // around ~5 us of work, the single pass one -- and measured no faster (8 x 512x424: 21.4 us per call against 20.0-21.6; 1 x 512x424, 106
@@ -1373,7 +1375,7 @@ static int lsnFusionRunStreamed_impl(LsnFusion *p, const void *d_depth, const vo
     LSN_HIP(hipMemcpyAsync(d_offsets, off_cur, sizeof(int) * off_elems, hipMemcpyDeviceToDevice, s));
     a.offsets = d_offsets;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (p->profile && next_event_pair(p, e0, e1)) return -1;
+    if (timed_launch(p) && next_event_pair(p, e0, e1)) return -1;
     if (e0) LSN_HIP(hipEventRecord(e0, s));
     if (d_next_depth) {
         a.depth_next = static_cast<const unsigned short *>(d_next_depth);

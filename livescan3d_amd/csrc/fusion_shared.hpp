@@ -569,6 +569,8 @@ struct LsnFusion {
     float thr_build_ms = 0;
     // dominant-kernel timing
     bool profile = false;
+    int profile_every = 1;               // ... of every launch, or of every n-th (lsnFusionProfile(plan, n)): two event records cost ~2 us each on the stream
+    unsigned long long profile_seq = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t ev_used = 0;
     double acc_ms = 0;
@@ -586,8 +588,11 @@ int ensure_thresholds(LsnFusion *p, hipStream_t s);
 void launch_count(LsnFusion *p, bool vec, hipStream_t s, const FuseArgs &a);
 // Next HIP-event pair of the dominant-kernel timer (profiling on).
 int next_event_pair(LsnFusion *p, hipEvent_t &e0, hipEvent_t &e1);
+// whether the dominant kernel of the launch sequence being queued is timed (profiling on, and this launch's turn)
+inline bool timed_launch(LsnFusion *p) { return p->profile && (p->profile_every <= 1 || p->profile_seq++ % (unsigned long long)p->profile_every == 0); }
 }  // namespace lsn
 using lsn::ensure_thresholds;
 using lsn::fill_args;
 using lsn::launch_count;
 using lsn::next_event_pair;
+using lsn::timed_launch;

@@ -542,8 +542,9 @@ class FusionPlan:
         """This batch is written while the next batch's depth (already resident) is counted in the same kernel."""
         _check(lib().lsnFusionRunStreamed(self._h, d_depth, d_colors, d_vertices, d_offsets, d_next_depth, stream), "lsnFusionRunStreamed")
 
-    def profile(self, enable=True):
-        _check(lib().lsnFusionProfile(self._h, 1 if enable else 0), "lsnFusionProfile")
+    def profile(self, enable=True, every=1):
+        """HIP events around the dominant kernel of every launch sequence (every = 1) or of every n-th one."""
+        _check(lib().lsnFusionProfile(self._h, max(1, int(every)) if enable else 0), "lsnFusionProfile")
 
     def kernel_stats(self, reset=True):
         avg, n = C.c_double(0), C.c_longlong(0)
