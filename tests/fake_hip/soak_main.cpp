@@ -58,6 +58,32 @@ struct Rig {
             memcpy(&wt[12 * s], tr, sizeof(tr));
         }
     }
+    // sensors of different sizes; the packed arrays are EXACTLY as long as the sensors need, so a read or a write-back that runs over
+    // the end of the caller's arrays (a copy run of the upload schedule cut wrongly, say) is a sanitizer report
+    Rig(const std::vector<int> &ws, const std::vector<int> &hs, unsigned seed) : n((int)ws.size()), w(0), h(0), widths(ws), heights(hs), intr(7 * ws.size()),
+                                                                                   wt(12 * ws.size()), valid(ws.size(), 0)
+    {
+        size_t px = 0;
+        for (int s = 0; s < n; s++) px += (size_t)widths[s] * heights[s];
+        depth.resize(px * 2);
+        colours.resize(px * 3);
+        uint32_t x = seed * 2654435761u + 1;
+        unsigned short *d = reinterpret_cast<unsigned short *>(depth.data());
+        size_t at = 0;
+        for (int s = 0; s < n; s++) {
+            for (int i = 0; i < widths[s] * heights[s]; i++) {
+                x = x * 1664525u + 1013904223u;
+                const unsigned short v = (x >> 28) == 0 ? 0 : (unsigned short)(500 + ((x >> 8) % 4000));
+                d[at++] = v;
+                valid[s] += v != 0;
+            }
+            const float in[7] = {(widths[s] - 1) * 0.5f, (heights[s] - 1) * 0.5f, 365.0f, 365.0f, 0.09f, -0.27f, 0.09f};
+            const float tr[12] = {0, 0, -2, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+            memcpy(&intr[7 * s], in, sizeof(in));
+            memcpy(&wt[12 * s], tr, sizeof(tr));
+        }
+        for (size_t i = 0; i < colours.size(); i++) colours[i] = (unsigned char)(i * 7);
+    }
     int total() const
     {
         int t = 0;
@@ -195,10 +221,55 @@ void null_sweep()
 
 }  // namespace
 
+// Random rigs of 1-8 sensors of different sizes (1 x 1 up to ~0.9 MB of colours each: below and above the size at which the upload
+// schedule cuts a call into groups and merges short copy runs) through every host export, one after the other on this thread.
+void ragged_rigs(int n_rigs)
+{
+    uint32_t x = 12345;
+    auto rnd = [&](int lo, int hi) {
+        x = x * 1664525u + 1013904223u;
+        return lo + (int)((x >> 8) % (uint32_t)(hi - lo + 1));
+    };
+    for (int r = 0; r < n_rigs; r++) {
+        const int n = rnd(1, 8);
+        std::vector<int> ws, hs;
+        for (int s = 0; s < n; s++) {
+            const int kind = rnd(0, 3);
+            ws.push_back(kind == 0 ? rnd(1, 12) : kind == 1 ? 8 * rnd(1, 80) + rnd(-1, 1) : rnd(200, 640));
+            hs.push_back(kind == 0 ? rnd(1, 9) : kind == 1 ? rnd(1, 60) : rnd(100, 480));
+        }
+        Rig rig(ws, hs, 100 + r);
+        char what[96];
+        snprintf(what, sizeof(what), "ragged rig %d (%d sensors)", r, n);
+        Mesh m;
+        generateMeshFromDepthMaps(rig.n, rig.depth.data(), rig.colours.data(), rig.widths.data(), rig.heights.data(), rig.intr.data(), rig.wt.data(), &m, false,
+                                  rig.b[0], rig.b[1], rig.b[2], rig.b[3], rig.b[4], rig.b[5], false);
+        check_mesh(m, rig.total(), true, what);
+        release(m);
+        const int one = rnd(0, n - 1);
+        generateVerticesFromDepthMap(rig.depth.data(), rig.colours.data(), rig.widths.data(), rig.heights.data(), rig.intr.data(), rig.wt.data(), &m, rig.b[0],
+                                     rig.b[1], rig.b[2], rig.b[3], rig.b[4], rig.b[5], one);
+        check_mesh(m, rig.valid[one], false, what);
+        release(m);
+        {
+            std::vector<unsigned char> d2 = rig.depth, c2 = rig.colours;   // exact-size copies: the export writes the corrected maps back into them
+            depthMapAndColorSetRadialCorrection(rig.n, d2.data(), c2.data(), rig.widths.data(), rig.heights.data(), rig.intr.data());
+        }
+        for (int back = 0; back < 2; back++) {
+            std::vector<unsigned char> d2 = rig.depth, c2 = rig.colours;
+            lsnCorrectAndGenerateMesh(rig.n, d2.data(), c2.data(), rig.widths.data(), rig.heights.data(), rig.intr.data(), rig.wt.data(), &m, rig.b[0], rig.b[1],
+                                      rig.b[2], rig.b[3], rig.b[4], rig.b[5], back);
+            if (!failed_call(m)) CHECK(m.nVertices >= 0 && m.triangles != nullptr, "%s: tick as one call", what);
+            release(m);
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 4;
     null_sweep();
+    ragged_rigs(3 * iters);
     {
         std::vector<std::thread> th;
         th.emplace_back(merge_thread, iters);
