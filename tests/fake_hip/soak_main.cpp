@@ -1,5 +1,6 @@
 // soak_main.cpp -- drives the exports of libNativeUtils' HOST side, built against tests/fake_hip (no GPU) under a sanitizer.
-//   1. every export with NULL pointers and zero sizes;
+//   1. every export with NULL pointers and zero sizes; random rigs of sensors of different sizes through every host export, the caller's
+//      arrays exactly as long as needed; the inbound formats (frame messages, recordings) valid, truncated, with flipped bits and lying headers;
 //   2. the call mix of LiveScanServer from four threads at once (MainWindowForm.cs:238,304: updateWorker's merge calls, refineWorker's
 //      single-sensor calls + ICP, plus the radial export and the last-mesh formats), every result checked against what the runtime
 //      double's kernels "compute" (every non-zero depth pixel survives, one triangle per vertex);
@@ -265,11 +266,91 @@ void ragged_rigs(int n_rigs)
     }
 }
 
+// The inbound formats are what arrives from the network and from disk: valid messages, then the same messages truncated, with bytes
+// flipped and with headers that lie about sizes, from buffers exactly as long as what is handed over.  Nothing may read or write outside
+// them (the sanitizers watch), and every answer is either a sensible length or -1.
+void parser_fuzz(int rounds)
+{
+    uint32_t x = 777;
+    auto rnd = [&](uint32_t n) {
+        x = x * 1664525u + 1013904223u;
+        return (x >> 8) % n;
+    };
+    for (int r = 0; r < rounds; r++) {
+        const int w = 1 + (int)rnd(40), h = 1 + (int)rnd(30), nb = (int)rnd(3);
+        // body block (liveScanClient.cpp:233-268): i32 count, then per body one flag byte, i32 joints, 28 bytes per joint
+        const int nj = 2;
+        std::vector<unsigned char> depth((size_t)w * h * 2), rgb((size_t)w * h * 3), bodies(4 + (size_t)nb * (5 + 28 * nj), 0);
+        for (auto &b : depth) b = (unsigned char)rnd(256);
+        for (auto &b : rgb) b = (unsigned char)rnd(256);
+        memcpy(bodies.data(), &nb, 4);
+        for (int k = 0; k < nb; k++) memcpy(bodies.data() + 4 + (size_t)k * (5 + 28 * nj) + 1, &nj, 4);
+        const int level = (lsnZstdAvailable() && (r & 1)) ? 3 : 0;
+        std::vector<unsigned char> msg(16 + depth.size() + rgb.size() + bodies.size() + 1024);
+        const long long len = lsnFrameEncode(depth.data(), rgb.data(), w, h, bodies.data(), (int)bodies.size(), level, msg.data(), (long long)msg.size());
+        CHECK(len > 16, "lsnFrameEncode %dx%d level %d: %lld", w, h, level, len);
+        if (len <= 16) continue;
+        msg.resize((size_t)len);
+        for (int variant = 0; variant < 12; variant++) {
+            std::vector<unsigned char> m = msg;                       // exact size: the sanitizer sees any byte read past it
+            if (variant >= 1 && variant <= 4) m.resize(16 + rnd((uint32_t)(m.size() - 16)));            // truncated payload
+            if (variant >= 5 && variant <= 8)
+                for (int k = 0; k < 1 + (int)rnd(8); k++) m[rnd((uint32_t)m.size())] ^= (unsigned char)(1u << rnd(8));   // flipped bits, header included
+            if (variant >= 9) {                                                                           // a header that lies
+                int lie = variant == 9 ? 0x7FFFFFFF : variant == 10 ? -5 : (int)rnd(1u << 20);
+                memcpy(m.data() + 4 * rnd(4), &lie, 4);
+            }
+            LsnFrameInfo info;
+            const int rc = lsnFrameParseHeader(m.data(), &info);
+            if (rc != 0) continue;
+            if (info.width <= 0 || info.height <= 0 || (long long)info.width * info.height > (1 << 22)) continue;   // a caller sizes its buffers from these
+            const size_t px = (size_t)info.width * info.height;
+            std::vector<unsigned char> d_out(px * 2), c_out(px * 3), b_out(256);
+            int n_bodies = -1;
+            const int have = (int)m.size() - 16;
+            const long long got = lsnFrameDecode(m.data() + 16, std::min(have, info.payload_bytes), info.compressed, info.width, info.height, d_out.data(), c_out.data(),
+                                                 b_out.data(), (int)b_out.size(), &n_bodies);
+            CHECK(got == -1 || got >= 4, "lsnFrameDecode returned %lld", got);
+            if (variant == 0)
+                CHECK(got == (long long)bodies.size() && d_out == depth && c_out == rgb, "round trip of a %dx%d frame (level %d): body block %lld of %zu, depth %d, colours %d", w,
+                      h, level, got, bodies.size(), (int)(d_out == depth), (int)(c_out == rgb));
+        }
+        // a recording of three such frames, then cut and damaged
+        std::vector<unsigned char> file(3 * (msg.size() + 96));
+        long long at = 0;
+        for (int k = 0; k < 3; k++) {
+            const long long wrote = lsnRecordingAppend(file.data() + at, (long long)file.size() - at, msg.data(), (int)msg.size(), 1000 * k);
+            CHECK(wrote > (long long)msg.size(), "lsnRecordingAppend");
+            if (wrote > 0) at += wrote;
+        }
+        file.resize((size_t)at);
+        for (int variant = 0; variant < 6; variant++) {
+            std::vector<unsigned char> f = file;
+            if (variant == 1 || variant == 2) f.resize(rnd((uint32_t)f.size()));
+            if (variant >= 3)
+                for (int k = 0; k < 1 + (int)rnd(6); k++) f[rnd((uint32_t)f.size())] = (unsigned char)rnd(256);
+            long long pos = 0;
+            int frames = 0;
+            while (pos >= 0 && pos < (long long)f.size() && frames < 16) {
+                long long off = 0;
+                int flen = 0, ts = 0;
+                const long long next = lsnRecordingNext(f.data(), (long long)f.size(), pos, &off, &flen, &ts);
+                if (next < 0) break;
+                CHECK(next > pos && off >= 0 && flen >= 0 && off + flen <= (long long)f.size(), "lsnRecordingNext: record [%lld, +%d) in a file of %zu", off, flen, f.size());
+                pos = next;
+                frames++;
+            }
+            if (variant == 0) CHECK(frames == 3, "a recording of three frames read back %d", frames);
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 4;
     null_sweep();
     ragged_rigs(3 * iters);
+    parser_fuzz(20 * iters);
     {
         std::vector<std::thread> th;
         th.emplace_back(merge_thread, iters);

@@ -3,7 +3,8 @@
 tests/fake_hip builds every .hip file of the product unchanged for the host alone (clang -x hip --cuda-host-only) against a double of the
 HIP runtime -- malloc-backed device and pinned memory, synchronous streams, kernels that return plausible in-bounds counts -- once with
 -fsanitize=address,undefined and once with -fsanitize=thread, and links tests/fake_hip/soak_main.cpp: every export with NULL / zero
-arguments, then LiveScanServer's call mix from four threads at once (merge + tick-as-one-call + last-mesh stream | single-sensor calls |
+arguments, random ragged rigs from arrays of exactly the needed length, the inbound parsers (frame messages and recordings: valid, truncated,
+bit-flipped, with lying headers -- what arrives from the network and from disk), then LiveScanServer's call mix from four threads at once (merge + tick-as-one-call + last-mesh stream | single-sensor calls |
 radial export | ICP), every mesh checked, the pool of pinned blocks empty at the end.  GPU sanitizers do not exist on the pool; the lanes,
 the pinned pool, the plan tables and (new this round) the worker threads of the sharded flow are host code, and this is where a race
 or a leaked block would be.
