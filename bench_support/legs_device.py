@@ -15,15 +15,15 @@ def bench_shapes(args, torch, synth, DeviceFusion, dev, dev_index):
     rig on one GPU, 2 x 1024x1024 = its per-GPU share at 8 GPUs) and the latency case (8 x 512x424, ONE tick per call).  Per shape:
     ms per step, the write kernel's HBM fraction (HIP events inside the library) and the whole step's."""
     out = {"note": "hash-noise frames, count -> scan -> write; frac = (2 P + 19 V) bytes / time of the kernel named / 8 TB/s, step_frac = the same "
-                   "bytes / step time.  `_single_pass`: the one-tick plan made with LSN_ONE_TICK_SINGLE_PASS=1 (fuse_kernel<4>, one launch instead of "
-                   "three): no faster -- a one-tick call is launch latency plus one workgroup's load -> compute -> store chain (profiles/r05_ab_lookback.txt)"}
+                   "bytes / step time.  A one-tick plan of up to 2048 tiles takes the single pass by itself (fuse_kernel<4>: one launch); `_three_launches` is "
+                   "the same plan made with LSN_ONE_TICK_SINGLE_PASS=0 (count -> scan -> write)"}
     stream = torch.cuda.current_stream().cuda_stream
-    for name, S, w, h, T, single_pass in (("16x1024x1024_x8ticks", 16, 1024, 1024, 8, False), ("2x1024x1024_x32ticks", 2, 1024, 1024, 32, False),
-                                          ("8x512x424_x1tick", 8, 512, 424, 1, False), ("8x512x424_x1tick_single_pass", 8, 512, 424, 1, True)):
+    for name, S, w, h, T, single_pass in (("16x1024x1024_x8ticks", 16, 1024, 1024, 8, None), ("2x1024x1024_x32ticks", 2, 1024, 1024, 32, None),
+                                          ("8x512x424_x1tick", 8, 512, 424, 1, None), ("8x512x424_x1tick_three_launches", 8, 512, 424, 1, "0")):
         P = w * h
         rig = synth.make_rig("noise", S, w, h, seed=1, bounds=synth.CROP_BOUNDS)
-        if single_pass:
-            os.environ["LSN_ONE_TICK_SINGLE_PASS"] = "1"
+        if single_pass is not None:
+            os.environ["LSN_ONE_TICK_SINGLE_PASS"] = single_pass
         try:
             fus = DeviceFusion(T, [w] * S, [h] * S, device=dev_index, mode=0)
         finally:

@@ -675,7 +675,7 @@ static LsnFusion * lsnFusionCreate_impl(int device, int n_ticks, int n_maps, con
     if (const char *env = getenv("LSN_TILES_PER_RUN")) p->tiles_per_run_override = atoi(env);
     if (const char *env = getenv("LSN_NO_THRESHOLDS")) p->thr_enabled = atoi(env) == 0;
     if (const char *env = getenv("LSN_LAZY_RGB")) p->lazy_rgb = atoi(env) != 0;
-    if (const char *env = getenv("LSN_ONE_TICK_SINGLE_PASS")) p->one_tick_single_pass = atoi(env) != 0;
+
     p->n_ticks = n_ticks;
     p->n_maps = n_maps;
     std::vector<FrameDesc> fr(n_maps);
@@ -725,6 +725,9 @@ static LsnFusion * lsnFusionCreate_impl(int device, int n_ticks, int n_maps, con
     p->tick_depth_elems = doff;
     p->tick_rgb_bytes = coff;
     p->tiles_per_tick = tiles;
+    // one-tick plans of up to 2048 tiles take the single pass (run_locked); $LSN_ONE_TICK_SINGLE_PASS=0 / 1 forces the three launches / the single pass
+    p->one_tick_single_pass = n_ticks == 1 && tiles <= 2048;
+    if (const char *env = getenv("LSN_ONE_TICK_SINGLE_PASS")) p->one_tick_single_pass = atoi(env) != 0;
     p->tile_start.push_back(tiles);
     p->vec_ok = vec;
     if (doff > 0x7FFFFFFFll) {
@@ -1149,10 +1152,11 @@ int lsn::run_locked(LsnFusion *p, const void *d_depth, const void *d_colors, voi
     if (timed_launch(p) && next_event_pair(p, e0, e1)) return -1;
 
     // One-tick plans (what a live device-resident caller holds: one merge per call): count -> scan -> write is three dependent launches
-    // around ~5 us of work, the single pass one -- and measured no faster (8 x 512x424: 21.4 us per call against 20.0-21.6; 1 x 512x424, 106
-    // tiles: still 14.9 us per call, i.e. the call is launch latency + one workgroup's load -> compute -> store chain, not the look-back) and
-    // slower on big ticks (16 x 1024x1024: 90 against 60 us) -- profiles/r05_ab_lookback.txt.  So the three launches stay the default;
-    // $LSN_ONE_TICK_SINGLE_PASS=1 when the plan is created selects the single pass (A/B, bench `shapes`).
+    // around ~5 us of work -- 13.4-15.8 us per call whatever the rig, the launches' own latency -- the single pass one launch whose
+    // look-back chain grows with the tick's tiles: 1 x 512x424 (106 tiles) 7.6-8.0 us, 8 x 512x424 (848) 13.5-13.6, 2 x 1024x1024 (2048)
+    // 14.2, 16 x 1024x1024 (16384) 82 against 55 (tools/one_tick_driver.py; measured WITHOUT the kernel-timing events, whose two
+    // records per call had hidden the difference: 21.4 against 20.0-21.6, profiles/r05_ab_lookback.txt).  So a one-tick plan of up to
+    // 2048 tiles takes the single pass (lsnFusionCreate), a bigger one the three launches; $LSN_ONE_TICK_SINGLE_PASS=0 / 1 forces either.
     const bool single_pass = (p->mode == 2 && !with_pixmap && !hooks) || (p->mode == 0 && p->n_ticks == 1 && !hooks && !p->pipelined && p->one_tick_single_pass);
     if (p->mode == 0) p->timed_kernel = single_pass ? "fuse_kernel<4>" : nullptr;   // what the event pair below brackets
 

@@ -562,7 +562,7 @@ struct LsnFusion {
     lsn::DevBuf thr;
     bool thr_valid = false;
     bool thr_enabled = true;             // $LSN_NO_THRESHOLDS=1 keeps the arithmetic count pass (ablation / tests)
-    bool one_tick_single_pass = false;   // $LSN_ONE_TICK_SINGLE_PASS=1: a one-tick plan takes the single pass (fuse_kernel<4>) instead of count -> scan -> write (A/B)
+    bool one_tick_single_pass = false;   // a one-tick plan of <= 2048 tiles takes the single pass (fuse_kernel<4>) instead of count -> scan -> write; $LSN_ONE_TICK_SINGLE_PASS=0 / 1 forces
     bool lazy_rgb = true;                // the write pass loads colours only where a lane kept a pixel; $LSN_LAZY_RGB=0 loads them with the depth (ablation)
     int runs_with_params = 0;
     std::vector<float> last_intr, last_wt;
