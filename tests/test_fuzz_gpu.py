@@ -137,11 +137,11 @@ def test_random_rig_matches_the_oracle(gpu, orc, seed):
 
 @pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_random_ticks_device_resident(gpu, orc, seed):
-    """lsnFusionRadialCorrectTo -> lsnFusionRunMesh on 2-5 DIFFERENT ticks of a random rig (the host exports above run one tick per
+    """lsnFusionRadialCorrectTo -> lsnFusionRunMesh on 1-5 DIFFERENT ticks of a random rig (the host exports above run one tick per
     call): every tick's corrected maps, cloud, offsets and triangles against the oracle."""
     import torch
     rng = np.random.default_rng(5000 + seed)
-    T = int(rng.integers(2, 6))
+    T = int(rng.integers(1, 6))                                 # (one tick: the plan takes the single pass by itself)
     rigs = [_random_rig(np.random.default_rng(7000 + seed))]
     sizes = list(zip(rigs[0].widths.tolist(), rigs[0].heights.tolist()))
     for k in range(1, T):                                    # the same calibration and sizes, other frames
