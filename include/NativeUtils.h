@@ -324,7 +324,9 @@ typedef struct LsnIcp LsnIcp;
 LsnIcp *lsnIcpCreate(int device, int max_n1, int max_n2);
 void lsnIcpDestroy(LsnIcp *icp);
 
-/* nn_mode: 0 = LDS-tiled brute force, 1 = voxel grid (exact; falls back to brute force per query when needed).
+/* nn_mode: 0 = brute force (one query per lane, the targets streamed through scalar loads; the ablation leg),
+ *          1 = voxel grid (exact at any distance: near path per query + box hierarchy per group of 64 queries; when a work
+ *              list overflows, the complete hierarchy walk per group).  Both give the same bits.
  * d_verts1: n1*3 floats (target), d_verts2: n2*3 floats (source, moved in place), d_R 9 floats, d_t 3 floats
  * (in/out, device).  Asynchronous on `stream`; no host synchronisation inside the iteration loop. */
 int lsnIcpRun(LsnIcp *icp, const float *d_verts1, int n1, float *d_verts2, int n2, float *d_R, float *d_t,
@@ -341,6 +343,13 @@ int lsnIcpNearest(LsnIcp *icp, const float *d_verts1, int n1, const float *d_ver
  * (:382-410, the C# loops as written); Rs_out (n x 9) / Ts_out (n x 3), nullable, receive the accumulated ICP poses. */
 int lsnRefine(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
               float *world_R, float *world_t, float *Rs_out, float *Ts_out);
+
+/* How many queries of the workspace's last voxel-grid NN step were settled by the near path (the walk over the cells around
+ * a query whose bound is small; diagnostic, synchronises `stream`; -1 on error).  $LSN_ICP_NEAR (read by lsnIcpCreate):
+ * 0 = the path off, every query goes through the group search; 1 (default) = the unseeded step always probes, a seeded step takes
+ * the path when at least half of the previous step's queries lay within one target cell of their neighbour; 2 = always.
+ * $LSN_ICP_NEAR_PTS: the candidate cap per query (<= 128).  Speed only: all settings give the same bits. */
+int lsnIcpNearResolved(LsnIcp *icp, void *stream);
 
 /* Optional phase timing of lsnIcpRun (measurement aid): with profiling on, every lsnIcpRun records HIP events on its stream;
  * lsnIcpProfile synchronises `stream` and returns the milliseconds of the last run in ms4 = {grid build + source sort,

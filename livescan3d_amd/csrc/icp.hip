@@ -70,6 +70,10 @@ struct IcpState {
     // clouds barely move between iterations, so the next matrix is almost diagonalised by them); v_valid is cleared at the
     // start of every lsnIcpRun, which keeps a call's result independent of what the workspace ran before
     int v_valid;
+    // the next seeded NN step takes the near path: set by accum_kernel when at least half of this step's queries lie within one
+    // target cell edge of their neighbour (below that the walk costs the step more than the shorter group search gives back:
+    // configs[1], 18 % settled, +6 us per iteration; configs[2], 98 %, -26 us).  A matter of speed only: the results are the same bits.
+    int near_next;
     double Vprev[9];
 };
 
@@ -552,8 +556,8 @@ __device__ __forceinline__ void scan_points(const float4 *__restrict__ sorted, i
 //   nn_scan_kernel    one wave per item: 64 queries x the range's points through LDS, packed f32; the lexicographic
 //                     (distance, index) minimum is merged into the query's 64-bit key with atomicMin
 //   nn_finish_kernel  one thread per query: index / distance out (original order) + the one-to-one claim
-// Without seeds (first ICP iteration, lsnIcpNearest) nn_seedless_kernel first emits the blocks nearest to each group as
-// scan items; their minima are the seeds.
+// Without seeds (first ICP iteration, lsnIcpNearest) nn_probe_kernel first lets every query look around its own cell and emits
+// the blocks nearest to the queries that found nothing as scan items; their minima are the seeds.
 //
 // Exactness: a query's key only ever takes (distance, index) pairs of real target points, and a box is passed over only
 // when no query of the group can need it: the group test opens a box when boxbox_min_dist2(W, box) <= max_l bound_l,
@@ -570,9 +574,10 @@ __device__ __forceinline__ void scan_points(const float4 *__restrict__ sorted, i
 constexpr unsigned long long kNoKey = 0x7F8000007FFFFFFFull;  // (+inf, no index)
 
 struct GroupInfo {  // per query group, written by nn_cull_kernel
-    float wlx, wly, wlz, whx, why, whz;  // W: the box of the group's queries
-    float rmax;                          // largest bound in the group (-1: nobody searches)
+    float wlx, wly, wlz, whx, why, whz;  // W: the box of the group's queries that still search
+    float rmax;                          // largest bound among them (-1: nobody searches)
     int pad;
+    unsigned long long resolved;         // lanes whose key is already final (the near path below): they open no box
 };
 
 constexpr int kSegs = 64;        // the work lists are cut into 64 segments with a counter each: an append is one atomicAdd per
@@ -717,26 +722,190 @@ __device__ void wave_search(const GridParams *__restrict__ gp, const float4 *__r
     }
 }
 
-// No seeds yet: every query's key starts empty, and the kSeedBlocks blocks nearest to the group's box (inside the nearest
-// super-block) become scan items; what they yield seeds the real search (any real point bounds it).
-__global__ __launch_bounds__(kThreads) void nn_seedless_kernel(const float4 *__restrict__ src, int n2, const GridParams *__restrict__ gp,
-                                                               const Box *__restrict__ boxes, const Box *__restrict__ supers,
-                                                               unsigned long long *best_key, NnWork wk, int bank)
+// ---------------------------------------------------------------------------------------------------------------------
+// The NEAR PATH: a query that knows a REAL target point near it walks the target grid's cells around it by itself -- a
+// handful of candidates instead of its group's ~800 -- and its key is final.  What the kd-tree does for such a query
+// (include/nanoflann.h:1200-1247: the leaf the query falls in and the few leaves its ball touches), with the grid's cells
+// as the leaves.  Two forms:
+//   seeded (nn_cull_kernel<true>)  the bound B is the f32 squared distance of the query's previous neighbour; the cells the ball
+//                                  of B touches are walked, and the result is final;
+//   probe (nn_probe_kernel)        no bound yet: the 27 cells around the query's own cell are walked; the result is final when
+//                                  the ball of the best distance found stays inside those cells, a seed for the group search otherwise.
+//
+// Exactness.  dist2 = fl(fl(fl(d0*d0) + fl(d1*d1)) + fl(d2*d2)), d_a = fl(q_a - p_a).  Every term is >= 0 and rounding is
+// monotone, so fl(d_a*d_a) <= dist2 for each axis.  With r such that fl(r*r) > B (checked, not assumed), any p with
+// dist2(q, p) <= B has |d_a| < r on every axis; fl(q_a - p_a) is off from q_a - p_a by <= 2^-24 relative, so
+// |q_a - p_a| < r (1 + 2^-23), and with r2 = r * 1.0001 + |q_a| * 2.4e-7 the f32 values lo = fl(q_a - r2), hi = fl(q_a + r2)
+// satisfy lo <= p_a <= hi (the two margins cover the roundings of r2 and of the subtraction / addition).  cell_coord is
+// monotone in its first argument (an f32 subtraction of o, a multiplication by inv_h > 0, floor, clamp), and it is the
+// very function -- same GridParams -- that binned the targets: every such p lies in a cell of
+// [cell(lo), cell(hi)]^3.  A walk over a box of cells that contains those takes (d < best) or (d == best and a lower index)
+// starting from (B, that real point's index): the result is the lexicographic (distance, index) minimum over ALL targets,
+// like the hierarchy's.  A target with a NaN coordinate never wins anywhere (its distance is NaN).  The path is taken only
+// when the box spans <= kNearSpan cells per axis and holds <= max_pts points; everything else goes through the query
+// groups below.
+//
+// Work split (measured, EXPERIMENTS.md R6-1: a lane -- or a team of 4 / 8 lanes -- walking its query's cells alone leaves the launch
+// waiting for the few workgroups whose queries sit in crowded cells: 9-15 us of walk at the 95th percentile against 0.2 us at the
+// median): the workgroup is one query group and shares ALL its candidates out evenly.  Wave 0 prepares the 64 queries (lane =
+// query); a team of 4 consecutive lanes per query fetches the cell ranges of the box's runs (a row of cells along x is one run
+// of consecutive cell indices inside a 4-cell block row, two when it crosses into the next block) and appends them to the
+// workgroup's list in LDS as chunks of <= 8 consecutive points; then every thread takes chunks from that list -- eight
+// loads in flight per chunk -- and merges the chunk's (distance, index) minimum into its query's key with
+// a 64-bit LDS atomicMin (the lexicographic minimum: distances are >= +0, so their bit patterns order like their values).
+constexpr int kNearSpan = 3;
+constexpr int kNearRows = kNearSpan * kNearSpan;
+constexpr int kNearRuns = 2 * kNearRows;     // runs per query at most
+constexpr int kTeam = 4;                     // lanes per query in the team phase; the workgroup is 64 x kTeam threads
+constexpr int kCullThreads = 64 * kTeam;
+constexpr int kChunkPts = 8;                 // points per chunk = loads in flight per thread and chunk
+constexpr int kNearCapMax = 128;             // largest candidate cap per query
+constexpr int kMaxChunks = 64 * (kNearCapMax / kChunkPts + kNearRuns);   // a run of n points is ceil(n / 8) chunks
+
+#ifdef LSN_CULL_STAMPS   // dev aid: per-workgroup clock stamps of nn_cull_kernel<true> (tools/cull_stamps.py)
+__device__ long long g_cull_stamps[8 * 8192];
+#define LSN_STAMP(i) do { if (APPLY && threadIdx.x == 0 && blockIdx.x < 8192) g_cull_stamps[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define LSN_STAMP(i) do { } while (0)
+#endif
+
+struct NearBox {   // a query's box of cells (inclusive), filled by lane = query, read by its team
+    int xl, xh, yl, yh, zl, zh;
+    int want;      // the query takes the near path (after near_enqueue: and its box held <= the cap)
+    int pad;
+};
+
+struct NearShared {   // LDS of one query group
+    float4 q[64];              // x, y, z, bound
+    unsigned long long key[64];
+    NearBox box[64];
+    int flag[64];              // seeded: resolved; probe: bit 0 resolved, bit 1 has a key
+    int n_chunks;
+    int2 chunks[kMaxChunks];   // (first point, query | points << 8)
+};
+
+__device__ __forceinline__ bool near_radius(float B, const GridParams &g, float &r)
 {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    const int j = g * 64 + lane;
-    if (g * 64 >= n2) return;  // wave-uniform
-    const bool active = j < n2;
-    float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
-    if (active) {
-        q4 = src[j];
-        best_key[j] = kNoKey;
+    r = fmaxf(sqrtf(B) * 1.00001f, 1e-18f);
+    return r * r > B && r < 1e18f && g.inv_h > 0.0f && g.inv_h < INFINITY;
+}
+
+__device__ __forceinline__ void near_axis(float q, float r, float o, float inv_h, int n, int &lo, int &hi)
+{
+    const float r2 = r * 1.0001f + fabsf(q) * 2.4e-7f;
+    lo = cell_coord(q - r2, o, inv_h, n);
+    hi = cell_coord(q + r2, o, inv_h, n);
+}
+
+// lane = query: the cells the ball of B around q touches; want = it is small enough for the near path
+__device__ __forceinline__ NearBox near_ball_box(const GridParams &g, bool want, float qx, float qy, float qz, float B)
+{
+    NearBox b = {0, 0, 0, 0, 0, 0, 0, 0};
+    float r;
+    if (want && near_radius(B, g, r)) {
+        near_axis(qx, r, g.ox, g.inv_h, g.nx, b.xl, b.xh);
+        near_axis(qy, r, g.oy, g.inv_h, g.ny, b.yl, b.yh);
+        near_axis(qz, r, g.oz, g.inv_h, g.nz, b.zl, b.zh);
+        b.want = b.xh - b.xl < kNearSpan && b.yh - b.yl < kNearSpan && b.zh - b.zl < kNearSpan;
     }
-    const bool part = active && finite3(q4.x, q4.y, q4.z);
-    if (!__ballot(part)) return;
-    const float wlx = wave_min_f(part ? q4.x : INFINITY), wly = wave_min_f(part ? q4.y : INFINITY), wlz = wave_min_f(part ? q4.z : INFINITY);
-    const float whx = wave_max_f(part ? q4.x : -INFINITY), why = wave_max_f(part ? q4.y : -INFINITY), whz = wave_max_f(part ? q4.z : -INFINITY);
+    return b;
+}
+
+// Team phase (all kCullThreads threads; thread = (query ql, lane sub of its team); sh.n_chunks is zero and the boxes are in LDS):
+// the runs of the query's box become chunks of the workgroup's list when the box holds <= max_pts (<= kNearCapMax) points;
+// sh.box[ql].want says so afterwards.
+template <bool PROBE>
+__device__ __forceinline__ void near_enqueue(NearShared &sh, const GridParams &g, const int *__restrict__ cell_start, int max_pts, int ql, int sub)
+{
+    constexpr int kMine = (kNearRuns + kTeam - 1) / kTeam;
+    const NearBox bx = sh.box[ql];
+    bool want = bx.want != 0;
+    if (!__ballot(want)) return;   // wave-uniform
+    const int xb = min(bx.xh, bx.xl | 3);
+    const bool two = bx.xh > xb;
+    const int nyr = bx.yh - bx.yl + 1, n_rows = nyr * (bx.zh - bx.zl + 1);
+    const int n_runs = want ? (two ? 2 * n_rows : n_rows) : 0;
+    int s[kMine], e[kMine];
+    int total = 0;
+#pragma unroll
+    for (int m = 0; m < kMine; m++) {
+        const int k = sub + m * kTeam;
+        s[m] = e[m] = 0;
+        if (k < n_runs) {
+            const int row = two ? k >> 1 : k;
+            const bool second = two && (k & 1);
+            const int dz = (row >= nyr) + (row >= 2 * nyr), dy = row - dz * nyr;
+            const int c = cell_index(second ? xb + 1 : bx.xl, bx.yl + dy, bx.zl + dz, g);
+            s[m] = cell_start[c];
+            e[m] = cell_start[c + (second ? bx.xh - xb : xb - bx.xl + 1)];
+        }
+        total += e[m] - s[m];
+    }
+#pragma unroll
+    for (int off = 1; off < kTeam; off <<= 1) total += __shfl_xor(total, off, 64);
+    const bool fits = total <= min(max_pts, kNearCapMax);
+    // a crowded box: left to the group search; the probe still takes a few of its points -- any real point is a seed (want = 2)
+    if (want && !fits && sub == 0) sh.box[ql].want = PROBE ? 2 : 0;
+    if (PROBE && want && !fits && e[0] > s[0]) {
+        const int base = atomicAdd(&sh.n_chunks, 1);
+        sh.chunks[base] = make_int2(s[0], ql | (min(kChunkPts, e[0] - s[0]) << 8));
+    }
+    want = want && fits;
+#pragma unroll
+    for (int m = 0; m < kMine; m++) {
+        const int n = want ? (e[m] - s[m] + kChunkPts - 1) / kChunkPts : 0;
+        if (n > 0) {
+            const int base = atomicAdd(&sh.n_chunks, n);   // <= kMaxChunks in total: every query's runs hold <= kNearCapMax points
+            for (int c = 0; c < n; c++) {
+                const int j = s[m] + kChunkPts * c;
+                sh.chunks[base + c] = make_int2(j, ql | (min(kChunkPts, e[m] - j) << 8));
+            }
+        }
+    }
+}
+
+// All threads, behind a barrier: the workgroup's chunks; sh.key[q] ends as the lexicographic minimum of
+// its start value and every point of the query's box.
+__device__ __forceinline__ void near_consume(NearShared &sh, const float4 *__restrict__ sorted)
+{
+    const int n = sh.n_chunks;
+    auto fetch = [&](int2 ck, float4 (&p)[kChunkPts]) {
+#pragma unroll
+        for (int u = 0; u < kChunkPts; u++)
+            if (u < (ck.y >> 8)) p[u] = sorted[ck.x + u];
+    };
+    auto merge = [&](int2 ck, const float4 (&p)[kChunkPts]) {
+        const int q = ck.y & 63, cnt = ck.y >> 8;
+        const float4 qq = sh.q[q];
+        float b = INFINITY;
+        int bi = 0x7FFFFFFF;
+#pragma unroll
+        for (int u = 0; u < kChunkPts; u++) {
+            const float d = dist2(qq.x, qq.y, qq.z, p[u].x, p[u].y, p[u].z);
+            const int i = __float_as_int(p[u].w);
+            const bool take = (u < cnt) & ((d < b) | ((d == b) & (i < bi)));   // NaN: never
+            b = take ? d : b;
+            bi = take ? i : bi;
+        }
+        const unsigned long long key = pack_key(b, bi);
+        if (cnt > 0 && b < INFINITY && key < sh.key[q]) atomicMin(&sh.key[q], key);
+    };
+    for (int c = threadIdx.x; c < n; c += kCullThreads) {
+        const int2 ck = sh.chunks[c];
+        float4 p[kChunkPts];
+        fetch(ck, p);
+        merge(ck, p);
+    }
+}
+
+// The kSeedBlocks blocks nearest to the box W of a group's queries (inside the nearest super-block) become scan items of the seed
+// round; what they yield seeds the real search (any real point bounds it).  One wave, lane = query; `need`: the lane takes part.
+__device__ __forceinline__ void emit_seed_blocks(const GridParams *__restrict__ gp, const Box *__restrict__ boxes, const Box *__restrict__ supers,
+                                                 const NnWork &wk, int bank, int g, int lane, bool need, float qx, float qy, float qz)
+{
+    if (!__ballot(need)) return;
+    const float wlx = wave_min_f(need ? qx : INFINITY), wly = wave_min_f(need ? qy : INFINITY), wlz = wave_min_f(need ? qz : INFINITY);
+    const float whx = wave_max_f(need ? qx : -INFINITY), why = wave_max_f(need ? qy : -INFINITY), whz = wave_max_f(need ? qz : -INFINITY);
     const int n_supers = gp->ncells / 4096;
     float m_best = INFINITY;
     int s_best = 0;
@@ -766,87 +935,193 @@ __global__ __launch_bounds__(kThreads) void nn_seedless_kernel(const float4 *__r
     emit_ranges(wk, wk.counters + kBankInts * bank, kCntSeed, g, g, (chosen >> lane) & 1, __float_as_int(bb.pad0), __float_as_int(bb.pad1), lane);
 }
 
-// One wave per query group.  APPLY: first move the group's queries by the previous iteration's (T, Rn) -- icp.cpp:143-146 +
-// :165: v = (v + T) * Rn, row vectors, f32, one rounding per operation -- in the sorted working copy and in the caller's
-// array (same three floats at the query's original position), and clear the match keys for this iteration's claims.
-// Then: the query's seed (its previous neighbour's distance from where the query is now; without seed_targets the key the
-// seed round left), the group's box and largest bound, and one (group, super-block) item per super-block the group may need.
-template <bool APPLY>
-__global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *verts2, int n2, const IcpState *st, unsigned long long *keys,
-                                                           int n_keys, const GridParams *__restrict__ gp, const Box *__restrict__ supers,
-                                                           const float *__restrict__ seed_targets, int n1, const int *idx,
-                                                           unsigned long long *best_key, GroupInfo *groups, NnWork wk, int bank)
+// No seeds yet (first ICP iteration, lsnIcpNearest).  One workgroup per query group.  Every query's key starts empty; the probe
+// (near_pts > 0) walks the 27 cells around the query's own cell: a query whose best find's ball stays inside them is settled
+// (groups[g].resolved, read by nn_cull_kernel<false>), any other find is the query's seed.  When some query of the group still has
+// no key, the blocks nearest to those queries become scan items of the seed round.
+__global__ __launch_bounds__(kCullThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) void nn_probe_kernel(const float4 *__restrict__ src, int n2, const GridParams *__restrict__ gp,
+                                                                const Box *__restrict__ boxes, const Box *__restrict__ supers,
+                                                                unsigned long long *best_key, GroupInfo *groups, NnWork wk, int bank,
+                                                                const int *__restrict__ cell_start, const float4 *__restrict__ sorted, int near_pts)
 {
-    if (APPLY)
-        for (int k = blockIdx.x * kThreads + threadIdx.x; k < n_keys; k += gridDim.x * kThreads) keys[k] = ~0ull;
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    const int j = g * 64 + lane;
-    if (g * 64 >= n2) return;  // wave-uniform
-    const bool active = j < n2;
-    float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
-    if (active) q4 = src[j];
-    const int orig = __float_as_int(q4.w);
-    if (APPLY && active && st->mk > 0) {
-        const float x = q4.x + st->T[0], y = q4.y + st->T[1], z = q4.z + st->T[2];
-        q4.x = x * st->Rn[0] + y * st->Rn[3] + z * st->Rn[6];
-        q4.y = x * st->Rn[1] + y * st->Rn[4] + z * st->Rn[7];
-        q4.z = x * st->Rn[2] + y * st->Rn[5] + z * st->Rn[8];
-        src[j] = q4;
-        const size_t o = 3 * (size_t)orig;
-        verts2[o] = q4.x;
-        verts2[o + 1] = q4.y;
-        verts2[o + 2] = q4.z;
-    }
-    const float qx = q4.x, qy = q4.y, qz = q4.z;
-    const bool part = active && finite3(qx, qy, qz);
-    unsigned long long key = kNoKey;
-    if (seed_targets) {
-        if (part) {
-            const int k = idx[j];   // the sorted-order copy of the previous neighbours (nn_finish_kernel): loaded together with src[j]
-            if ((unsigned int)k < (unsigned int)n1) {
-                const float d = dist2(qx, qy, qz, seed_targets[3 * (size_t)k], seed_targets[3 * (size_t)k + 1], seed_targets[3 * (size_t)k + 2]);
-                if (d == d) key = pack_key(d, k);  // not NaN
-            }
+    __shared__ NearShared sh;
+    const int g = blockIdx.x;
+    if (g * 64 >= n2) return;  // workgroup-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const GridParams grid = *gp;
+    if (wave == 0) {
+        const int j = g * 64 + lane;
+        float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
+        if (j < n2) q4 = src[j];
+        const bool part = j < n2 && finite3(q4.x, q4.y, q4.z);
+        NearBox b = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (near_pts > 0 && part && grid.inv_h > 0.0f && grid.inv_h < INFINITY) {
+            const int cx = cell_coord(q4.x, grid.ox, grid.inv_h, grid.nx), cy = cell_coord(q4.y, grid.oy, grid.inv_h, grid.ny),
+                      cz = cell_coord(q4.z, grid.oz, grid.inv_h, grid.nz);
+            b.xl = max(cx - 1, 0); b.xh = min(cx + 1, grid.nx - 1);
+            b.yl = max(cy - 1, 0); b.yh = min(cy + 1, grid.ny - 1);
+            b.zl = max(cz - 1, 0); b.zh = min(cz + 1, grid.nz - 1);
+            b.want = 1;
         }
-        if (active) best_key[j] = key;
-    } else if (active) {
-        key = best_key[j];
+        sh.q[lane] = make_float4(q4.x, q4.y, q4.z, part ? 0.0f : -1.0f);
+        sh.box[lane] = b;
+        sh.flag[lane] = 0;
+        sh.key[lane] = kNoKey;
+        if (lane == 0) sh.n_chunks = 0;
     }
-    const float bound = part ? key_dist(key) : -1.0f;  // a lane outside the search never opens a box
+    __syncthreads();
+    if (near_pts > 0) {
+        near_enqueue<true>(sh, grid, cell_start, near_pts, threadIdx.x / kTeam, threadIdx.x % kTeam);
+        __syncthreads();
+        near_consume(sh, sorted);
+        __syncthreads();
+        if (wave == 0 && sh.box[lane].want && sh.key[lane] != kNoKey) {
+            // final when every target within the distance found lies in a cell that was walked
+            const float4 q = sh.q[lane];
+            const NearBox w = sh.box[lane];
+            const NearBox n = near_ball_box(grid, true, q.x, q.y, q.z, key_dist(sh.key[lane]));
+            const bool done = n.want && n.xl >= w.xl && n.xh <= w.xh && n.yl >= w.yl && n.yh <= w.yh && n.zl >= w.zl && n.zh <= w.zh;
+            sh.flag[lane] = done && w.want == 1 ? 3 : 2;
+        }
+    }
+    if (wave != 0) return;
+    const int j = g * 64 + lane;
+    const float4 me = sh.q[lane];
+    const int flag = sh.flag[lane];
+    if (j < n2) best_key[j] = sh.key[lane];
+    const unsigned long long resolved = __ballot((flag & 1) != 0);
+    if (lane == 0) {
+        GroupInfo gi = {0, 0, 0, 0, 0, 0, -1.0f, 0, resolved};   // the rest is nn_cull_kernel<false>'s to fill
+        groups[g] = gi;
+    }
+    emit_seed_blocks(gp, boxes, supers, wk, bank, g, lane, me.w >= 0.0f && !(flag & 2), me.x, me.y, me.z);
+}
+
+// One workgroup of 64 x kTeam threads per query group.
+// Phase A, wave 0 with lane = query: (APPLY) move the query by the previous iteration's (T, Rn) -- icp.cpp:143-146 + :165:
+// v = (v + T) * Rn, row vectors, f32, one rounding per operation -- in the sorted working copy and in the caller's array (same
+// three floats at the query's original position); the query's seed (its previous neighbour's distance from where the query is
+// now; without seed_targets the key the probe / the seed round left) and the cells its ball touches.  All threads (APPLY): clear
+// the match keys for this iteration's claims.  The team phases: the near path (seeded form; after a probe its verdicts are
+// taken from groups[g].resolved instead).  Phase B, every wave with lane = query: the box and the largest bound of the queries
+// that still search, and one (group, super-block) item per super-block they may need -- the waves share out the chunks of
+// super-blocks.
+template <bool APPLY>
+__global__ __launch_bounds__(kCullThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) void nn_cull_kernel(float4 *src, float *verts2, int n2, const IcpState *st, unsigned long long *keys,
+                                                               int n_keys, const GridParams *__restrict__ gp, const Box *__restrict__ supers,
+                                                               const float *__restrict__ seed_targets, int n1, const int *idx,
+                                                               unsigned long long *best_key, GroupInfo *groups, NnWork wk, int bank,
+                                                               const int *__restrict__ cell_start, const float4 *__restrict__ sorted, int near_arg)
+{
+    __shared__ NearShared sh;
+    // near_arg: 0 = no near path; n > 0 = candidate cap n, seeded steps when the previous step said so (st->near_next); n < 0 = cap -n, always
+    const int near_pts = near_arg < 0 ? -near_arg : (!APPLY || st->near_next ? near_arg : 0);
+    if (APPLY)
+        for (int k = blockIdx.x * kCullThreads + threadIdx.x; k < n_keys; k += gridDim.x * kCullThreads) keys[k] = ~0ull;
+    const int g = blockIdx.x;
+    if (g * 64 >= n2) return;  // workgroup-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LSN_STAMP(0);
+    const GridParams grid = *gp;
+    if (wave == 0) {
+        const int j = g * 64 + lane;
+        const bool active = j < n2;
+        float4 q4 = make_float4(NAN, NAN, NAN, 0.0f);
+        if (active) q4 = src[j];
+        const int orig = __float_as_int(q4.w);
+        if (APPLY && active && st->mk > 0) {
+            const float x = q4.x + st->T[0], y = q4.y + st->T[1], z = q4.z + st->T[2];
+            q4.x = x * st->Rn[0] + y * st->Rn[3] + z * st->Rn[6];
+            q4.y = x * st->Rn[1] + y * st->Rn[4] + z * st->Rn[7];
+            q4.z = x * st->Rn[2] + y * st->Rn[5] + z * st->Rn[8];
+            src[j] = q4;
+            const size_t o = 3 * (size_t)orig;
+            verts2[o] = q4.x;
+            verts2[o + 1] = q4.y;
+            verts2[o + 2] = q4.z;
+        }
+        const float qx = q4.x, qy = q4.y, qz = q4.z;
+        const bool part = active && finite3(qx, qy, qz);
+        unsigned long long key = kNoKey;
+        bool settled = false;   // by the probe
+        if (seed_targets) {
+            if (part) {
+                const int k = idx[j];   // the sorted-order copy of the previous neighbours (nn_finish_kernel): loaded together with src[j]
+                if ((unsigned int)k < (unsigned int)n1) {
+                    const float d = dist2(qx, qy, qz, seed_targets[3 * (size_t)k], seed_targets[3 * (size_t)k + 1], seed_targets[3 * (size_t)k + 2]);
+                    if (d == d) key = pack_key(d, k);  // not NaN
+                }
+            }
+        } else {
+            if (active) key = best_key[j];
+            settled = near_pts > 0 && ((groups[g].resolved >> lane) & 1);
+        }
+        const float B = key_dist(key);
+        sh.q[lane] = make_float4(qx, qy, qz, part && !settled ? B : -1.0f);
+        sh.key[lane] = key;
+        sh.box[lane] = near_ball_box(grid, seed_targets && near_pts > 0 && part && B < INFINITY, qx, qy, qz, B);
+        sh.flag[lane] = settled;
+        if (lane == 0) sh.n_chunks = 0;
+        LSN_STAMP(1);
+    }
+    __syncthreads();
+    LSN_STAMP(2);
+    if (seed_targets && near_pts > 0) {
+        near_enqueue<false>(sh, grid, cell_start, near_pts, threadIdx.x / kTeam, threadIdx.x % kTeam);
+        __syncthreads();
+        LSN_STAMP(3);
+        near_consume(sh, sorted);
+        __syncthreads();
+        LSN_STAMP(4);
+        if (wave == 0 && sh.box[lane].want) {   // the walk covered the ball of the bound: the key is final
+            sh.q[lane].w = -1.0f;
+            sh.flag[lane] = 1;
+        }
+        __syncthreads();
+    }
+    const float4 me = sh.q[lane];
+    if (wave == 0 && seed_targets && g * 64 + lane < n2) best_key[g * 64 + lane] = sh.key[lane];
+    const bool search = me.w >= 0.0f;   // (a bound is a squared distance or +inf)
     GroupInfo gi;
-    gi.wlx = wave_min_f(part ? qx : INFINITY); gi.wly = wave_min_f(part ? qy : INFINITY); gi.wlz = wave_min_f(part ? qz : INFINITY);
-    gi.whx = wave_max_f(part ? qx : -INFINITY); gi.why = wave_max_f(part ? qy : -INFINITY); gi.whz = wave_max_f(part ? qz : -INFINITY);
-    gi.rmax = wave_max_f(bound);
+    gi.wlx = wave_min_f(search ? me.x : INFINITY); gi.wly = wave_min_f(search ? me.y : INFINITY); gi.wlz = wave_min_f(search ? me.z : INFINITY);
+    gi.whx = wave_max_f(search ? me.x : -INFINITY); gi.why = wave_max_f(search ? me.y : -INFINITY); gi.whz = wave_max_f(search ? me.z : -INFINITY);
+    gi.rmax = wave_max_f(me.w);
     gi.pad = 0;
-    if (lane == 0) groups[g] = gi;
+    gi.resolved = __ballot(sh.flag[lane] != 0);
+    if (threadIdx.x == 0) groups[g] = gi;
+    LSN_STAMP(5);
     if (!(gi.rmax >= 0.0f)) return;
-    const int n_supers = gp->ncells / 4096;
+    const int n_supers = grid.ncells / 4096;
     int *cnt = wk.counters + kBankInts * bank;
-    // two passes over the super-block boxes (count, then write) so that the append costs the wave ONE atomicAdd; the boxes of
+    // two passes over the wave's super-block boxes (count, then write) so that the append costs the wave ONE atomicAdd; the boxes of
     // four chunks (256 super-blocks) are loaded at once: one memory round trip per four chunks instead of one per chunk
     auto chunk_dist = [&](int c0, float (&m)[4]) {
-        Box b[4];
+        float4 lo[4];   // lx, ly, lz, hx
+        float2 hi[4];   // hy, hz (the two spare words of a super-block's box stay where they are)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int sl = c0 + 64 * k + lane;
-            if (sl < n_supers) b[k] = supers[sl];
+            if (sl < n_supers) {
+                lo[k] = *reinterpret_cast<const float4 *>(&supers[sl].lx);
+                hi[k] = *reinterpret_cast<const float2 *>(&supers[sl].hy);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int sl = c0 + 64 * k + lane;
-            m[k] = sl < n_supers ? boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, b[k]) : INFINITY;
+            const Box b = {lo[k].x, lo[k].y, lo[k].z, lo[k].w, hi[k].x, hi[k].y, 0.0f, 0.0f};
+            m[k] = sl < n_supers ? boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, b) : INFINITY;
         }
     };
     int total = 0;
-    for (int c0 = 0; c0 < n_supers; c0 += 256) {
+    for (int c0 = 256 * wave; c0 < n_supers; c0 += 256 * kTeam) {
         float m[4];
         chunk_dist(c0, m);
 #pragma unroll
         for (int k = 0; k < 4; k++) total += __popcll(__ballot(m[k] <= gi.rmax && m[k] < INFINITY));
     }
     if (total == 0) return;
-    const int seg = g & (kSegs - 1);
+    const int seg = (g + wave) & (kSegs - 1);
     int base = 0;
     if (lane == 0) base = atomicAdd(cnt + seg * kSegStride + kCntA, total);
     base = __shfl(base, 0, 64);
@@ -855,7 +1130,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *v
         return;
     }
     uint2 *out = wk.list_a + (size_t)seg * wk.seg_a + base;
-    for (int c0 = 0; c0 < n_supers; c0 += 256) {
+    for (int c0 = 256 * wave; c0 < n_supers; c0 += 256 * kTeam) {
         float m[4];
         chunk_dist(c0, m);
 #pragma unroll
@@ -866,6 +1141,7 @@ __global__ __launch_bounds__(kThreads) void nn_cull_kernel(float4 *src, float *v
             out += __popcll(mask);
         }
     }
+    LSN_STAMP(6);
 }
 
 // One wave per (group, super-block) item: the super-block's 64 blocks, one per lane, against the group's box, then each
@@ -892,7 +1168,7 @@ __global__ __launch_bounds__(64) void nn_blocks_kernel(const float4 *__restrict_
         float bound = -1.0f;
         if (j < n2) {
             q4 = src[j];
-            if (finite3(q4.x, q4.y, q4.z)) bound = key_dist(best_key[j]);
+            if (finite3(q4.x, q4.y, q4.z) && !((gi.resolved >> lane) & 1)) bound = key_dist(best_key[j]);
         }
         const float mb = boxbox_min_dist2(gi.wlx, gi.wly, gi.wlz, gi.whx, gi.why, gi.whz, bb);
         unsigned long long cand = __ballot(mb <= gi.rmax && mb < INFINITY);
@@ -1081,24 +1357,29 @@ __device__ __forceinline__ bool is_winner(const unsigned long long *keys, const 
 }
 
 // pass 1: m = number of one-to-one matches, the sum of their squared distances and the sum of the squares of those
+// (fourth sum, for the next step's choice of path: the queries within one target cell edge of their neighbour; gp null: brute force)
 __global__ __launch_bounds__(kThreads) void stats_kernel(const int *idx, const float *dist, const unsigned long long *keys, int n2,
-                                                         double *part /* [blocks][4]: count, sum d, sum d^2, - */)
+                                                         const GridParams *gp, double *part /* [blocks][4]: count, sum d, sum d^2, near */)
 {
-    __shared__ double lds[4 * 3];
-    double v[3] = {0, 0, 0};
+    __shared__ double lds[4 * 4];
+    const float h2 = gp ? gp->h * gp->h : -1.0f;
+    double v[4] = {0, 0, 0, 0};
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n2; i += gridDim.x * kThreads) {
+        const float df = dist[i];
+        if (df <= h2) v[3] += 1.0;
         if (is_winner(keys, idx, i)) {
-            const double d = (double)dist[i];
+            const double d = (double)df;
             v[0] += 1.0;
             v[1] += d;
             v[2] += d * d;
         }
     }
-    block_sum_d<3>(v, lds);
-    if (threadIdx.x < 3) {
+    block_sum_d<4>(v, lds);
+    if (threadIdx.x < 4) {
         double out = v[0];
         if (threadIdx.x == 1) out = v[1];
         if (threadIdx.x == 2) out = v[2];
+        if (threadIdx.x == 3) out = v[3];
         part[blockIdx.x * 4 + threadIdx.x] = out;
     }
 }
@@ -1114,8 +1395,8 @@ __global__ __launch_bounds__(kThreads) void accum_kernel(const float *verts1, co
 {
     __shared__ double lds[4 * 16];
     __shared__ double red[kThreads + 4];
-    double s1[3];
-    reduce_partials<3, 4>(part1, n_part1, s1, red);
+    double s1[4];
+    reduce_partials<4, 4>(part1, n_part1, s1, red);
     const float mean = (float)(s1[1] / s1[0]);
     const float m_f = (float)(int)s1[0];
     const double dev = s1[2] - 2.0 * (double)mean * s1[1] + s1[0] * (double)mean * (double)mean;
@@ -1128,6 +1409,7 @@ __global__ __launch_bounds__(kThreads) void accum_kernel(const float *verts1, co
         st->mean = mean;
         st->stddev = sd;
         st->thresh = thresh;
+        st->near_next = 2.0 * s1[3] >= (double)n2;
     }
     double v[16];
 #pragma unroll
@@ -1380,6 +1662,9 @@ struct LsnIcp {
     size_t n_events = 0;
     int trace_iters = 0;
     bool seed_nn = true;   // $LSN_ICP_NO_SEED=1 turns the previous-neighbour seeding off (ablation)
+    int near_mode = 1;     // $LSN_ICP_NEAR: 0 = no near path, 1 = the probe always, seeded steps when the previous step's distances say it pays, 2 = always
+    int near_pts = 128;    // the near path's candidate cap per query (<= kNearCapMax); $LSN_ICP_NEAR=0 turns the path off (A/B, tests), $LSN_ICP_NEAR_PTS sets the cap
+    int last_groups = 0;   // query groups of the last grid NN step (lsnIcpNearResolved)
     std::mutex mu;
 };
 
@@ -1399,6 +1684,8 @@ static LsnIcp * lsnIcpCreate_impl(int device, int max_n1, int max_n2)
     w->max_n1 = max_n1;
     w->max_n2 = max_n2;
     if (const char *e2 = getenv("LSN_ICP_NO_SEED")) w->seed_nn = atoi(e2) == 0;
+    if (const char *e3 = getenv("LSN_ICP_NEAR_PTS")) w->near_pts = std::max(1, std::min(kNearCapMax, atoi(e3)));
+    if (const char *e4 = getenv("LSN_ICP_NEAR")) w->near_mode = std::max(0, std::min(2, atoi(e4)));
     const char *env = getenv("LSN_ICP_CELL");
     if (env) w->cell_override = (float)atof(env);
     bool bad = false;
@@ -1518,13 +1805,14 @@ static int build_grid(LsnIcp *w, GridBufs &g, const float *d_pts, int n, bool wi
     hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, s, w->bbox_part.as<float>(), nb, n, w->cell_override, gp);
     if (!g.counts_clear) LSN_HIP(hipMemsetAsync(g.cell_cnt.p, 0, sizeof(int) * (size_t)kMaxCells, s));
     g.counts_clear = false;   // dirty until the scatter below has been enqueued
-    hipLaunchKernelGGL(cell_count_kernel, dim3(nb), dim3(kThreads), 0, s, d_pts, n, gp, g.cell_of.as<int>(), g.cell_cnt.as<int>());
+    const int nall = std::max(1, blocks_for(n));   // one point per thread: a capped grid makes every thread a chain of dependent rounds
+    hipLaunchKernelGGL(cell_count_kernel, dim3(nall), dim3(kThreads), 0, s, d_pts, n, gp, g.cell_of.as<int>(), g.cell_cnt.as<int>());
     const int sb = kMaxCells / kScanBlock;  // 1024
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sb), dim3(kThreads), 0, s, g.cell_cnt.as<int>(), gp, w->block_sums.as<int>());
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, w->block_sums.as<int>(), sb);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(sb + 1), dim3(kThreads), 0, s, g.cell_cnt.as<int>(), gp, w->block_sums.as<int>(),
                        g.cell_start.as<int>());
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(kThreads), 0, s, d_pts, n, g.cell_of.as<int>(), g.cell_start.as<int>(),
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nall), dim3(kThreads), 0, s, d_pts, n, g.cell_of.as<int>(), g.cell_start.as<int>(),
                        g.cell_cnt.as<int>(), g.sorted.as<float4>());
     LSN_HIP(hipGetLastError());   // (a failed launch leaves counts_clear false: the next build clears them again)
     g.counts_clear = true;
@@ -1578,11 +1866,12 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
     const GridParams *gp = w->tgt.gp.as<GridParams>();
     const float4 *sorted = w->tgt.sorted.as<float4>();
     const Box *boxes = w->tgt.boxes.as<Box>(), *supers = w->tgt.supers.as<Box>();
+    const int *cell_start = w->tgt.cell_start.as<int>();
     unsigned long long *best_key = w->best_key.as<unsigned long long>();
     GroupInfo *groups = w->groups.as<GroupInfo>();
+    w->last_groups = (n2 + 63) / 64;
     const NnWork wk = work_of(w);
     const int n_groups = (n2 + 63) / 64;
-    const dim3 per_group((n_groups + kThreads / 64 - 1) / (kThreads / 64));
     // consumer launches (one wave per workgroup, a multiple of 64 of them): a seeded group needs ~3-5 super-blocks and ~5-8
     // point ranges; longer lists are served by looping.  Waves without an item leave after one load.
     // waves per query group of the two list consumers.  The scan list of a seeded step holds ~6 (configs[1]) to ~11 (configs[2]) items
@@ -1592,13 +1881,16 @@ static int run_nn(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int
     static const int block_waves = getenv("LSN_ICP_BLOCK_WAVES") ? std::max(1, atoi(getenv("LSN_ICP_BLOCK_WAVES"))) : 8;
     const dim3 blocks_grid(64 * ((block_waves * n_groups + 63) / 64)), scan_grid(64 * ((scan_waves * n_groups + 63) / 64));
     if (seeded) {
-        hipLaunchKernelGGL(nn_cull_kernel<true>, per_group, dim3(kThreads), 0, s, src, d_verts2, n2, st, keys, n1, gp, supers, d_verts1, n1,
-                           (const int *)w->idx_sorted.as<int>(), best_key, groups, wk, bank);
+        hipLaunchKernelGGL(nn_cull_kernel<true>, dim3(n_groups), dim3(kCullThreads), 0, s, src, d_verts2, n2, st, keys, n1, gp, supers, d_verts1, n1,
+                           (const int *)w->idx_sorted.as<int>(), best_key, groups, wk, bank, cell_start, sorted,
+                           w->near_mode == 0 ? 0 : (w->near_mode == 2 ? -w->near_pts : w->near_pts));
     } else {
-        hipLaunchKernelGGL(nn_seedless_kernel, per_group, dim3(kThreads), 0, s, (const float4 *)src, n2, gp, boxes, supers, best_key, wk, bank);
+        hipLaunchKernelGGL(nn_probe_kernel, dim3(n_groups), dim3(kCullThreads), 0, s, (const float4 *)src, n2, gp, boxes, supers, best_key, groups, wk, bank,
+                           cell_start, sorted, w->near_mode == 0 ? 0 : w->near_pts);
         hipLaunchKernelGGL(nn_scan_kernel, scan_grid, dim3(64), 0, s, (const float4 *)src, n2, sorted, best_key, wk, bank, kCntSeed);
-        hipLaunchKernelGGL(nn_cull_kernel<false>, per_group, dim3(kThreads), 0, s, src, (float *)nullptr, n2, (const IcpState *)nullptr,
-                           (unsigned long long *)nullptr, 0, gp, supers, (const float *)nullptr, n1, (const int *)nullptr, best_key, groups, wk, bank);
+        hipLaunchKernelGGL(nn_cull_kernel<false>, dim3(n_groups), dim3(kCullThreads), 0, s, src, (float *)nullptr, n2, (const IcpState *)nullptr,
+                           (unsigned long long *)nullptr, 0, gp, supers, (const float *)nullptr, n1, (const int *)nullptr, best_key, groups, wk, bank,
+                           cell_start, sorted, w->near_mode == 0 ? 0 : w->near_pts);
     }
     hipLaunchKernelGGL(nn_blocks_kernel, blocks_grid, dim3(64), 0, s, (const float4 *)src, n2, boxes,
                        (const unsigned long long *)best_key, (const GroupInfo *)groups, wk, bank);
@@ -1705,7 +1997,7 @@ static int lsnIcpRun_impl(LsnIcp *w, const float *d_verts1, int n1, float *d_ver
         if (run_nn(w, d_verts1, n1, d_verts2, n2, w->idx.as<int>(), w->dist.as<float>(), keys, nn_mode, s, fused, st, iter & 1)) return -1;
         mark(w, 1, s);
         hipLaunchKernelGGL(stats_kernel, dim3(nb), dim3(kThreads), 0, s, w->idx.as<int>(), w->dist.as<float>(), keys, n2,
-                           w->part1.as<double>());
+                           nn_mode != 0 ? (const GridParams *)w->tgt.gp.as<GridParams>() : (const GridParams *)nullptr, w->part1.as<double>());
         hipLaunchKernelGGL(accum_kernel, dim3(nb), dim3(kThreads), 0, s, d_verts1, (const float *)d_verts2, w->idx.as<int>(),
                            w->dist.as<float>(), keys, n2, w->part1.as<double>(), nb, w->part3.as<double>(), st);
         hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(kThreads), 0, s, w->part3.as<double>(), nb, d_R, d_t, st,
@@ -1724,6 +2016,34 @@ extern "C" int lsnIcpRun(LsnIcp *w, const float *d_verts1, int n1, float *d_vert
 {
     return lsn::guarded<int>("lsnIcpRun", static_cast<int>(-1), [&]() { return lsnIcpRun_impl(w, d_verts1, n1, d_verts2, n2, d_R, d_t, maxIter, nn_mode, stream); });
 }
+
+// How many queries of the last voxel-grid NN step the near path settled (diagnostic: synchronises `stream`, reads the groups' masks back).
+static int lsnIcpNearResolved_impl(LsnIcp *w, void *stream)
+{
+    lsn::clear_error();
+    if (!w) return -1;
+    std::lock_guard<std::mutex> g(w->mu);
+    LSN_HIP(hipSetDevice(w->device));
+    LSN_HIP(hipStreamSynchronize(lsn::as_stream(stream)));
+    std::vector<GroupInfo> gi((size_t)w->last_groups);
+    if (w->last_groups > 0) LSN_HIP(hipMemcpy(gi.data(), w->groups.p, sizeof(GroupInfo) * gi.size(), hipMemcpyDeviceToHost));
+    long long n = 0;
+    for (const GroupInfo &x : gi) n += __builtin_popcountll(x.resolved);
+    return (int)n;
+}
+
+extern "C" int lsnIcpNearResolved(LsnIcp *w, void *stream)
+{
+    return lsn::guarded<int>("lsnIcpNearResolved", static_cast<int>(-1), [&]() { return lsnIcpNearResolved_impl(w, stream); });
+}
+
+#ifdef LSN_CULL_STAMPS
+extern "C" int lsnDevCullStamps(long long *out, int n_blocks)
+{
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cull_stamps), sizeof(long long) * 8 * (size_t)(n_blocks < 8192 ? n_blocks : 8192)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 static int lsnIcpTrace_impl(LsnIcp *w, float *out, int max_iters, void *stream)
 {

@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libNativeUtils.so")
+# $LSN_NATIVE_LIB: another build of the same library (development A/Bs); the default is the in-tree build
+LIB_PATH = os.environ.get("LSN_NATIVE_LIB") or os.path.join(_HERE, "lib", "libNativeUtils.so")
 
 VERTEX_DTYPE = np.dtype([("R", "u1"), ("G", "u1"), ("B", "u1"), ("A", "u1"),
                          ("X", "<f4"), ("Y", "<f4"), ("Z", "<f4")])  # VertexC4ubV3f, 16 bytes
@@ -27,7 +28,7 @@ EXPORTS = [
     "lsnFusionTilesPerTick", "lsnFusionPackSurvivors", "lsnFusionReconstruct",
     "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
     "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardPrepare", "lsnShardConnect", "lsnShardRcclPath", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent", "lsnShardRanksSeen",
-    "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnRefine",
+    "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnIcpNearResolved", "lsnRefine",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnTransferLastPath", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
     "lsnZstdAvailable", "lsnFrameParseHeader", "lsnFrameDecode", "lsnFrameEncode", "lsnRecordingNext", "lsnRecordingAppend",
@@ -207,6 +208,9 @@ def lib():
     L.lsnIcpSetProfiling.argtypes = [vp, C.c_int]
     L.lsnIcpProfile.restype = C.c_int
     L.lsnIcpProfile.argtypes = [vp, vp, vp]
+    if hasattr(L, "lsnIcpNearResolved"):   # (absent from an older build loaded through $LSN_NATIVE_LIB)
+        L.lsnIcpNearResolved.restype = C.c_int
+        L.lsnIcpNearResolved.argtypes = [vp, vp]
     ll = C.c_longlong
     L.lsnTransferCreate.restype = vp
     L.lsnTransferCreate.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -677,6 +681,13 @@ class IcpWorkspace:
         if lib().lsnIcpProfile(self._h, _ptr(ms), stream) < 0:
             raise NativeUtilsError(f"lsnIcpProfile failed: {last_error()}")
         return {"build": float(ms[0]), "nn": float(ms[1]), "match_reduce_solve": float(ms[2]), "final_apply": float(ms[3])}
+
+    def near_resolved(self, stream=0):
+        """Queries of the last voxel-grid NN step that the near path settled (diagnostic; synchronises the stream)."""
+        n = lib().lsnIcpNearResolved(self._h, stream)
+        if n < 0:
+            raise NativeUtilsError(f"lsnIcpNearResolved failed: {last_error()}")
+        return int(n)
 
     def trace(self, max_iters, stream=0):
         out = np.zeros((max(max_iters, 1), 16), dtype=np.float32)

@@ -119,6 +119,100 @@ def test_nn_list_overflow_falls_back_to_the_complete_walk(gpu, orc, monkeypatch)
     assert np.abs(got_v - ref_v).max() <= TOL
 
 
+def _near_cases(orc):
+    """Clouds that exercise the near path's corners: where the bound is tiny, zero, at a cell edge, far from the origin."""
+    rng = np.random.default_rng(21)
+    clouds = _scene_clouds(orc, 3, 256, 212)
+    base = rng.uniform(-1, 1, size=(6000, 3)).astype(np.float32)
+    lattice = (np.stack(np.meshgrid(np.arange(24), np.arange(24), np.arange(8), indexing="ij"), -1).reshape(-1, 3) * 0.0625).astype(np.float32)
+    cases = {
+        "overlapping surfaces": (clouds[1], clouds[0]),
+        "merged target": (np.concatenate([clouds[1], clouds[2]]), clouds[0]),
+        "source = target (bound 0)": (base, base.copy()),
+        "source = target + 1e-4 noise": (base, base + rng.normal(scale=1e-4, size=base.shape).astype(np.float32)),
+        "source = target + 2e-2 noise": (base, base + rng.normal(scale=2e-2, size=base.shape).astype(np.float32)),
+        "duplicated targets, queries on them (ties -> lowest index)": (np.repeat(base[:1500], 4, axis=0), base[:1500].copy()),
+        "lattice, queries at cell-edge midpoints (exact ties)": (lattice, lattice[::3] + np.float32(0.03125)),
+        "lattice shuffled": (lattice[rng.permutation(len(lattice))], lattice[::2] + np.array([0.03125, 0, 0], np.float32)),
+        "far from the origin (|q| >> r)": (base * 0.01 + 1000.0, base[:4000] * 0.01 + 1000.0 + rng.normal(scale=1e-4, size=(4000, 3)).astype(np.float32)),
+        "huge coordinates": (base * 1e6, base[:3000] * 1e6 + rng.normal(scale=10.0, size=(3000, 3)).astype(np.float32)),
+        "tiny coordinates": (base * 1e-12, base[:3000] * 1e-12),
+        "flat target": ((base * [1, 1, 0]).astype(np.float32), (base[:3000] * [1, 1, 0]).astype(np.float32) + np.array([0, 0, 1e-3], np.float32)),
+        "one cell holds everything + outlier": (np.concatenate([base[:3000] * 1e-3, [[50, 50, 50]]]).astype(np.float32), (base[:2000] * 1e-3).astype(np.float32)),
+    }
+    t = base[:5000].copy(); q = t[:3000] + rng.normal(scale=1e-3, size=(3000, 3)).astype(np.float32)
+    t[7] = [np.nan, 0, 0]; t[4000] = [np.inf, 1, 1]; t[123, 2] = -np.inf
+    cases["non-finite targets beside near queries"] = (t, q)
+    return cases
+
+
+def test_near_path_gives_the_group_searchs_bits(gpu, orc, monkeypatch):
+    """The near path (a query with a small bound walks the grid cells around it, icp.hip near_search) against the same step with
+    the path off ($LSN_ICP_NEAR=0: every query through the box hierarchy), against the brute force and against the oracle:
+    indices and squared distances bit for bit -- and the path did settle queries in every case (lsnIcpNearResolved)."""
+    import torch
+    for name, (t, q) in _near_cases(orc).items():
+        t = np.ascontiguousarray(t, np.float32); q = np.ascontiguousarray(q, np.float32)
+        outs = {}
+        for near in ("2", "0"):
+            monkeypatch.setenv("LSN_ICP_NEAR", near)
+            ws = native.IcpWorkspace(0, len(t), len(q))
+            td, qd = torch.from_numpy(t).cuda(), torch.from_numpy(q).cuda()
+            idx = torch.full((len(q),), -7, dtype=torch.int32, device="cuda"); d2 = torch.zeros(len(q), dtype=torch.float32, device="cuda")
+            st = int(torch.cuda.current_stream().cuda_stream)
+            ws.nearest(td.data_ptr(), len(t), qd.data_ptr(), len(q), idx.data_ptr(), d2.data_ptr(), native.NN_GRID, st)
+            outs[near] = (idx.cpu().numpy().astype(np.int64), d2.cpu().numpy(), ws.near_resolved(st))
+            ws.close()
+        monkeypatch.delenv("LSN_ICP_NEAR")
+        assert outs["0"][2] == 0, name
+        if name.startswith("one cell"):
+            assert outs["2"][2] == 0, name          # 3000 candidates in the query's cell: over the cap, left to the group search
+        elif name.startswith(("tiny", "non-finite")):
+            pass                                    # degenerate grids (an infinite box; a cell edge clamped at extent / 4): crowded cells, cap decides
+        else:
+            assert outs["2"][2] > 0, f"{name}: the near path settled nothing"
+        assert np.array_equal(outs["2"][0], outs["0"][0]) and np.array_equal(outs["2"][1].view(np.uint32), outs["0"][1].view(np.uint32)), name
+        bi, bd = _gpu_nn(t, q, native.NN_BRUTE)
+        assert np.array_equal(outs["2"][0], bi) and np.array_equal(outs["2"][1].view(np.uint32), bd.view(np.uint32)), name
+        want_i, want_d = orc.nn(t, q, mode="brute", n_threads=8)
+        ok = np.isfinite(q).all(axis=1)
+        assert np.array_equal(outs["2"][0][ok], want_i[ok]) and np.array_equal(outs["2"][1][ok].view(np.uint32), want_d[ok].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("cap", ["1", "7", "100000"])
+def test_near_path_candidate_caps(gpu, orc, monkeypatch, cap):
+    """$LSN_ICP_NEAR_PTS: whatever the cap hands to the group search, the bits stay."""
+    monkeypatch.setenv("LSN_ICP_NEAR_PTS", cap)
+    clouds = _scene_clouds(orc, 2, 256, 212)
+    want_i, want_d = orc.nn(clouds[0], clouds[1], mode="kdtree", n_threads=8)
+    got_i, got_d = _gpu_nn(clouds[0], clouds[1], native.NN_GRID)
+    assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)) and np.array_equal(got_i, want_i)
+
+
+def test_icp_runs_identically_with_and_without_the_near_path(gpu, orc, monkeypatch):
+    """A whole lsnIcpRun (seeded iterations: the bound is the previous neighbour's distance) with the near path forced, chosen
+    per step by the library (the default) and off: the moved cloud, R, t and every iteration's trace bit-identical; forced, the
+    last step settled a good part of the queries."""
+    import torch
+    clouds = _scene_clouds(orc, 3, 256, 212)
+    tgt, src = np.concatenate(clouds[1:]), clouds[0]
+    outs = {}
+    for near in ("2", "1", "0"):
+        monkeypatch.setenv("LSN_ICP_NEAR", near)
+        v1 = torch.from_numpy(tgt).cuda(); v2 = torch.from_numpy(src.copy()).cuda()
+        Rt = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device="cuda")
+        ws = native.IcpWorkspace(0, len(tgt), len(src))
+        st = int(torch.cuda.current_stream().cuda_stream)
+        ws.run(v1.data_ptr(), len(tgt), v2.data_ptr(), len(src), Rt.data_ptr(), Rt.data_ptr() + 36, 8, native.NN_GRID, st)
+        outs[near] = (v2.cpu().numpy(), Rt.cpu().numpy(), ws.trace(8, st), ws.near_resolved(st))
+        ws.close()
+    monkeypatch.delenv("LSN_ICP_NEAR")
+    assert outs["0"][3] == 0 and outs["2"][3] > len(src) // 4 and outs["1"][3] in (0, outs["2"][3])
+    for near in ("2", "1"):
+        for k in range(3):
+            assert np.array_equal(outs[near][k].view(np.uint32), outs["0"][k].view(np.uint32)), (near, k)
+
+
 def test_nn_non_finite_points_do_not_derail_the_search(gpu, orc):
     """NaN / inf coordinates in either cloud: the finite queries still get their exact neighbour among the comparable targets,
     the others an index in range (they take no part in the culling), and nothing hangs."""

@@ -29,5 +29,7 @@ for rep in range(int(os.environ.get("ICP_REPS", "3"))):
     e1.record()
     torch.cuda.synchronize()
     print("n1", n1, "n2", n2, "ms/iter", e0.elapsed_time(e1) / 10)
+if hasattr(native.lib(), "lsnIcpNearResolved"):
+    print("near path settled", ws.near_resolved(int(torch.cuda.current_stream().cuda_stream)), "of", n2, "queries in the last step")
 tr = ws.trace(10)
 print("matched/kept per iter:", [(int(t[0]), int(t[1])) for t in tr])
