@@ -270,30 +270,52 @@ __global__ __launch_bounds__(64) void grid_setup_kernel(const float *part, int n
     gp->n_points = n_points;
 }
 
-__global__ __launch_bounds__(kThreads) void cell_count_kernel(const float *pts, int n, const GridParams *gp, int *cell_of,
+// One point per thread: its cell and its rank inside the cell (the value the cell's counter had: cell_scatter_kernel then needs no
+// atomics).  Consecutive points of a cloud are raster neighbours and mostly share a cell, so a run of equal cells among the wave's
+// lanes costs ONE atomicAdd (measured on configs[2]'s 738 k targets: an atomic per point 47 us, per run see EXPERIMENTS.md R6-1).
+__global__ __launch_bounds__(kThreads) void cell_count_kernel(const float *pts, int n, const GridParams *gp, int *cell_of, int *rank_of,
                                                               int *cell_cnt)
 {
     const GridParams g = *gp;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-        int cx = cell_coord(pts[3 * (size_t)i], g.ox, g.inv_h, g.nx);
-        int cy = cell_coord(pts[3 * (size_t)i + 1], g.oy, g.inv_h, g.ny);
-        int cz = cell_coord(pts[3 * (size_t)i + 2], g.oz, g.inv_h, g.nz);
-        int c = cell_index(cx, cy, cz, g);
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int c = -1 - lane;   // past the end: a run of its own, no atomic
+    if (i < n) {
+        const int cx = cell_coord(pts[3 * (size_t)i], g.ox, g.inv_h, g.nx);
+        const int cy = cell_coord(pts[3 * (size_t)i + 1], g.oy, g.inv_h, g.ny);
+        const int cz = cell_coord(pts[3 * (size_t)i + 2], g.oz, g.inv_h, g.nz);
+        c = cell_index(cx, cy, cz, g);
+    }
+    const int prev = __shfl_up(c, 1, 64);
+    const unsigned long long starts = __ballot(lane == 0 || c != prev);
+    const int first = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));                 // the run's first lane (<= lane)
+    const unsigned long long later = lane == 63 ? 0ull : starts & (~0ull << (lane + 1));
+    const int end = later ? __ffsll((long long)later) - 1 : 64;                                    // one past the run's last lane
+    int base = 0;
+    if (lane == first && c >= 0) base = atomicAdd(&cell_cnt[c], end - first);
+    base = __shfl(base, first, 64);
+    if (i < n) {
         cell_of[i] = c;
-        atomicAdd(&cell_cnt[c], 1);
+        rank_of[i] = base + (lane - first);
     }
 }
 
 // exclusive scan of cell_cnt[0..ncells) into cell_start[0..ncells], three small kernels over the fixed capacity
+// (ncells is a multiple of 16^3 = kScanBlock: a scan block lies inside the grid or outside it)
 __global__ __launch_bounds__(kThreads) void scan_block_sums_kernel(const int *cnt, const GridParams *gp, int *block_sums)
 {
     __shared__ int lds[4];
     const int ncells = gp->ncells;
     const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
     int s = 0;
+    if (blockIdx.x * kScanBlock < ncells) {
+        const int4 *v = reinterpret_cast<const int4 *>(cnt + base);
 #pragma unroll
-    for (int k = 0; k < kScanItems; k++)
-        if (base + k < ncells) s += cnt[base + k];
+        for (int k = 0; k < kScanItems / 4; k++) {
+            const int4 a = v[k];
+            s += (a.x + a.y) + (a.z + a.w);
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
@@ -324,13 +346,20 @@ __global__ __launch_bounds__(kThreads) void scan_finish_kernel(const int *cnt, c
     __shared__ int lds[4];
     const int ncells = gp->ncells;
     const int base = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
-    if (blockIdx.x * kScanBlock > ncells) return;
+    if (blockIdx.x * kScanBlock >= ncells) {
+        if (blockIdx.x * kScanBlock == ncells && threadIdx.x == 0) cell_start[ncells] = block_sums[blockIdx.x];   // = n_points
+        return;
+    }
     int v[kScanItems];
     int s = 0;
+    {
+        const int4 *v4 = reinterpret_cast<const int4 *>(cnt + base);
 #pragma unroll
-    for (int k = 0; k < kScanItems; k++) {
-        v[k] = (base + k < ncells) ? cnt[base + k] : 0;
-        s += v[k];
+        for (int k = 0; k < kScanItems / 4; k++) {
+            const int4 a = v4[k];
+            v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
+            s += (a.x + a.y) + (a.z + a.w);
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = s;
@@ -344,21 +373,26 @@ __global__ __launch_bounds__(kThreads) void scan_finish_kernel(const int *cnt, c
     int pre = block_sums[blockIdx.x];
     for (int w = 0; w < wave; w++) pre += lds[w];
     int run = pre + incl - s;
+    int4 *o4 = reinterpret_cast<int4 *>(cell_start + base);
 #pragma unroll
-    for (int k = 0; k < kScanItems; k++) {
-        if (base + k <= ncells) cell_start[base + k] = run;  // also writes cell_start[ncells] = n_points
-        run += v[k];
+    for (int k = 0; k < kScanItems / 4; k++) {
+        int4 o;
+        o.x = run; run += v[4 * k];
+        o.y = run; run += v[4 * k + 1];
+        o.z = run; run += v[4 * k + 2];
+        o.w = run; run += v[4 * k + 3];
+        o4[k] = o;
     }
 }
 
-__global__ __launch_bounds__(kThreads) void cell_scatter_kernel(const float *pts, int n, const int *cell_of, const int *cell_start,
+__global__ __launch_bounds__(kThreads) void cell_scatter_kernel(const float *pts, int n, const int *cell_of, const int *rank_of, const int *cell_start,
                                                                 int *cell_cnt, float4 *sorted)
 {
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-        const int c = cell_of[i];
-        const int slot = cell_start[c] + atomicSub(&cell_cnt[c], 1) - 1;  // counts run back down to zero
-        sorted[slot] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], __int_as_float(i));
-    }
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_of[i];
+    sorted[cell_start[c] + rank_of[i]] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], __int_as_float(i));
+    cell_cnt[c] = 0;   // every touched counter back to zero (plain stores of the same value): one memset per workspace, not per build
 }
 
 // ---- nearest neighbour ----------------------------------------------------------------------------------------
@@ -1626,13 +1660,14 @@ __global__ __launch_bounds__(kThreads) void run_init_kernel(unsigned long long *
 
 // One voxel grid over a cloud: the cell-sorted copy (x, y, z, original index) and, for a target, the box hierarchy.
 struct GridBufs {
-    lsn::DevBuf gp, cell_of, cell_cnt, cell_start, sorted, boxes, supers;
-    bool counts_clear = false;   // cell_cnt is all zero (cell_scatter_kernel runs every count back down to zero: one memset per workspace, not per build)
+    lsn::DevBuf gp, cell_of, rank_of, cell_cnt, cell_start, sorted, boxes, supers;
+    bool counts_clear = false;   // cell_cnt is all zero (cell_scatter_kernel writes every touched count back to zero: one memset per workspace, not per build)
     int reserve(int max_n, bool with_boxes)
     {
         int bad = 0;
         bad |= gp.reserve(sizeof(GridParams));
         bad |= cell_of.reserve(sizeof(int) * (size_t)max_n);
+        bad |= rank_of.reserve(sizeof(int) * (size_t)max_n);
         bad |= cell_cnt.reserve(sizeof(int) * (size_t)kMaxCells);
         bad |= cell_start.reserve(sizeof(int) * ((size_t)kMaxCells + kScanBlock));
         bad |= sorted.reserve(sizeof(float4) * (size_t)max_n);
@@ -1806,13 +1841,13 @@ static int build_grid(LsnIcp *w, GridBufs &g, const float *d_pts, int n, bool wi
     if (!g.counts_clear) LSN_HIP(hipMemsetAsync(g.cell_cnt.p, 0, sizeof(int) * (size_t)kMaxCells, s));
     g.counts_clear = false;   // dirty until the scatter below has been enqueued
     const int nall = std::max(1, blocks_for(n));   // one point per thread: a capped grid makes every thread a chain of dependent rounds
-    hipLaunchKernelGGL(cell_count_kernel, dim3(nall), dim3(kThreads), 0, s, d_pts, n, gp, g.cell_of.as<int>(), g.cell_cnt.as<int>());
+    hipLaunchKernelGGL(cell_count_kernel, dim3(nall), dim3(kThreads), 0, s, d_pts, n, gp, g.cell_of.as<int>(), g.rank_of.as<int>(), g.cell_cnt.as<int>());
     const int sb = kMaxCells / kScanBlock;  // 1024
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(sb), dim3(kThreads), 0, s, g.cell_cnt.as<int>(), gp, w->block_sums.as<int>());
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, w->block_sums.as<int>(), sb);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(sb + 1), dim3(kThreads), 0, s, g.cell_cnt.as<int>(), gp, w->block_sums.as<int>(),
                        g.cell_start.as<int>());
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nall), dim3(kThreads), 0, s, d_pts, n, g.cell_of.as<int>(), g.cell_start.as<int>(),
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nall), dim3(kThreads), 0, s, d_pts, n, g.cell_of.as<int>(), g.rank_of.as<int>(), g.cell_start.as<int>(),
                        g.cell_cnt.as<int>(), g.sorted.as<float4>());
     LSN_HIP(hipGetLastError());   // (a failed launch leaves counts_clear false: the next build clears them again)
     g.counts_clear = true;
