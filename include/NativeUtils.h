@@ -340,7 +340,9 @@ int lsnIcpNearest(LsnIcp *icp, const float *d_verts1, int n1, const float *d_ver
  * call: Gauss-Seidel over the sensors x n_refine_iters, each step ICP(all other sensors' current clouds, this sensor's
  * cloud, Rs[i], Ts[i], n_icp_iters), with every cloud resident in HBM for the whole pass.  clouds[i] = counts[i] x 3 floats
  * on the HOST, moved in place; world_R (n x 9) / world_t (n x 3), nullable, are updated like worldTransforms[i]
- * (:382-410, the C# loops as written); Rs_out (n x 9) / Ts_out (n x 3), nullable, receive the accumulated ICP poses. */
+ * (:382-410, the C# loops as written); Rs_out (n x 9) / Ts_out (n x 3), nullable, receive the accumulated ICP poses.
+ * The pass's device state (ICP workspace, cloud buffers, stream) is kept for the next call on the same device (grown when a
+ * rig needs more); a pass that runs while another is in flight allocates its own and frees it again. */
 int lsnRefine(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
               float *world_R, float *world_t, float *Rs_out, float *Ts_out);
 

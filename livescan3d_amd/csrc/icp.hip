@@ -2101,6 +2101,30 @@ extern "C" int lsnIcpTrace(LsnIcp *w, float *out, int max_iters, void *stream)
 // n_sensors x n_refine_iters ICP calls; here each cloud goes up once and comes back once.  The pose composition at the
 // end repeats the C# loops literally, including their in-place update of worldTransforms[i].R while later rows still
 // read it (:398-406).
+struct RefineState {   // what a refine pass keeps on the device between calls
+    std::mutex mu;
+    int device = -1;
+    LsnIcp *ws = nullptr;
+    hipStream_t s = nullptr;
+    lsn::DevBuf d_all, d_others, d_Rt;
+    void drop()
+    {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (ws) lsnIcpDestroy(ws);
+        ws = nullptr;
+        if (s) (void)hipStreamDestroy(s);
+        s = nullptr;
+        d_all.release(); d_others.release(); d_Rt.release();
+    }
+    ~RefineState() { drop(); }
+};
+
+static RefineState &refine_state()
+{
+    static RefineState *st = new RefineState();   // never destroyed: no HIP calls from static destructors at process exit
+    return *st;
+}
+
 static int lsnRefine_impl(int device, int n_sensors, float *const *clouds, const int *counts, int n_refine_iters, int n_icp_iters,
                          float *world_R, float *world_t, float *Rs_out, float *Ts_out)
 {
@@ -2126,11 +2150,23 @@ static int lsnRefine_impl(int device, int n_sensors, float *const *clouds, const
     const bool runnable = n_sensors >= 2 && min_n > 0 && total - min_n <= 0x7FFFFFFFll && n_refine_iters > 0 && n_icp_iters > 0;
     if (runnable) {
         LSN_HIP(hipSetDevice(device));
-        hipStream_t s = nullptr;
-        LSN_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        lsn::DevBuf d_all, d_others, d_Rt;
-        LsnIcp *ws = lsnIcpCreate(device, (int)(total - min_n), max_n);
-        int rc = ws ? 0 : -1;
+        // the pass's device state (workspace, cloud buffers, stream) is kept between calls: allocating it was 2-3 ms of a 20 ms pass.
+        // A second pass running at the same time gets a state of its own.
+        RefineState *rs = &refine_state();
+        std::unique_lock<std::mutex> hold(rs->mu, std::try_to_lock);
+        RefineState own;
+        if (!hold.owns_lock()) rs = &own;
+        const int need1 = (int)(total - min_n), need2 = max_n;
+        if (rs->ws && (rs->device != device || rs->ws->max_n1 < need1 || rs->ws->max_n2 < need2)) rs->drop();
+        if (!rs->ws) {
+            rs->device = device;
+            rs->ws = lsnIcpCreate(device, need1, need2);
+        }
+        int rc = rs->ws ? 0 : -1;
+        if (!rc && !rs->s) rc = hipStreamCreateWithFlags(&rs->s, hipStreamNonBlocking) != hipSuccess;
+        hipStream_t s = rs->s;
+        LsnIcp *ws = rs->ws;
+        lsn::DevBuf &d_all = rs->d_all, &d_others = rs->d_others, &d_Rt = rs->d_Rt;
         if (!rc) rc = d_all.reserve(sizeof(float) * 3 * (size_t)total) || d_others.reserve(sizeof(float) * 3 * (size_t)(total - min_n)) ||
                       d_Rt.reserve(sizeof(float) * Rt.size());
         std::vector<long long> off(n_sensors + 1, 0);
@@ -2156,11 +2192,11 @@ static int lsnRefine_impl(int device, int n_sensors, float *const *clouds, const
         std::vector<float> back((size_t)total * 3);
         if (!rc) rc = hipMemcpyAsync(back.data(), d_all.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess;
         if (!rc) rc = hipMemcpyAsync(Rt.data(), d_Rt.p, sizeof(float) * Rt.size(), hipMemcpyDeviceToHost, s) != hipSuccess;
-        if (!rc) rc = hipStreamSynchronize(s) != hipSuccess;
-        if (ws) lsnIcpDestroy(ws);
-        (void)hipStreamDestroy(s);
+        if (!rc && s) rc = hipStreamSynchronize(s) != hipSuccess;
         if (rc) {
             if (!lsn::has_error()) lsn::set_error("lsnRefine: %s", hipGetErrorString(hipGetLastError()));
+            if (s) (void)hipStreamSynchronize(s);
+            rs->drop();   // nothing of a failed pass is kept
             return -1;
         }
         for (int i = 0; i < n_sensors; i++) memcpy(clouds[i], back.data() + 3 * off[i], sizeof(float) * 3 * (size_t)counts[i]);
