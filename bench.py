@@ -211,6 +211,24 @@ def main():
             sync()
             repeats.append(B * args.steps / (time.perf_counter() - t0))
 
+    # the outputs behind `value`, checked after the timed region: ticks 0, B/2 - 1 and B - 1 of the last step's merged clouds + offsets against
+    # the oracle's merge of the same frames (both resident input sets hold the same frames); N > 1: the merged cloud of the WHOLE rig on rank 0
+    verified = None
+    if rank == 0 and not args.no_cpu:
+        from bench_support.verify import verify_clouds
+        check_ticks = sorted({0, max(0, B // 2 - 1), B - 1})
+        if multi:
+            m_v, m_o = ex.merged_cloud()
+            frames = [synth.noise_frames_torch(dev, 1, 1, S, w, h, tick0=t) for t in range(B) if t in check_ticks]
+            d_chk = torch.zeros((B, S * P), dtype=torch.int16, device=dev)
+            c_chk = torch.zeros((B, S * P * 3), dtype=torch.uint8, device=dev)
+            for t, (dd, cc) in zip(check_ticks, frames):
+                d_chk[t], c_chk[t] = dd.view(-1), cc.view(-1)
+            verified = verify_clouds(torch, d_chk, c_chk, m_v, m_o, check_ticks, [w] * S, [h] * S, intr_all, wt_all, bounds)
+            del d_chk, c_chk
+        else:
+            verified = verify_clouds(torch, depth, rgb, fus.vertices, fus.offsets, check_ticks, [w] * S_loc, [h] * S_loc, cx.intr_loc, cx.wt_loc, bounds)
+
     # algorithmic bytes of one launch of the dominant kernel on this rank
     if use_shard:
         moff = ex.merged[1].cpu().numpy().astype(np.int64)
@@ -258,6 +276,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            **({"value_verified": verified} if verified is not None else {}),
             **({"value_repeats": repeats, "value_spread_pct": 100.0 * (max(repeats) - min(repeats)) / float(np.median(repeats)),
                 "value_spread_note": "the same K steps timed four more times right after the region `value` comes from (value_repeats[0] = value); "
                                      "across fresh boxes the driver command has read 210-220 k (+-2 %)"} if len(repeats) > 1 else {}),
@@ -333,7 +352,7 @@ def main():
         # the reference's real tick, chained: CorrectRadialDistortionsForDepthMaps then GenerateMesh on every tick (KinectServer.cs:518-525,
         # :354-374), and the merge call always triangulates (depthprocessing.cpp:1786): `value` is the vertices-only fusion of the named path
         with leg(result, "full_tick"):
-            result["full_tick"] = dl.bench_full_tick(args, torch, synth, fus, depth, rgb, cx.intr_loc, S_loc, B, w, h, dev, stream)
+            result["full_tick"] = dl.bench_full_tick(args, torch, synth, fus, depth, rgb, cx.intr_loc, S_loc, B, w, h, dev, stream, wt_loc=cx.wt_loc, bounds=bounds)
         with leg(result, "wire"):           # outbound formats of one tick's mesh, built in HBM
             result["wire"] = hl.bench_wire(args, torch, native, synth, dev, stream, S, w, h, bounds, with_cpu=not args.no_cpu)
     if solo and args.mode == 0 and not args.core_only:
@@ -375,12 +394,20 @@ def main():
         dist.barrier()
         if not abandoned:
             dist.destroy_process_group()
+    status = 0
     if rank == 0:
+        from bench_support.verify import failures
+        bad = failures(result)
+        if bad:   # a number whose outputs do not match the oracle is not a measurement: the line says so and the run fails
+            result["error"] = "outputs differ from the oracle: " + "; ".join(f"{path}: {rec.get('first_mismatch', rec)}" for path, rec in bad)
+            status = 1
         real_stdout.write(json.dumps(result) + "\n")
         real_stdout.flush()
     if abandoned:
         sys.stderr.flush()
-        os._exit(0)   # the line is out; an orderly shutdown would wait for that thread
+        os._exit(status)   # the line is out; an orderly shutdown would wait for that thread
+    if status:
+        sys.exit(status)
 
 
 if __name__ == "__main__":

@@ -51,7 +51,11 @@ def bench_shapes(args, torch, synth, DeviceFusion, dev, dev_index):
         fus.plan.profile(False)
         V = int(fus.offsets[:, -1].sum().item())
         alg = 2 * P * S * T + 19 * V
-        out[name] = {"sensors": S, "width": w, "height": h, "ticks_per_step": T, "ms_per_step": 1e3 * dt, "frames_per_s": T / dt,
+        verified = None
+        if not args.no_cpu:   # the first tick of the last timed step against the oracle (bench_support/verify.py)
+            from .verify import verify_clouds
+            verified = verify_clouds(torch, d, c, fus.vertices, fus.offsets, [0], [w] * S, [h] * S, rig.intr, rig.wt, rig.bounds)
+        out[name] = {**({"value_verified": verified} if verified is not None else {}), "sensors": S, "width": w, "height": h, "ticks_per_step": T, "ms_per_step": 1e3 * dt, "frames_per_s": T / dt,
                      "kernel": ks["kernel"], "kernel_avg_ms": ks["avg_ms"], "algorithmic_bytes_per_step": alg,
                      "frac": alg / (ks["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if ks["avg_ms"] > 0 else None,
                      "step_frac": alg / dt / 1e9 / HBM_PEAK_GBS}
@@ -60,7 +64,7 @@ def bench_shapes(args, torch, synth, DeviceFusion, dev, dev_index):
     return out
 
 
-def bench_full_tick(args, torch, synth, fus, depth, rgb, intr_loc, S, B, w, h, dev, stream):
+def bench_full_tick(args, torch, synth, fus, depth, rgb, intr_loc, S, B, w, h, dev, stream, wt_loc=None, bounds=None):
     """radial correction (out of place) -> unproject / transform / crop / compaction -> triangulation, launched back to back on the same
     stream for B ticks of S sensors resident in HBM; ticks per second and the split by stage (each stage alone, same inputs)."""
     cap = fus.capacity
@@ -111,7 +115,19 @@ def bench_full_tick(args, torch, synth, fus, depth, rgb, intr_loc, S, B, w, h, d
         # algorithmic bytes of the chain per sensor-frame: radial 5 B in + 5 B out per pixel; fusion 2 P + 19 V; triangulation reads the
         # corrected depth again (2 P) and writes 12 B per triangle
         alg = B * (S * P * (10 + 2 + 2) + 19 * nv + 12 * nt)
-        out[kind] = {"value": B / dt, "ms_per_step": 1e3 * dt, "vertices_per_tick": nv, "triangles_per_tick": nt,
+        verified = None
+        if kind == "scene" and not args.no_cpu:
+            # the chain once more, then tick 0 (and the last tick) of what it left against the oracle: corrected maps, cloud, offsets, triangles
+            from .verify import verify_mesh_tick
+            tick()
+            verified = verify_mesh_tick(torch, 0, d_in, c_in, d_corr, c_corr, fus.vertices, fus.offsets, tri, toff, [w] * S, [h] * S,
+                                        intr_loc, wt_loc, bounds)
+            if verified["bitexact"]:
+                last = verify_mesh_tick(torch, B - 1, d_in, c_in, d_corr, c_corr, fus.vertices, fus.offsets, tri, toff, [w] * S, [h] * S,
+                                        intr_loc, wt_loc, bounds)
+                verified = {**last, "ticks": [0, B - 1]} if last["bitexact"] else last
+        out[kind] = {**({"value_verified": verified} if verified is not None else {}),
+                     "value": B / dt, "ms_per_step": 1e3 * dt, "vertices_per_tick": nv, "triangles_per_tick": nt,
                      "stages_ms": {"radial_correction": 1e3 * t_r, "vertices": 1e3 * t_v, "vertices_and_triangles": 1e3 * t_m},
                      "algorithmic_GB_per_step": alg / 1e9, "achieved_GBps": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS}
         del d_corr, c_corr

@@ -130,6 +130,13 @@ class Exchange:
             cx.fus.run(d_in, c_in)
             self.xch.exchange(cx.fus.vertices, cx.fus.offsets)
 
+    def merged_cloud(self):
+        """(vertices [B, capacity, 16] u8, offsets [B, S + 1] i32) of the last step on this rank: the merged cloud of the whole rig."""
+        if self.use_shard:
+            return self.merged[0], self.merged[1]
+        x = self.sx if self.use_sx else self.xch
+        return x.merged, x.merged_off
+
     def ranks_seen_by_library(self):
         return self.shard.shard.ranks_seen() if self.use_shard else None
 

@@ -47,3 +47,55 @@ def test_call_with_timeout_reports_value_error_and_timeout():
     t0 = time.time()
     assert call_with_timeout(lambda: time.sleep(30), 0.3) == ("timeout", None)
     assert time.time() - t0 < 5.0
+
+
+def test_bench_line_carries_value_verified_and_fails_on_a_mismatch():
+    """bench.py puts `value_verified` beside `value` (and into every `shapes` entry and `full_tick.scene`) and ends non-zero when one of them is not bit-exact."""
+    from bench_support.verify import failures
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"value_verified": verified' in src and "failures(result)" in src and "sys.exit(status)" in src
+    legs = open(os.path.join(ROOT, "bench_support", "legs_device.py")).read()
+    assert legs.count('"value_verified": verified') >= 2
+    line = {"value": 1.0, "value_verified": {"ticks": [0, 31, 63], "bitexact": True},
+            "shapes": {"a": {"value_verified": {"ticks": [0], "bitexact": True}}, "b": {"value_verified": {"ticks": [0], "bitexact": False, "first_mismatch": "tick 0: x"}}},
+            "full_tick": {"scene": {"value_verified": {"ticks": [0], "bitexact": True}}}}
+    bad = failures(line)
+    assert [p for p, _ in bad] == ["shapes.b.value_verified"]
+    line["shapes"]["b"]["value_verified"]["bitexact"] = True
+    assert failures(line) == []
+    line["value_verified"] = {"ticks": [0], "bitexact": None}
+    assert [p for p, _ in failures(line)] == ["value_verified"]
+
+
+def test_value_verification_catches_a_corrupted_cloud(orc):
+    """The checker itself (bench_support/verify.py) on the CPU: the oracle's own cloud passes; one flipped byte, one wrong offset, one missing
+    vertex and one wrong triangle index do not."""
+    import numpy as np
+    from bench_support.verify import compare_cloud, compare_mesh
+    from livescan3d_amd import synth
+    rig = synth.make_rig("scene", 3, 96, 80, seed=5)
+    args = (rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    v, counts = orc.generate_mesh_vertices(*args)
+    cloud = v.view(np.uint8).reshape(-1, 16).copy()
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    assert compare_cloud(orc, *args, cloud, off)[0]
+    for k, (r, c) in enumerate([(0, 0), (len(cloud) // 2, 7), (len(cloud) - 1, 15)]):
+        bad = cloud.copy(); bad[r, c] ^= 1 << (k % 8)
+        ok, why = compare_cloud(orc, *args, bad, off)
+        assert not ok and "differ" in why
+    bad_off = off.copy(); bad_off[1] += 1
+    assert not compare_cloud(orc, *args, cloud, bad_off)[0]
+    assert not compare_cloud(orc, *args, cloud[:-1], off)[0]
+    # the chained tick's checker
+    cd, cc = orc.radial_correction(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr)
+    cd8 = np.ascontiguousarray(np.asarray(cd)).view(np.uint8).ravel(); cc8 = np.ascontiguousarray(np.asarray(cc)).ravel()
+    mv, mcounts, mt = orc.generate_mesh(cd8, cc8, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    moff = np.concatenate([[0], np.cumsum(np.asarray(mcounts).ravel()[:3])]).astype(np.int32)
+    mt = np.asarray(mt, np.int32).reshape(-1, 3)
+    toff = np.array([0, 0, 0, len(mt)], np.int32)
+    good = (cd8.view(np.uint16), cc8, mv.view(np.uint8).reshape(-1, 16), moff, mt, toff)
+    assert compare_mesh(orc, *args, *good)[0]
+    t2 = mt.copy(); t2[len(t2) // 3, 1] += 1
+    assert not compare_mesh(orc, *args, good[0], good[1], good[2], good[3], t2, toff)[0]
+    d2 = good[0].copy(); d2[1234] ^= 1
+    assert not compare_mesh(orc, *args, d2, *good[1:])[0]

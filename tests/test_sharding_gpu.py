@@ -396,7 +396,8 @@ ODD8 = [(61, 37), (11, 4), (11, 4), (61, 37), (37, 61), (4, 11), (2257, 1), (2, 
     (2, UNIFORM4, 1, False), (2, UNIFORM4, 3, False), (4, UNIFORM8, 4, False), (4, UNIFORM4, 1, True), (2, UNIFORM8, 5, False),
     (4, UNIFORM4, 4, False), (4, UNIFORM4, 1, False),                 # one sensor per rank (the shape of BASELINE configs[3]), compact: chunked and one shot
     (2, RAGGED4, 1, False), (2, RAGGED4, 1, True),
-    # survivor exchange (every width a multiple of 8) on sensors of different sizes, uneven pixel totals per rank, an odd world
+    # survivor exchange (every width a multiple of 8) on sensors of different sizes (every rank's block the same pixel total, as lsnShardPrepare
+    # asks: 15360 / 6144 / 6144 pixels per rank here), an odd world
     (2, MIXED8_4, 3, False), (4, MIXED8_8, 2, False), (3, MIXED8_6, 1, False), (3, MIXED8_6, 4, True),
     # vertex exchange (widths that are not multiples of 8) over three and four ranks
     (3, ODD3, 1, False), (4, ODD8, 2, False)])
@@ -415,10 +416,11 @@ def test_shard_step_several_ranks_on_one_gpu(gpu, tmp_path, world, sizes, chunks
     assert open(out).read() == "ok"
 
 
-def _shard_worker_world8(proc, n_procs, port, out):
-    """BASELINE configs[3] at its true split: 8 shards x 1 sensor x 512x424.  A GPU box admits 6 processes on its card, so the 8 ranks are
-    8 LsnShard handles driven by 2 threads in each of 4 processes (ctypes releases the GIL: the blocking rendezvous and collectives of the
-    ranks of one process run side by side); every rank holds its merged cloud against the CPU oracle's merge of all 8 sensors."""
+def _shard_worker_world8(proc, n_procs, port, out, S=8, w=512, h=424, T=2):
+    """BASELINE configs[3] at its true split: 8 shards x 1 sensor x 512x424 (or configs[4]'s: 8 shards x 2 sensors x 1024x1024).  A GPU box
+    admits 6 processes on its card, so the 8 ranks are 8 LsnShard handles driven by 2 threads in each of 4 processes (ctypes releases the
+    GIL: the blocking rendezvous and collectives of the ranks of one process run side by side); every rank holds its merged cloud against
+    the CPU oracle's merge of all S sensors."""
     sys.path.insert(0, ROOT)
     os.environ["LSN_RCCL_LIBRARY"] = FAKE_RCCL
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -431,9 +433,9 @@ def _shard_worker_world8(proc, n_procs, port, out):
     dist.init_process_group("gloo", rank=proc, world_size=n_procs)   # carries the 128-byte id and the verdicts only
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    world, T, S, w, h = 8, 2, 8, 512, 424
+    world = 8
     per_proc = world // n_procs
-    P = w * h
+    P, mpr = w * h, S // world
     rigs = [synth.make_rig("scene" if k else "noise", S, w, h, seed=31, tick=k, bounds=synth.CROP_BOUNDS) for k in range(T)]
     depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).to(dev)     # [T, S * P]
     rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).to(dev)
@@ -460,8 +462,8 @@ def _shard_worker_world8(proc, n_procs, port, out):
                 sh.connect(ident)                                       # ncclCommInitRank: returns once all 8 ranks have called it
                 seen = sh.ranks_seen()
                 sh.set_params(rigs[0].intr, rigs[0].wt, rigs[0].bounds, st.cuda_stream)
-                mine_d = depth[:, rank * P:(rank + 1) * P].contiguous()
-                mine_c = rgb[:, 3 * rank * P:3 * (rank + 1) * P].contiguous()
+                mine_d = depth[:, rank * mpr * P:(rank + 1) * mpr * P].contiguous()
+                mine_c = rgb[:, 3 * rank * mpr * P:3 * (rank + 1) * mpr * P].contiguous()
                 torch.cuda.synchronize()
                 ok = seen == world
                 for rep in range(2):
@@ -506,6 +508,18 @@ def test_configs3_true_split_world8_on_one_gpu(gpu, tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
     mp.spawn(_shard_worker_world8, args=(4, _free_port(), out), nprocs=4, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_configs4_true_split_world8_on_one_gpu(gpu, tmp_path):
+    """BASELINE configs[4] at its own split: 16 sensors x 1024x1024 over 8 ranks x 2 sensors, through lsnShardPrepare / lsnShardConnect /
+    lsnShardStep (4 processes x 2 rank threads over tests/fake_rccl, like configs[3]'s test above).  Every one of the 8 ranks must end with
+    the oracle's merged cloud of all 16 sensors (4.7 M vertices per tick), byte for byte, offsets included."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_shard_worker_world8, args=(4, _free_port(), out, 16, 1024, 1024, 1), nprocs=4, join=True)
     assert open(out).read() == "ok"
 
 
