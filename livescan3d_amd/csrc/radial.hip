@@ -609,7 +609,10 @@ __device__ __forceinline__ int wave_reserve(int *counter, int mine)
 }
 
 constexpr int kCntStride = 32;   // ints between two frames' counters: one 128-byte line each (atomics on one line serialise in its L2 channel)
-constexpr int kBandThreads = 512;
+#ifndef LSN_BAND_THREADS
+#define LSN_BAND_THREADS 256
+#endif
+constexpr int kBandThreads = LSN_BAND_THREADS;   // (A/B knob: tools/ab_band.sh)
 
 struct BandDesc { int frame, y0; };
 
@@ -1212,10 +1215,12 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
     // bands: as many rows as fit the LDS budget of two workgroups per CU for the widest frame
     int max_w = 1, max_h = 1;
     for (int i = 0; i < p->n_maps; i++) { max_w = std::max(max_w, p->w[i]); max_h = std::max(max_h, p->h[i]); }
-    // 12 rows of a 512-wide frame: 48 KB, three workgroups per CU (measured on 512 scene frames: 16 rows 0.775 ms for the whole correction,
-    // 12 rows 0.753, 8 rows 0.783, 4 rows 0.93)
-    int rows = 12;
-    while (rows > 1 && band_lds_bytes(rows, max_w) > 52 * 1024) rows--;
+    // 256 threads on 6 rows of a 512-wide frame: 27 KB, six workgroups of four waves per CU.  Round 6 (512 scene frames, radial_band_kernel
+    // alone, profiles/r06_ab_band.txt): 512 threads x 12 rows (rounds 3-5: three workgroups of eight waves) 462-467 us, 256 x 6 417-419,
+    // 256 x 4 426, 256 x 7 432, 256 x 5 470, 256 x 8 489, 256 x 12 551, 128 x 4 496, 1024 x 12 718 -- the same 24 waves per CU, but six
+    // groups marching through their phases (gather: memory; closing: VALU + LDS) on their own fill each other's waits better than three
+    int rows = 6;
+    while (rows > 1 && band_lds_bytes(rows, max_w) > 28 * 1024) rows--;
     if (const char *env = getenv("LSN_RADIAL_BAND_ROWS")) {  // tuning
         const int v = atoi(env);
         if (v >= 1 && band_lds_bytes(v, max_w) <= 160 * 1024) rows = v;
