@@ -138,7 +138,12 @@ void *pinned_get(Ctx &c, size_t bytes)
         lsn::set_error("NativeUtils: hipHostMalloc(%zu) failed", cap);
         return nullptr;
     }
-    c.live[p] = cap;
+    try {
+        c.live[p] = cap;
+    } catch (...) {   // the table cannot take it (its node allocation failed): the block is freed, not lost (the mirror of pinned_put)
+        (void)hipHostFree(p);
+        throw;
+    }
     return p;
 }
 

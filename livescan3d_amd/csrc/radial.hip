@@ -703,7 +703,10 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
 
     // ---- 1. the un-closed band into LDS ----
     if (GATHER) {
-        constexpr int kFly = 6;
+#ifndef LSN_BAND_FLY
+#define LSN_BAND_FLY 8
+#endif
+        constexpr int kFly = LSN_BAND_FLY;
         for (int i0 = lo + tid; i0 < hi; i0 += kFly * kBandThreads) {
             int p[kFly];
             bool in[kFly];
@@ -1219,8 +1222,13 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
     // alone, profiles/r06_ab_band.txt): 512 threads x 12 rows (rounds 3-5: three workgroups of eight waves) 462-467 us, 256 x 6 417-419,
     // 256 x 4 426, 256 x 7 432, 256 x 5 470, 256 x 8 489, 256 x 12 551, 128 x 4 496, 1024 x 12 718 -- the same 24 waves per CU, but six
     // groups marching through their phases (gather: memory; closing: VALU + LDS) on their own fill each other's waits better than three
+    // (eight pixels in flight per thread: the 8 x 512 pixels of such a band are two full trips for 256 threads -- 378-391 us; six in flight:
+    // 416-419, 16: 468.)  Wider frames keep the 52 KB budget of rounds 3-5: no measurement says otherwise.
     int rows = 6;
-    while (rows > 1 && band_lds_bytes(rows, max_w) > 28 * 1024) rows--;
+    if (band_lds_bytes(rows, max_w) > 28 * 1024) {
+        rows = 12;
+        while (rows > 1 && band_lds_bytes(rows, max_w) > 52 * 1024) rows--;
+    }
     if (const char *env = getenv("LSN_RADIAL_BAND_ROWS")) {  // tuning
         const int v = atoi(env);
         if (v >= 1 && band_lds_bytes(v, max_w) <= 160 * 1024) rows = v;

@@ -10,10 +10,19 @@
 // "survives", one triangle per pixel with a vertex -- so that counts, offsets, mirrors and every byte the real kernels would write are
 // written (ASan checks the extents, TSan the ordering between the threads).  Every other kernel is a no-op on zero-filled memory.
 // NOTHING here is numerically meaningful; parity is tested on the GPU (tests/*_gpu.py).
+//
+// Device discipline (round 6): the devices are DISTINCT.  Every device block, pinned block and stream remembers the device it was
+// created under (the calling thread's hipSetDevice) and every use is checked against the device current at the call: a device pointer
+// in a copy, a memset or the arguments of an emulated kernel, the stream of a launch or an asynchronous copy, both ends of
+// hipMemcpyPeerAsync against the ordinals it names, a pinned block that is not hipHostMallocPortable used under another device than
+// the one it was allocated under, a kernel argument that points at pageable memory.  A violation prints "CHECK failed: fake hip: ..."
+// (tests/test_host_sanitizers.py fails on that line) -- this is how the sharded host flow's hipSetDevice discipline and its
+// portable-pinned-block requirement are checked on a box that has one GPU or none.
 #include "../../livescan3d_amd/csrc/fusion_shared.hpp"
 
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -38,7 +47,84 @@ std::map<const void *, std::string> &registry()
     return *r;
 }
 
-std::atomic<long long> g_launches{0}, g_allocs{0}, g_frees{0};
+std::atomic<long long> g_launches{0}, g_allocs{0}, g_frees{0}, g_violations{0};
+
+// ---- who owns what ----------------------------------------------------------------------------------------------------------------
+enum Kind { kDeviceMem = 0, kPinnedMem = 1, kStream = 2 };
+struct Block {
+    size_t size;
+    Kind kind;
+    int dev;
+    bool portable;
+};
+std::mutex g_own_mu;
+std::map<uintptr_t, Block> &owners()
+{
+    static std::map<uintptr_t, Block> *m = new std::map<uintptr_t, Block>();
+    return *m;
+}
+void own_add(void *p, size_t n, Kind kind, bool portable)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_own_mu);
+    owners()[reinterpret_cast<uintptr_t>(p)] = Block{n ? n : 1, kind, g_device, portable};
+}
+void own_del(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_own_mu);
+    owners().erase(reinterpret_cast<uintptr_t>(p));
+}
+bool own_find(const void *p, Block &out)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    std::lock_guard<std::mutex> g(g_own_mu);
+    auto it = owners().upper_bound(a);
+    if (it == owners().begin()) return false;
+    --it;
+    if (a >= it->first + it->second.size) return false;
+    out = it->second;
+    return true;
+}
+extern "C" void __sanitizer_print_stack_trace(void) __attribute__((weak));
+void violation(const char *what, const char *where, int have, int want)
+{
+    if (g_violations++ == 0 && __sanitizer_print_stack_trace) __sanitizer_print_stack_trace();   // where the first one came from
+    fprintf(stderr, "CHECK failed: fake hip: %s in %s (belongs to device %d, used under device %d)\n", what, where, have, want);
+}
+// a pointer the device `dev` is about to touch; must_be_gpu_visible: pageable memory is an error too (kernel arguments)
+void check_use(const void *p, const char *where, int dev, bool must_be_gpu_visible)
+{
+    if (!p) return;
+    Block b;
+    if (!own_find(p, b)) {
+        if (must_be_gpu_visible) violation("a pointer to pageable memory", where, -1, dev);
+        return;
+    }
+    if (b.kind == kDeviceMem && b.dev != dev) violation("a device pointer of another device", where, b.dev, dev);
+    if (b.kind == kPinnedMem && !b.portable && b.dev != dev) violation("a pinned block that is not hipHostMallocPortable", where, b.dev, dev);
+    if (b.kind == kStream) violation("a stream handle used as memory", where, b.dev, dev);
+}
+void check_stream(hipStream_t s, const char *where)
+{
+    if (!s) return;   // the null stream of the current device
+    Block b;
+    if (!own_find(s, b) || b.kind != kStream) return;
+    if (b.dev != g_device) violation("a stream of another device", where, b.dev, g_device);
+}
+// the pointer members of the emulated kernels' argument blocks (null = not used by the launch; everything else must be memory the
+// current device may touch -- a pointer to pageable memory is an error as well)
+void check_fuse_args(const FuseArgs &a, const char *where)
+{
+    const void *ptrs[] = {a.frames, a.tiles, a.params, a.xtab, a.ytab, a.depth, a.rgb, a.out, a.tile_counts, a.run_state, a.ticket, a.offsets, a.pixmap,
+                          a.pm_first, a.pm_mask, a.depth_next, a.tile_counts_next, a.error_flag, a.thr, a.group_end_mirror, a.offsets_mirror};
+    for (const void *p : ptrs) check_use(p, where, g_device, true);
+}
+void check_tri_args(const TriArgs &t, const char *where)
+{
+    const void *ptrs[] = {t.frames, t.tiles, t.depth, t.pixmap, t.pm_first, t.pm_mask, t.tri, t.tile_counts, t.codes};
+    for (const void *p : ptrs) check_use(p, where, g_device, true);
+}
 
 int device_count()
 {
@@ -240,7 +326,7 @@ hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hip
     return hipSuccess;
 }
 
-hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3, void **args, size_t, hipStream_t)
+hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3, void **args, size_t, hipStream_t stream)
 {
     std::string name;
     {
@@ -249,6 +335,11 @@ hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3, void **args, size_t,
         if (it != registry().end()) name = it->second;
     }
     g_launches++;
+    check_stream(stream, name.c_str());
+    if (has(name, "16count_thr_kernel") || has(name, "11fuse_kernelILi")) check_fuse_args(*static_cast<const FuseArgs *>(args[0]), name.c_str());
+    else if (has(name, "10tri_kernelILi")) check_tri_args(*static_cast<const TriArgs *>(args[0]), name.c_str());
+    else if (has(name, "11scan_kernel"))
+        for (int k : {0, 2, 4, 5}) check_use(*static_cast<void **>(args[k]), name.c_str(), g_device, true);
     // Itanium names: <len><identifier>I<template args>E...; Li<N>E an int argument, Lb<0|1>E a bool
     if (has(name, "16count_thr_kernel") || has(name, "11fuse_kernelILi0E")) emu_count(*static_cast<const FuseArgs *>(args[0]));
     else if (has(name, "11scan_kernel"))
@@ -286,49 +377,77 @@ hipError_t hipMalloc(void **p, size_t n)
 {
     *p = zalloc(n);
     g_allocs++;
+    own_add(*p, n, kDeviceMem, false);
     return *p ? hipSuccess : (g_last = hipErrorOutOfMemory);
 }
 hipError_t hipFree(void *p)
 {
     if (p) g_frees++;
+    own_del(p);
     free(p);
     return hipSuccess;
 }
-hipError_t hipHostMalloc(void **p, size_t n, unsigned int)
+hipError_t hipHostMalloc(void **p, size_t n, unsigned int flags)
 {
     *p = zalloc(n);
     g_allocs++;
+    own_add(*p, n, kPinnedMem, (flags & hipHostMallocPortable) != 0);
     return *p ? hipSuccess : (g_last = hipErrorOutOfMemory);
 }
 hipError_t hipHostFree(void *p)
 {
     if (p) g_frees++;
+    own_del(p);
     free(p);
     return hipSuccess;
 }
 
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind)
 {
+    check_use(dst, "hipMemcpy (destination)", g_device, false);
+    check_use(src, "hipMemcpy (source)", g_device, false);
     if (n) memmove(dst, src, n);
     return hipSuccess;
 }
-hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(dst, src, n, k); }
-hipError_t hipMemcpyWithStream(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(dst, src, n, k); }
-hipError_t hipMemcpyPeerAsync(void *dst, int, const void *src, int, size_t n, hipStream_t) { return hipMemcpy(dst, src, n, hipMemcpyDefault); }
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s)
+{
+    check_stream(s, "hipMemcpyAsync");
+    return hipMemcpy(dst, src, n, k);
+}
+hipError_t hipMemcpyWithStream(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s)
+{
+    check_stream(s, "hipMemcpyWithStream");
+    return hipMemcpy(dst, src, n, k);
+}
+hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t s)
+{
+    check_stream(s, "hipMemcpyPeerAsync");
+    check_use(dst, "hipMemcpyPeerAsync (destination against the destination ordinal)", dst_dev, true);
+    check_use(src, "hipMemcpyPeerAsync (source against the source ordinal)", src_dev, true);
+    if (n) memmove(dst, src, n);
+    return hipSuccess;
+}
 hipError_t hipMemset(void *p, int v, size_t n)
 {
+    check_use(p, "hipMemset", g_device, false);
     if (n) memset(p, v, n);
     return hipSuccess;
 }
-hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { return hipMemset(p, v, n); }
+hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s)
+{
+    check_stream(s, "hipMemsetAsync");
+    return hipMemset(p, v, n);
+}
 
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int)
 {
     *s = reinterpret_cast<hipStream_t>(zalloc(64));
+    own_add(*s, 64, kStream, false);
     return hipSuccess;
 }
 hipError_t hipStreamDestroy(hipStream_t s)
 {
+    own_del(s);
     free(s);
     return hipSuccess;
 }
@@ -357,6 +476,8 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t)
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 
 // what the soak reads at the end: launches seen, blocks allocated and freed
+long long lsnFakeHipViolations(void) { return g_violations.load(); }
+
 void lsnFakeHipStats(long long *launches, long long *allocs, long long *frees)
 {
     if (launches) *launches = g_launches.load();

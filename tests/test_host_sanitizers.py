@@ -50,7 +50,7 @@ def test_call_mix_from_four_threads(soaks, kind):
 
 
 @pytest.mark.parametrize("kind", ["asan", "tsan"])
-@pytest.mark.parametrize("devices,parts", [("0,1", 2), ("0,1,1", 3), ("1,0,1,0,1,0,1,0", 8)])
+@pytest.mark.parametrize("devices,parts", [("0,1", 2), ("1,0", 2), ("0,1,1", 3), ("1,0,1,0,1,0,1,0", 8)])
 def test_merge_calls_sharded_over_devices(soaks, kind, devices, parts):
     """The sharded flow ($LSN_HOST_DEVICES): one worker thread per device part, counts exchanged through atomics, every part storing into
     the same pinned block at its base -- the double's two devices listed in any order and more than once."""
@@ -72,3 +72,53 @@ def test_failed_allocations_leave_nothing_behind(soaks, devices):
 def test_an_exception_at_any_guarded_entry(soaks):
     for n in (1, 5, 12, 30, 31, 32, 60):
         _run(soaks["asan"], 2, LSN_TEST_THROW=str(n))
+
+
+def _scratch_soak(tmp_path, soaks, edit):
+    """An ASan soak built from a scratch copy of the product's sources with `edit(text of host_flows.hip)` applied (only that object is rebuilt:
+    the others are taken over from the regular build)."""
+    import shutil
+    root = tmp_path / "tree"
+    shutil.copytree(os.path.join(ROOT, "livescan3d_amd", "csrc"), root / "livescan3d_amd" / "csrc", ignore=shutil.ignore_patterns("build"))
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    b = tmp_path / "b"
+    shutil.copytree(os.path.join(FAKE, "build", "asan"), b / "asan")              # copy2: the objects keep their times, newer than the copied sources
+    f = root / "livescan3d_amd" / "csrc" / "host_flows.hip"
+    text = f.read_text()
+    edited = edit(text)
+    assert edited != text, "the edit did not apply: the product's code has moved on, update this test"
+    f.write_text(edited)
+    r = subprocess.run(["make", "-C", FAKE, "asan", f"CSRC={root}/livescan3d_amd/csrc", f"B={b}"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return str(b / "asan" / "soak")
+
+
+def _violations(binary, **env):
+    e = {k: v for k, v in os.environ.items() if not k.startswith("LSN_")}
+    e.update(ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", **env)
+    r = subprocess.run([binary, "2"], capture_output=True, text=True, env=e, timeout=600)
+    return [ln for ln in (r.stdout + r.stderr).splitlines() if ln.startswith("CHECK failed: fake hip:")]
+
+
+def test_the_double_tells_its_two_devices_apart(soaks, tmp_path):
+    """First contact of the sharded host flow with two REAL devices, as far as a box without them allows: the runtime double keeps the
+    devices' allocations, pinned blocks and streams apart and checks every use against the calling thread's hipSetDevice (fake_hip.cpp,
+    "device discipline").  The product passes with two devices in any order (test_merge_calls_sharded_over_devices, both sanitizers);
+    here two scratch copies show that the check bites: (1) the mesh block allocated hipHostMallocDefault while shards exist
+    (host_flows.hip pinned_get: every device's kernels store into that block), (2) a shard's part run without selecting its device."""
+    assert _violations(soaks["asan"], LSN_HOST_DEVICES="0,1") == []
+    not_portable = _scratch_soak(tmp_path / "a", soaks, lambda t: t.replace("c.shards.empty() ? hipHostMallocDefault : hipHostMallocPortable", "hipHostMallocDefault"))
+    assert _violations(not_portable) == []                                   # one device: nothing to tell apart
+    got = _violations(not_portable, LSN_HOST_DEVICES="0,1")
+    assert got and all("not hipHostMallocPortable" in ln for ln in got), got[:5]
+    import re
+    def drop_set_device(t):
+        # the first hipSetDevice of the sharded flow's per-part function
+        i = t.index("LSN_HIP(hipSetDevice(l.device));", t.index("int shard_part("))
+        return t[:i] + "(void)0;" + t[i + len("LSN_HIP(hipSetDevice(l.device));"):]
+    wrong_device = _scratch_soak(tmp_path / "b", soaks, drop_set_device)
+    # (with "0,1" the omission is harmless by accident: part 0 runs on the calling thread, whose device is 0 already, and device 1's worker
+    # thread keeps the device it selected once; "1,0" asks the calling thread for device 1)
+    assert _violations(soaks["asan"], LSN_HOST_DEVICES="1,0") == []
+    got = _violations(wrong_device, LSN_HOST_DEVICES="1,0")
+    assert got and any("of another device" in ln for ln in got), got[:5]
