@@ -52,22 +52,34 @@ class Exchange:
             # The communicator set-up itself (ncclCommInitRank inside lsnShardConnect) blocks until every rank is in it, and on a node it
             # has never run on it may not come back at all (bootstrap interface, ...): it runs on a thread of its own, and a rank that has
             # waited $LSN_BENCH_CONNECT_TIMEOUT_S for it reports that instead (the thread stays behind: the process then ends with os._exit).
+            # Only that one call is on the watchdog's thread: the local preparation and the ranks' "all ready" agreement -- a collective of
+            # torch's own group -- stay on this thread, so no torch.distributed call of a slow rank can still be in flight on another thread
+            # when this one goes on to the all_reduce below.
             err = None
             limit = float(os.environ.get("LSN_BENCH_CONNECT_TIMEOUT_S", "120"))
 
-            def connect():
-                torch.cuda.set_device(cx.dev)
-                sf = ShardedFusion(cx.rank, cx.world, B, [w] * S, [h] * S, cx.dev)
-                sf.set_params(cx.intr_all, cx.wt_all, cx.bounds)
-                return sf
-            status, val = call_with_timeout(connect, limit)
-            if status == "ok":
-                self.shard = val
-            elif status == "timeout":
+            class _ConnectTimeout(Exception):
+                pass
+
+            def watched(fn):
+                def on_thread():
+                    torch.cuda.set_device(cx.dev)
+                    fn()
+                status, val = call_with_timeout(on_thread, limit)
+                if status == "timeout":
+                    raise _ConnectTimeout()
+                if status == "error":
+                    raise val
+            try:
+                self.shard = ShardedFusion(cx.rank, cx.world, B, [w] * S, [h] * S, cx.dev, run_connect=watched)
+                self.shard.set_params(cx.intr_all, cx.wt_all, cx.bounds)
+            except _ConnectTimeout:
                 err = f"the library's communicator set-up did not return within {limit:.0f} s"
                 cx.abandoned_thread = True
-            else:
-                err = f"{type(val).__name__}: {val}"
+                self.shard = None      # (its handle stays with the thread that is still inside lsnShardConnect)
+            except Exception as ex:  # noqa: BLE001
+                err = f"{type(ex).__name__}: {ex}"
+                self.shard = None
             flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=flag_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()):

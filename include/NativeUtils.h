@@ -169,9 +169,14 @@ int lsnFusionSetParams(LsnFusion *plan, const float *intr_params, const float *w
  * (include/NativeUtils/depthprocessing.h:56-63,96-97) without a GPU. */
 int lsnPackSensorParams(const float *intr7, const float *wt12, float *out16);
 
-/* Selects how the raster-order compaction gets its global offsets: 0 = two-pass (count kernel + write kernel),
- * 1 = single launch, runs of tiles counted then re-evaluated, decoupled look-back per run, 2 = single pass, every tile
- * evaluated once, decoupled look-back per tile.  Results are identical; 0 is the fastest on MI355X. */
+/* Selects how the raster-order compaction gets its global offsets: 0 = two-pass (count kernel + write kernel) -- except that a
+ * ONE-tick plan of up to 2048 tiles takes the single pass of mode 2 by itself (one launch instead of three: 7.5-13.6 us per call
+ * against 13.4-15.8; $LSN_ONE_TICK_SINGLE_PASS=0 / 1, read by lsnFusionCreate, forces either), 1 = single launch, runs of tiles
+ * counted then re-evaluated, decoupled look-back per run, 2 = single pass, every tile evaluated once, decoupled look-back per
+ * tile.  Results are identical; 0 is the fastest on MI355X.  The look-back forms (modes 1, 2 and the
+ * one-tick case of mode 0) poll with a bound so that the grid always drains: a launch that gives up raises flag 1 of
+ * lsnFusionCheck, writes nothing for the tiles concerned and -- single pass -- stores -1 as the tick's vertex count
+ * (offsets[n_maps]) instead of leaving the previous call's value there. */
 int lsnFusionSetMode(LsnFusion *plan, int mode);
 
 /* Pipelined calls (mode 0 only): the caller promises that the INPUTS of a call are already resident and stay untouched
@@ -311,7 +316,8 @@ long long lsnShardLastBytesSent(const LsnShard *shard);
 int lsnShardRanksSeen(LsnShard *shard);
 
 /* The plan's sticky device-side error flag since the last check (synchronises `stream`, clears the flag):
- *   0 = fine; 1 = a look-back launch (mode 1) gave up on a bounded spin; 2 = a write pass found a tile whose survivors
+ *   0 = fine; 1 = a look-back launch (mode 1, mode 2, a one-tick plan of mode 0: lsnFusionSetMode) gave up on a bounded spin --
+ *   the call's outputs are invalid (single pass: offsets[n_maps] = -1); 2 = a write pass found a tile whose survivors
  *   differ from what the count pass had counted (the inputs changed between the two passes: a buffer counted ahead by
  *   lsnFusionRunStreamed was refilled, or the inputs of a call in flight were overwritten) -- the affected tiles wrote
  *   nothing, the outputs of that call are invalid.  lsnFusionLookbackFailed is the same call under its round-1 name. */

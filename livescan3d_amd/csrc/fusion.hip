@@ -439,7 +439,16 @@ __global__ __launch_bounds__(kThreads) void fuse_kernel(const FuseArgs a)
         }
         __syncthreads();
         base = s_base;
-        if (base < 0) return;
+        if (base < 0) {
+            // the look-back gave up (this tile or one before it): nothing of the tile is written, and the tick's vertex count -- which every
+            // consumer reads first -- says so instead of keeping the previous call's value (every tile behind a poisoned one gives up as
+            // well, so the tick's last tile always gets here)
+            if (threadIdx.x == 0 && tile == a.tiles_per_tick - 1) {
+                a.offsets[tick * (a.n_frames + 1) + a.n_frames] = -1;
+                if (a.offsets_mirror) a.offsets_mirror[a.n_frames] = -1;
+            }
+            return;
+        }
         if (threadIdx.x == 0) {   // the per-sensor offsets table scan_kernel writes in mode 0
             int *off = a.offsets + tick * (a.n_frames + 1);
             if (t.frame_start) off[t.f] = base;
@@ -775,6 +784,7 @@ static void lsnFusionDestroy_impl(LsnFusion *p)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (p->radial_done) (void)hipEventDestroy(p->radial_done);
     if (p->side) {
         (void)hipStreamSynchronize(p->side);
         (void)hipStreamDestroy(p->side);

@@ -543,7 +543,9 @@ struct LsnFusion {
     lsn::DevBuf ctab;                                   // [pixels per tick] their compact form (one dword per destination)
     lsn::DevBuf bands, holes, work, work2, work_cnt;    // hole closing: band list, hole bitmap, per-frame work lists (two, used in turn) and their counters
     int band_rows = 0, bands_per_tick = 0;              // what `bands` was built for
-    hipStream_t work_cnt_stream = nullptr;              // ... on this stream (a call on another stream clears them again)
+    hipStream_t work_cnt_stream = nullptr;              // the stream of the last radial call ...
+    hipEvent_t radial_done = nullptr;                   // ... and the end of its chain: a call on another stream waits for it (radial.hip radial_correct)
+    bool radial_chain_open = false;                     // radial_done has been recorded at least once
     bool work_cnt_clean = false;                        // the closing chain of the last call was enqueued to its end (it leaves work_cnt zeroed)
     bool band_attr_set = false;
     std::vector<float> radial_intr;                     // the intrinsics `cand` was built for

@@ -1103,10 +1103,29 @@ static int make_bands(const LsnFusion *p, int rows, std::vector<BandDesc> &bands
 
 }  // namespace
 
+static int radial_correct_on(LsnFusion *p, const float *intr_params, const void *d_depth_in, const void *d_colors_in, void *d_depth, void *d_colors,
+                             hipStream_t s);
+
+// The plan's radial scratch -- warp tables, band list, hole bitmap, work lists and their counters -- is shared by all calls on the plan: a
+// call on ANOTHER stream than the previous one's first waits for that chain's end (an event recorded behind every chain), so that nothing
+// of it is still counting, listing or reading when this call clears and refills the scratch.  Calls on one stream are ordered by the stream.
 static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_depth_in, const void *d_colors_in, void *d_depth, void *d_colors,
                           hipStream_t s)
 {
     LSN_HIP(hipSetDevice(p->device));
+    if (!p->radial_done) LSN_HIP(hipEventCreateWithFlags(&p->radial_done, hipEventDisableTiming));
+    if (p->radial_chain_open && p->work_cnt_stream != s) LSN_HIP(hipStreamWaitEvent(s, p->radial_done, 0));
+    const int rc = radial_correct_on(p, intr_params, d_depth_in, d_colors_in, d_depth, d_colors, s);
+    // (also behind a call that failed half-way: whatever it did enqueue is what the next stream has to wait for)
+    if (hipEventRecord(p->radial_done, s) == hipSuccess) p->radial_chain_open = true;
+    else (void)hipGetLastError();
+    p->work_cnt_stream = s;
+    return rc;
+}
+
+static int radial_correct_on(LsnFusion *p, const float *intr_params, const void *d_depth_in, const void *d_colors_in, void *d_depth, void *d_colors,
+                             hipStream_t s)
+{
     const bool in_place = d_depth_in == d_depth && d_colors_in == d_colors;
     if (!in_place && (d_depth_in == d_depth || d_colors_in == d_colors)) {
         lsn::set_error("lsnFusionRadialCorrectTo: depth and colours must both be in place or both out of place");
@@ -1256,11 +1275,9 @@ static int radial_correct(LsnFusion *p, const float *intr_params, const void *d_
         if (p->work_cnt.reserve(cnt_bytes)) return -1;
         p->work_cnt_clean = false;
     }
-    // ... and on the same stream as this call: behind another stream's chain the counters may still be counting
-    if (p->work_cnt_stream != s) p->work_cnt_clean = false;
+    // (a call on another stream than the previous one's has waited for that chain's end: radial_correct)
     if (!p->work_cnt_clean) LSN_HIP(hipMemsetAsync(p->work_cnt.p, 0, p->work_cnt.bytes, s));
     p->work_cnt_clean = false;
-    p->work_cnt_stream = s;
     if (!vec) LSN_HIP(hipMemsetAsync(p->holes.p, 0, (size_t)holes_tick_bytes * p->n_ticks, s));   // the pixel-by-pixel pass only sets bits
     BandArgs ba;
     ba.frames = p->frames.as<FrameDesc>();

@@ -100,6 +100,12 @@ __device__ __forceinline__ int triangle_new_mask(const int *__restrict__ tri, in
 // and invalidates the XCD's whole L2 (buffer_wbl2 / buffer_inv), per wave that executes it -- measured on ICP's match step, where two
 // such fences per workgroup made one fused launch cost 44 us against 24 us for the three launches it replaced
 // (profiles/r05_ab_icp_fused_match.txt).  Everything else these kernels write is read by LATER launches.
+// This rests on two gfx9 (gfx942 / gfx950) facts, not on the HSA memory model: agent-scope atomics are sc1 write-through accesses that
+// reach the memory side, and s_waitcnt's vmcnt counts STORES as well as loads -- on gfx10+ stores have their own counter (vscnt) and
+// s_waitcnt(0) would not wait for them.  The library is built for gfx950 only (csrc/Makefile); any other target stops here.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "stores_acknowledged() relies on gfx9 semantics (vmcnt covers stores, sc1 write-through atomics): build for gfx950"
+#endif
 __device__ __forceinline__ void stores_acknowledged()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

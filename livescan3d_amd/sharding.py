@@ -32,7 +32,10 @@ class ShardedFusion:
     group: a torch.distributed process group used ONLY for the rendezvous (broadcast of rank 0's unique id); None with
     world == 1.  depth_local [T, mpr*P] u16-pattern, rgb_local [T, mpr*P*3] u8, resident on this rank's GPU."""
 
-    def __init__(self, rank, world, n_ticks, widths, heights, device, group=None):
+    def __init__(self, rank, world, n_ticks, widths, heights, device, group=None, run_connect=None):
+        """run_connect: optional wrapper around the one blocking step (lsnShardConnect = ncclCommInitRank), called as run_connect(fn) -- a
+        caller that wants a watchdog around the rendezvous runs fn on a thread of its own there; everything else (local preparation and the
+        ranks' agreement over torch.distributed) runs on the calling thread whatever it is."""
         self.rank, self.world, self.n_ticks = rank, world, n_ticks
         self.device = torch.device(device)
         # 1. everything that can fail on this rank alone (argument checks, loading RCCL, device buffers); rank 0 also draws the id
@@ -56,7 +59,10 @@ class ShardedFusion:
                 self.shard = None
             raise native.NativeUtilsError("lsnShardPrepare failed on " + "; ".join(errors))
         # 3. the collective part
-        self.shard.connect(reports[0][1])
+        if run_connect is None:
+            self.shard.connect(reports[0][1])
+        else:
+            run_connect(lambda: self.shard.connect(reports[0][1]))
         self.n_maps = self.shard.n_maps
         self.capacity = self.shard.capacity
 

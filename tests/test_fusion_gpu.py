@@ -642,3 +642,41 @@ def test_sharded_call_on_a_ragged_rig(gpu, orc, devices):
         assert len(want_v) > 1000
         assert got[k][:3] == [len(want_v), len(want_t), hashlib.sha256(want_v.tobytes() + want_t.tobytes()).hexdigest()], (devices, seed, "merge call")
         assert got[k][3] == hashlib.sha256(v1.tobytes() + t1.tobytes() + cd.tobytes() + cc.tobytes()).hexdigest(), (devices, seed, "tick as one call")
+
+
+@pytest.mark.parametrize("n,w,h", [(1, 512, 424), (8, 512, 424), (3, 250, 120), (2, 1024, 1024)])
+def test_one_tick_plans_single_pass_and_three_launches_give_the_same_bytes(gpu, orc, monkeypatch, n, w, h):
+    """A one-tick mode-0 plan of up to 2048 tiles takes the single pass by itself (fuse_kernel<4>); $LSN_ONE_TICK_SINGLE_PASS=0 / 1 (read
+    when the plan is created) forces the three launches / the single pass.  lsnFusionRun AND lsnFusionRunMesh (whose triangle passes read
+    the pixel -> vertex map the vertex pass leaves) must give the same bytes either way -- the oracle's -- and no device-side flag."""
+    import torch
+    rig = synth.make_rig("scene", n, w, h, seed=12, bounds=synth.CROP_BOUNDS)
+    want_v, want_counts, want_t = orc.generate_mesh(rig.depth_maps, rig.depth_colors, rig.widths, rig.heights, rig.intr, rig.wt, rig.bounds)
+    want_t = np.asarray(want_t, np.int32).reshape(-1, 3)
+    depth = torch.from_numpy(rig.depth_maps.view(np.int16).copy()).cuda().unsqueeze(0).contiguous()
+    rgb = torch.from_numpy(rig.depth_colors.copy()).cuda().unsqueeze(0).contiguous()
+    outs = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("LSN_ONE_TICK_SINGLE_PASS", force)
+        plan = native.FusionPlan(0, 1, rig.widths, rig.heights)
+        monkeypatch.delenv("LSN_ONE_TICK_SINGLE_PASS")
+        plan.set_params(rig.intr, rig.wt, rig.bounds)
+        cap = plan.capacity
+        res = []
+        for rep in range(2):   # the second run counts from the per-pixel thresholds the first one left
+            v = torch.zeros((1, cap, 16), dtype=torch.uint8, device="cuda"); o = torch.full((1, n + 1), -7, dtype=torch.int32, device="cuda")
+            plan.run(depth.data_ptr(), rgb.data_ptr(), v.data_ptr(), o.data_ptr())
+            v2 = torch.zeros_like(v); o2 = torch.full_like(o, -7)
+            t2 = torch.zeros((1, 2 * cap, 3), dtype=torch.int32, device="cuda"); to2 = torch.full((1, n + 1), -7, dtype=torch.int32, device="cuda")
+            plan.run_mesh(depth.data_ptr(), rgb.data_ptr(), v2.data_ptr(), o2.data_ptr(), t2.data_ptr(), to2.data_ptr())
+            torch.cuda.synchronize()
+            assert plan.check() == 0
+            nv, nt = int(o[0, -1]), int(to2[0, -1])
+            assert nv == len(want_v) == int(o2[0, -1]) and nt == len(want_t)
+            res.append((o.cpu().numpy().tobytes(), v[0, :nv].cpu().numpy().tobytes(), o2.cpu().numpy().tobytes(), v2[0, :nv].cpu().numpy().tobytes(),
+                        to2.cpu().numpy().tobytes(), t2[0, :nt].cpu().numpy().tobytes()))
+        assert res[0] == res[1]
+        assert res[0][1] == want_v.tobytes() and res[0][3] == want_v.tobytes() and res[0][5] == want_t.tobytes()
+        outs[force] = res[0]
+        plan.close()
+    assert outs["0"] == outs["1"]

@@ -256,3 +256,30 @@ def test_closing_chain_leaves_its_counters_cleared(gpu, orc, monkeypatch, ticks,
         for k in (0, 1, ticks - 1):
             assert np.array_equal(d[k].cpu().numpy().view(np.uint8), np.asarray(want[k % 4][0]).view(np.uint8).ravel()), f"call {rep}: tick {k} depth"
             assert np.array_equal(c[k].cpu().numpy(), np.asarray(want[k % 4][1]).ravel()), f"call {rep}: tick {k} colours"
+
+
+def test_calls_on_two_streams_back_to_back_share_the_plans_scratch_safely(gpu, orc):
+    """One plan, two streams, no synchronisation in between: the second call clears and refills the scratch (tables, lists, hole bitmap,
+    counters) the first one's chain is still working on -- unless it waits for that chain's end, which radial_correct makes it do (an event
+    behind every chain).  Both calls, and a third one back on the first stream, must be right; a batch big enough that the first chain is
+    still running when the second call is issued."""
+    import torch
+    N, w, h, ticks = 4, 256, 212, 48
+    rigs = [synth.make_rig("scene", N, w, h, seed=17, tick=k % 3) for k in range(ticks)]
+    plan = native.FusionPlan(0, ticks, rigs[0].widths, rigs[0].heights)
+    src_d = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda()
+    src_c = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda()
+    want = [orc.radial_correction(r.depth_maps, r.depth_colors, r.widths, r.heights, rigs[0].intr) for r in rigs[:3]]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        outs = [(src_d.clone(), src_c.clone()) for _ in range(3)]
+        torch.cuda.synchronize()
+        for (d, c), st in zip(outs, (s1, s2, s1)):
+            plan.radial_correct(rigs[0].intr, d.data_ptr(), c.data_ptr(), int(st.cuda_stream))
+        torch.cuda.synchronize()
+        assert plan.radial_counters_left(int(s1.cuda_stream)) == 0
+        for i, (d, c) in enumerate(outs):
+            for k in (0, 1, 2, ticks - 1):
+                assert np.array_equal(d[k].cpu().numpy().view(np.uint8), np.asarray(want[k % 3][0]).view(np.uint8).ravel()), f"round {rep} call {i}: tick {k} depth"
+                assert np.array_equal(c[k].cpu().numpy(), np.asarray(want[k % 3][1]).ravel()), f"round {rep} call {i}: tick {k} colours"
+    plan.close()

@@ -618,4 +618,5 @@ def test_bench_goes_on_when_the_communicator_setup_never_returns(gpu):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert "did not return within" in str(line["config"].get("shard_preflight")), line["config"]
+    assert "never returned" in line.get("degraded", ""), line.get("degraded")
     assert "Python over torch.distributed" in line["config"]["parallelism"], line["config"]["parallelism"]
