@@ -716,7 +716,10 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
                 in[k] = i0 + k * kBandThreads < hi;
             }
             unsigned int d[kFly], c[kFly];
-            gather_batch<kFly>(a.src, fb, fd.depth_off, fd.npix, pl0 + lo, p, in, d, c);
+#ifndef LSN_BAND_SPEC
+#define LSN_BAND_SPEC false
+#endif
+            gather_batch<kFly, LSN_BAND_SPEC>(a.src, fb, fd.depth_off, fd.npix, pl0 + lo, p, in, d, c);
 #pragma unroll
             for (int k = 0; k < kFly; k++) {
                 if (!in[k]) continue;
@@ -894,7 +897,10 @@ __global__ __launch_bounds__(kBandThreads) void radial_band_kernel(const BandArg
     }
 }
 
-constexpr int kFixThreads = 256;   // measured on 512 scene frames: 1024 threads 377 us, 512: 274, 256: 245 -- the rounds are short, idle waves only add barrier time
+#ifndef LSN_FIX_THREADS
+#define LSN_FIX_THREADS 256
+#endif
+constexpr int kFixThreads = LSN_FIX_THREADS;   // measured on 512 scene frames: 1024 threads 377 us, 512: 274, 256: 245 -- the rounds are short, idle waves only add barrier time
 constexpr int kFixList = 8192;   // entries per round list (LDS, two lists: 64 KB)
 
 struct FixArgs {
