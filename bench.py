@@ -215,20 +215,21 @@ def main():
     # the oracle's merge of the same frames (both resident input sets hold the same frames); N > 1: the merged cloud of the WHOLE rig on rank 0
     verified = None
     if rank == 0 and not args.no_cpu:
-        from bench_support.verify import verify_clouds
+        from bench_support.verify import checked, verify_clouds
         check_ticks = sorted({0, max(0, B // 2 - 1), B - 1})
-        if multi:
-            m_v, m_o = ex.merged_cloud()
-            frames = [synth.noise_frames_torch(dev, 1, 1, S, w, h, tick0=t) for t in range(B) if t in check_ticks]
-            d_chk = torch.zeros((B, S * P), dtype=torch.int16, device=dev)
-            c_chk = torch.zeros((B, S * P * 3), dtype=torch.uint8, device=dev)
-            for t, (dd, cc) in zip(check_ticks, frames):
-                d_chk[t], c_chk[t] = dd.view(-1), cc.view(-1)
-            verified = verify_clouds(torch, d_chk, c_chk, m_v, m_o, check_ticks, [w] * S, [h] * S, intr_all, wt_all, bounds)
-            del d_chk, c_chk
-        else:
-            verified = verify_clouds(torch, depth, rgb, fus.vertices, fus.offsets, check_ticks, [w] * S_loc, [h] * S_loc, cx.intr_loc, cx.wt_loc, bounds)
 
+        @checked
+        def verify_value():
+            if multi:
+                m_v, m_o = ex.merged_cloud()
+                frames = [synth.noise_frames_torch(dev, 1, 1, S, w, h, tick0=t) for t in range(B) if t in check_ticks]
+                d_chk = torch.zeros((B, S * P), dtype=torch.int16, device=dev)
+                c_chk = torch.zeros((B, S * P * 3), dtype=torch.uint8, device=dev)
+                for t, (dd, cc) in zip(check_ticks, frames):
+                    d_chk[t], c_chk[t] = dd.view(-1), cc.view(-1)
+                return verify_clouds(torch, d_chk, c_chk, m_v, m_o, check_ticks, [w] * S, [h] * S, intr_all, wt_all, bounds)
+            return verify_clouds(torch, depth, rgb, fus.vertices, fus.offsets, check_ticks, [w] * S_loc, [h] * S_loc, cx.intr_loc, cx.wt_loc, bounds)
+        verified = verify_value()
     # algorithmic bytes of one launch of the dominant kernel on this rank
     if use_shard:
         moff = ex.merged[1].cpu().numpy().astype(np.int64)

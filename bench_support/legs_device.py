@@ -53,8 +53,8 @@ def bench_shapes(args, torch, synth, DeviceFusion, dev, dev_index):
         alg = 2 * P * S * T + 19 * V
         verified = None
         if not args.no_cpu:   # the first tick of the last timed step against the oracle (bench_support/verify.py)
-            from .verify import verify_clouds
-            verified = verify_clouds(torch, d, c, fus.vertices, fus.offsets, [0], [w] * S, [h] * S, rig.intr, rig.wt, rig.bounds)
+            from .verify import checked, verify_clouds
+            verified = checked(verify_clouds)(torch, d, c, fus.vertices, fus.offsets, [0], [w] * S, [h] * S, rig.intr, rig.wt, rig.bounds)
         out[name] = {**({"value_verified": verified} if verified is not None else {}), "sensors": S, "width": w, "height": h, "ticks_per_step": T, "ms_per_step": 1e3 * dt, "frames_per_s": T / dt,
                      "kernel": ks["kernel"], "kernel_avg_ms": ks["avg_ms"], "algorithmic_bytes_per_step": alg,
                      "frac": alg / (ks["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if ks["avg_ms"] > 0 else None,
@@ -118,7 +118,8 @@ def bench_full_tick(args, torch, synth, fus, depth, rgb, intr_loc, S, B, w, h, d
         verified = None
         if kind == "scene" and not args.no_cpu:
             # the chain once more, then tick 0 (and the last tick) of what it left against the oracle: corrected maps, cloud, offsets, triangles
-            from .verify import verify_mesh_tick
+            from .verify import checked, verify_mesh_tick
+            verify_mesh_tick = checked(verify_mesh_tick)
             tick()
             verified = verify_mesh_tick(torch, 0, d_in, c_in, d_corr, c_corr, fus.vertices, fus.offsets, tri, toff, [w] * S, [h] * S,
                                         intr_loc, wt_loc, bounds)

@@ -53,7 +53,7 @@ def test_bench_line_carries_value_verified_and_fails_on_a_mismatch():
     """bench.py puts `value_verified` beside `value` (and into every `shapes` entry and `full_tick.scene`) and ends non-zero when one of them is not bit-exact."""
     from bench_support.verify import failures
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert '"value_verified": verified' in src and "failures(result)" in src and "sys.exit(status)" in src
+    assert '"value_verified": verified' in src and "failures(result)" in src and "sys.exit(status)" in src and "@checked" in src
     legs = open(os.path.join(ROOT, "bench_support", "legs_device.py")).read()
     assert legs.count('"value_verified": verified') >= 2
     line = {"value": 1.0, "value_verified": {"ticks": [0, 31, 63], "bitexact": True},
@@ -63,8 +63,11 @@ def test_bench_line_carries_value_verified_and_fails_on_a_mismatch():
     assert [p for p, _ in bad] == ["shapes.b.value_verified"]
     line["shapes"]["b"]["value_verified"]["bitexact"] = True
     assert failures(line) == []
-    line["value_verified"] = {"ticks": [0], "bitexact": None}
-    assert [p for p, _ in failures(line)] == ["value_verified"]
+    line["value_verified"] = {"bitexact": None, "not_checked": "OSError: liblsn_oracle.so"}       # a check that could not run is reported, not failed
+    assert failures(line) == []
+    from bench_support.verify import checked
+    assert checked(lambda: 1 / 0)() == {"bitexact": None, "not_checked": "ZeroDivisionError: division by zero"}
+    assert checked(lambda x: {"bitexact": True, "x": x})(3) == {"bitexact": True, "x": 3}
 
 
 def test_value_verification_catches_a_corrupted_cloud(orc):
