@@ -369,6 +369,25 @@ int lsnIcpProfile(LsnIcp *icp, float *ms4, void *stream);
  * out[iter] = {n_matched, n_kept, mean, stddev, T[3], Rn[9]} as 16 floats (counts stored as floats). */
 int lsnIcpTrace(LsnIcp *icp, float *out16_per_iter, int max_iters, void *stream);
 
+/* The reference's tick, device resident, as ONE call: the radial correction (out of place) then the merge call with its
+ * triangulation -- CorrectRadialDistortionsForDepthMaps then GenerateMesh on every tick (LiveScanServer/KinectServer.cs:518-525,
+ * :354-374) = lsnFusionRadialCorrectTo + lsnFusionRunMesh on a batch of n_ticks ticks.  From 8 ticks up the batch is cut in two
+ * halves that run side by side -- the caller's stream and an internal one, joined before the call's work ends on the caller's
+ * stream -- so that one half's latency chains (the closing rounds) are filled by the other half's throughput-bound passes:
+ * +4.5 to +6.5 % ticks/s on scene frames, -2 % on hash noise ($LSN_TICK_PARTS=1: one plan, one stream).  Same bytes as the two
+ * calls on one plan.  Arrays as for those calls: inputs and corrected maps [n_ticks][pixels per tick] u16 / [..][3] u8,
+ * d_vertices [n_ticks][lsnTickCapacity()] VertexC4ubV3f, d_triangles [n_ticks][lsnTickTriangleCapacity()][3] int,
+ * offset tables [n_ticks][n_maps + 1]. */
+typedef struct LsnTick LsnTick;
+LsnTick *lsnTickCreate(int device, int n_ticks, int n_maps, const int *widths, const int *heights);
+void lsnTickDestroy(LsnTick *tick);
+int lsnTickSetParams(LsnTick *tick, const float *intr_params, const float *wtransform_params, const float *bounds6, void *stream);
+long long lsnTickCapacity(const LsnTick *tick);
+long long lsnTickTriangleCapacity(const LsnTick *tick);
+int lsnTickParts(const LsnTick *tick);   /* 1 or 2 */
+int lsnTickRun(LsnTick *tick, const void *d_depth_in, const void *d_colors_in, void *d_depth_corrected, void *d_colors_corrected,
+               void *d_vertices, int *d_offsets, void *d_triangles, int *d_tri_offsets, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Part 3 -- the data formats either side of the path.
  *

@@ -29,6 +29,7 @@ EXPORTS = [
     "lsnDeviceMalloc", "lsnDeviceFree", "lsnDeviceUpload", "lsnDeviceDownload", "lsnStreamCreate", "lsnStreamDestroy", "lsnStreamSynchronize",
     "lsnFusionPackSurvivorsRun", "lsnFusionReconstructRun", "lsnShardUniqueId", "lsnShardPlan", "lsnShardCreate", "lsnShardPrepare", "lsnShardConnect", "lsnShardRcclPath", "lsnShardDestroy", "lsnShardMergedCapacity", "lsnShardSetParams", "lsnShardStep", "lsnShardLastBytesSent", "lsnShardRanksSeen",
     "lsnIcpCreate", "lsnIcpDestroy", "lsnIcpRun", "lsnIcpNearest", "lsnIcpTrace", "lsnIcpSetProfiling", "lsnIcpProfile", "lsnIcpNearResolved", "lsnRefine",
+    "lsnTickCreate", "lsnTickDestroy", "lsnTickSetParams", "lsnTickCapacity", "lsnTickTriangleCapacity", "lsnTickParts", "lsnTickRun",
     "lsnTransferCreate", "lsnTransferDestroy", "lsnTransferFrameBound", "lsnTransferPack", "lsnTransferLastPath", "lsnPlyBinaryBytes", "lsnPlyPack",
     "lsnLastMeshTransferFrame", "lsnLastMeshPly",
     "lsnZstdAvailable", "lsnFrameParseHeader", "lsnFrameDecode", "lsnFrameEncode", "lsnRecordingNext", "lsnRecordingAppend",
@@ -208,6 +209,21 @@ def lib():
     L.lsnIcpSetProfiling.argtypes = [vp, C.c_int]
     L.lsnIcpProfile.restype = C.c_int
     L.lsnIcpProfile.argtypes = [vp, vp, vp]
+    if hasattr(L, "lsnTickCreate"):
+        L.lsnTickCreate.restype = vp
+        L.lsnTickCreate.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]
+        L.lsnTickDestroy.restype = None
+        L.lsnTickDestroy.argtypes = [vp]
+        L.lsnTickSetParams.restype = C.c_int
+        L.lsnTickSetParams.argtypes = [vp, vp, vp, vp, vp]
+        L.lsnTickCapacity.restype = C.c_longlong
+        L.lsnTickCapacity.argtypes = [vp]
+        L.lsnTickTriangleCapacity.restype = C.c_longlong
+        L.lsnTickTriangleCapacity.argtypes = [vp]
+        L.lsnTickParts.restype = C.c_int
+        L.lsnTickParts.argtypes = [vp]
+        L.lsnTickRun.restype = C.c_int
+        L.lsnTickRun.argtypes = [vp] + [vp] * 9
     if hasattr(L, "lsnIcpNearResolved"):   # (absent from an older build loaded through $LSN_NATIVE_LIB)
         L.lsnIcpNearResolved.restype = C.c_int
         L.lsnIcpNearResolved.argtypes = [vp, vp]
@@ -652,6 +668,41 @@ class Shard:
 
 
 NN_BRUTE, NN_GRID = 0, 1
+
+
+class TickPipeline:
+    """lsnTick*: the chained tick (radial correction out of place -> vertices -> triangulation) of n_ticks x n_maps frames in HBM as one call."""
+
+    def __init__(self, device, n_ticks, widths, heights):
+        require_gpu()
+        self.widths, self.heights = _as(widths, np.int32), _as(heights, np.int32)
+        self.n_ticks, self.n_maps = int(n_ticks), len(self.widths)
+        self._h = lib().lsnTickCreate(int(device), self.n_ticks, self.n_maps, _ptr(self.widths), _ptr(self.heights))
+        if not self._h:
+            raise NativeUtilsError(f"lsnTickCreate failed: {last_error()}")
+        self.capacity = int(lib().lsnTickCapacity(self._h))
+        self.tri_capacity = int(lib().lsnTickTriangleCapacity(self._h))
+        self.parts = int(lib().lsnTickParts(self._h))
+
+    def set_params(self, intr, wt, bounds, stream=0):
+        intr, wt, bounds = _as(intr, np.float32).ravel(), _as(wt, np.float32).ravel(), _as(bounds, np.float32).ravel()
+        assert intr.size == 7 * self.n_maps and wt.size == 12 * self.n_maps and bounds.size == 6
+        _check(lib().lsnTickSetParams(self._h, _ptr(intr), _ptr(wt), _ptr(bounds), stream), "lsnTickSetParams")
+
+    def run(self, d_depth_in, d_colors_in, d_depth_corr, d_colors_corr, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream=0):
+        _check(lib().lsnTickRun(self._h, d_depth_in, d_colors_in, d_depth_corr, d_colors_corr, d_vertices, d_offsets, d_triangles, d_tri_offsets, stream),
+               "lsnTickRun")
+
+    def close(self):
+        if self._h:
+            lib().lsnTickDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class IcpWorkspace:

@@ -680,3 +680,51 @@ def test_one_tick_plans_single_pass_and_three_launches_give_the_same_bytes(gpu, 
         outs[force] = res[0]
         plan.close()
     assert outs["0"] == outs["1"]
+
+
+@pytest.mark.parametrize("T,sizes,parts_env", [(9, [(512, 424)] * 3, None), (16, [(250, 120), (61, 37), (128, 96)], None), (3, [(128, 96)] * 2, None),
+                                               (5, [(128, 96)] * 2, "2"), (12, [(256, 212)] * 2, "1")])
+def test_tick_pipeline_gives_the_two_calls_bytes(gpu, orc, monkeypatch, T, sizes, parts_env):
+    """lsnTickRun = lsnFusionRadialCorrectTo + lsnFusionRunMesh as one call; from 8 ticks up (or $LSN_TICK_PARTS=2) the batch runs as two
+    halves side by side on two streams.  Corrected maps, clouds, offsets, triangles: the oracle's, byte for byte, for every tick -- odd
+    tick counts, ragged rigs (the second half's slices then start unaligned), both settings of the split; twice, on a side stream."""
+    import torch
+    if parts_env:
+        monkeypatch.setenv("LSN_TICK_PARTS", parts_env)
+    N = len(sizes)
+    rigs = []
+    for k in range(T):
+        depths, rgbs, intr, wt = [], [], [], []
+        for s_, (w, h) in enumerate(sizes):
+            d, c = synth.scene_frame(21, k, s_, N, w, h) if (w, h) == (512, 424) or k % 2 else synth.noise_frame(21, k, s_, w, h)
+            depths.append(d); rgbs.append(c)
+            ki = synth.kinect_intrinsics(w, h).copy(); ki[4:7] = [0.09, -0.05, 0.01]
+            intr.append(ki.astype(np.float32))
+            wt.append(synth.pack_pose(*synth.ring_pose(s_, N)))
+        rigs.append(synth.Rig(depths, rgbs, np.concatenate(intr), np.concatenate(wt), synth.CROP_BOUNDS))
+    r0 = rigs[0]
+    tp = native.TickPipeline(0, T, r0.widths, r0.heights)
+    assert tp.parts == (int(parts_env) if parts_env else (2 if T >= 8 else 1))
+    tp.set_params(r0.intr, r0.wt, r0.bounds)
+    cap, tcap = tp.capacity, tp.tri_capacity
+    depth = torch.from_numpy(np.stack([r.depth_maps.view(np.int16) for r in rigs])).cuda().contiguous()
+    rgb = torch.from_numpy(np.stack([r.depth_colors for r in rigs])).cuda().contiguous()
+    st = torch.cuda.Stream()
+    for rep in range(2):
+        cd, cc = torch.zeros_like(depth), torch.zeros_like(rgb)
+        v = torch.zeros((T, cap, 16), dtype=torch.uint8, device="cuda"); o = torch.full((T, N + 1), -7, dtype=torch.int32, device="cuda")
+        tr = torch.zeros((T, tcap, 3), dtype=torch.int32, device="cuda"); to = torch.full((T, N + 1), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        tp.run(depth.data_ptr(), rgb.data_ptr(), cd.data_ptr(), cc.data_ptr(), v.data_ptr(), o.data_ptr(), tr.data_ptr(), to.data_ptr(), int(st.cuda_stream))
+        st.synchronize()                                        # the call's work is complete on the CALLER's stream (the join)
+        for k, r in enumerate(rigs):
+            wd, wc = orc.radial_correction(r.depth_maps, r.depth_colors, r.widths, r.heights, r.intr)
+            wd = np.ascontiguousarray(np.asarray(wd)).view(np.uint8).ravel(); wc = np.ascontiguousarray(np.asarray(wc)).ravel()
+            assert cd[k].cpu().numpy().view(np.uint8).tobytes() == wd.tobytes() and cc[k].cpu().numpy().tobytes() == wc.tobytes(), (rep, k)
+            want_v, want_counts, want_t = orc.generate_mesh(wd, wc, r.widths, r.heights, r.intr, r.wt, r.bounds)
+            oh = o[k].cpu().numpy()
+            assert oh[-1] == len(want_v) and np.array_equal(np.diff(oh), np.asarray(want_counts).ravel()[:N]), (rep, k)
+            assert v[k, :len(want_v)].cpu().numpy().tobytes() == want_v.tobytes(), (rep, k)
+            want_t = np.asarray(want_t, np.int32).reshape(-1, 3)
+            assert int(to[k, -1]) == len(want_t) and np.array_equal(tr[k, :len(want_t)].cpu().numpy(), want_t), (rep, k)
+    tp.close()

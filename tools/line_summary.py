@@ -11,6 +11,6 @@ for k, v in (d.get("shapes") or {}).items():
 ft = d.get("full_tick") or {}
 for kind in ("noise", "scene"):
     if kind in ft:
-        print(" full_tick", kind, round(ft[kind]["value"]), "ticks/s", ft[kind].get("stages_ms"), "verified", ft[kind].get("value_verified"))
+        print(" full_tick", kind, round(ft[kind]["value"]), "ticks/s", "one_plan", round((ft[kind].get("one_plan") or {}).get("value", 0)), ft[kind].get("stages_ms"), "verified", (ft[kind].get("value_verified") or {}).get("bitexact"))
 print("icp_iter_ms", d.get("icp_iter_ms"), "config2", d.get("icp_iter_ms_config2"), "refine", g("refine", "total_ms"))
 print("legs with errors:", [k for k, v in d.items() if isinstance(v, dict) and "error" in v])
