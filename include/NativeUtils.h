@@ -373,9 +373,10 @@ int lsnIcpTrace(LsnIcp *icp, float *out16_per_iter, int max_iters, void *stream)
  * triangulation -- CorrectRadialDistortionsForDepthMaps then GenerateMesh on every tick (LiveScanServer/KinectServer.cs:518-525,
  * :354-374) = lsnFusionRadialCorrectTo + lsnFusionRunMesh on a batch of n_ticks ticks.  From 8 ticks up the batch is cut in two
  * halves that run side by side -- the caller's stream and an internal one, joined before the call's work ends on the caller's
- * stream -- so that one half's latency chains (the closing rounds) are filled by the other half's throughput-bound passes:
- * +4.5 to +6.5 % ticks/s on scene frames, -2 % on hash noise ($LSN_TICK_PARTS=1: one plan, one stream).  Same bytes as the two
- * calls on one plan.  Arrays as for those calls: inputs and corrected maps [n_ticks][pixels per tick] u16 / [..][3] u8,
+ * stream, the second half started behind the first half's band kernel -- so that one half's latency chains (the closing rounds)
+ * are filled by the other half's throughput-bound passes: +2 % ticks/s on scene frames with the join per call (+5 % for two
+ * free-running streams, which a caller that can consume the halves separately may build from two plans itself);
+ * $LSN_TICK_PARTS=1: one plan, one stream.  Same bytes as the two calls on one plan.  Arrays as for those calls: inputs and corrected maps [n_ticks][pixels per tick] u16 / [..][3] u8,
  * d_vertices [n_ticks][lsnTickCapacity()] VertexC4ubV3f, d_triangles [n_ticks][lsnTickTriangleCapacity()][3] int,
  * offset tables [n_ticks][n_maps + 1]. */
 typedef struct LsnTick LsnTick;

@@ -546,6 +546,7 @@ struct LsnFusion {
     hipStream_t work_cnt_stream = nullptr;              // the stream of the last radial call ...
     hipEvent_t radial_done = nullptr;                   // ... and the end of its chain: a call on another stream waits for it (radial.hip radial_correct)
     bool radial_chain_open = false;                     // radial_done has been recorded at least once
+    hipEvent_t after_band = nullptr;                    // not owned: recorded behind the band kernel of a radial call (set by lsnTickRun around its calls)
     bool work_cnt_clean = false;                        // the closing chain of the last call was enqueued to its end (it leaves work_cnt zeroed)
     bool band_attr_set = false;
     std::vector<float> radial_intr;                     // the intrinsics `cand` was built for

@@ -1316,6 +1316,8 @@ static int radial_correct_on(LsnFusion *p, const float *intr_params, const void 
         if (vec) hipLaunchKernelGGL((radial_band_kernel<false, true>), bgrid, dim3(kBandThreads), lds, s, ba);
         else     hipLaunchKernelGGL((radial_band_kernel<false, false>), bgrid, dim3(kBandThreads), lds, s, ba);
     }
+    // (tick.hip: the other half of a tick batch starts its own band kernel here, beside this half's closing rounds)
+    if (p->after_band) LSN_HIP(hipEventRecord(p->after_band, s));
     FixArgs fa;
     fa.frames = ba.frames;
     fa.out_d = ba.out_d;

@@ -5,10 +5,12 @@
 // latency chain that occupies a quarter of the wave slots for 0.23 ms, the count passes are VALU-bound, the write passes store-bound --
 // and a batch cut in two halves that run side by side (the caller's stream and an internal one, two plans) lets one half's waits be
 // the other half's work.  Round 4 measured that at +1.7 % and did not build it; with the band kernel regrouped into 27 KB workgroups
-// (round 6: room beside the closing's two 64 KB workgroups per CU) it is +4.5 to +6.5 % on scene frames (44.1-44.7 -> 46.6-47.2 k ticks/s
-// for 64 ticks x 8 x 512x424; four parts: 42.0 k; hash-noise frames, which have nothing to close: -2 %; tools/tick_pipelined.py).
-// Results are those of the two calls on one plan, byte for byte: the halves share nothing but the calibration.
-#include "lsn_common.hpp"
+// (round 6: room beside the closing's two 64 KB workgroups per CU) two FREE-RUNNING streams gain +4.5 to +6.5 % on scene frames (44.1-44.7 ->
+// 46.6-47.4 k ticks/s for 64 ticks x 8 x 512x424; four parts: 42.0 k; hash-noise frames, which have nothing to close: -2 %;
+// tools/tick_pipelined.py).  This call forks from and joins to the caller's stream every time -- its outputs are complete on the caller's
+// stream when its work there is -- which keeps +2 % of that (45.0-45.1 k against 44.1-44.3; profiles/r06_tick_pipelined.txt): the rest is
+// overlap across calls.  Results are those of the two calls on one plan, byte for byte: the halves share nothing but the calibration.
+#include "fusion_shared.hpp"
 
 #include <mutex>
 #include <vector>
@@ -20,7 +22,8 @@ struct LsnTick {
     long long cap = 0, tri_cap = 0;      // vertices / triangles per tick
     std::vector<float> intr;             // the radial correction's intrinsics (lsnTickSetParams)
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_band = nullptr;
+    bool stagger = true;                 // $LSN_TICK_STAGGER=0: both halves start together
     std::mutex mu;
 };
 
@@ -34,6 +37,7 @@ static void lsnTickDestroy_impl(LsnTick *t)
     }
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    if (t->ev_band) (void)hipEventDestroy(t->ev_band);
     for (LsnFusion *p : t->plan)
         if (p) lsnFusionDestroy(p);
     delete t;
@@ -75,7 +79,9 @@ static LsnTick *lsnTickCreate_impl(int device, int n_ticks, int n_maps, const in
         if (!bad && parts == 2)
             bad = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess ||
                   hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                  hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) != hipSuccess;
+                  hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&t->ev_band, hipEventDisableTiming) != hipSuccess;
+        if (const char *e = getenv("LSN_TICK_STAGGER")) t->stagger = atoi(e) != 0;
         if (bad && !lsn::has_error()) lsn::set_error("lsnTickCreate: %s", hipGetErrorString(hipGetLastError()));
     }
     if (bad) {
@@ -139,14 +145,20 @@ static int lsnTickRun_impl(LsnTick *t, const void *d_depth_in, const void *d_col
                                 static_cast<unsigned char *>(d_triangles) + 12 * (size_t)t->tri_cap * t0, d_tri_offsets + nm * t0, st);
     };
     if (t->parts == 1) return part(0, s);
-    // fork: the side stream starts where the caller's stream stands; join: the caller's stream continues behind both halves
+    // fork: the side stream starts where the caller's stream stands -- and, staggered, only when the first half's band kernel is through: two
+    // halves that start together march in step (band beside band, closing beside closing) and gain nothing; half a stage apart, one half's
+    // closing rounds run beside the other half's band kernel, then beside its count / write / triangle passes.  join: the caller's stream
+    // continues behind both halves.
     LSN_HIP(hipEventRecord(t->ev_fork, s));
     LSN_HIP(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-    const int rc_b = part(1, t->side);
-    char err_b[lsn::kErrorLen];
-    snprintf(err_b, sizeof(err_b), "%s", lsn::error_buffer());   // (every export clears the channel on entry: half A's calls would wipe half B's text)
+    t->plan[0]->after_band = t->stagger ? t->ev_band : nullptr;
     const int rc_a = part(0, s);
-    if (rc_b && !rc_a) lsn::set_error("%s", err_b);
+    t->plan[0]->after_band = nullptr;
+    char err_a[lsn::kErrorLen];
+    snprintf(err_a, sizeof(err_a), "%s", lsn::error_buffer());   // (every export clears the channel on entry: the second half's calls would wipe the first half's text)
+    if (t->stagger) (void)hipStreamWaitEvent(t->side, t->ev_band, 0);   // (a closing route without a band kernel records nothing new: no wait, the halves start together)
+    const int rc_b = part(1, t->side);
+    if (rc_a) lsn::set_error("%s", err_a);
     // (the join is enqueued whatever happened: nothing of a failed half may still be running unobserved when the caller's stream goes on)
     if (hipEventRecord(t->ev_join, t->side) == hipSuccess) (void)hipStreamWaitEvent(s, t->ev_join, 0);
     else (void)hipGetLastError();
