@@ -66,6 +66,10 @@ static LsnTick *lsnTickCreate_impl(int device, int n_ticks, int n_maps, const in
     t->parts = parts;
     t->first[0] = 0;
     t->first[1] = parts == 2 ? (n_ticks + 1) / 2 : n_ticks;
+    if (const char *e = getenv("LSN_TICK_FIRST")) {   // tuning: ticks in the first half
+        const int v = atoi(e);
+        if (parts == 2 && v >= 1 && v < n_ticks) t->first[1] = v;
+    }
     t->first[2] = n_ticks;
     bool bad = false;
     for (int k = 0; k < parts && !bad; k++) {
