@@ -9,6 +9,12 @@
 // single calls fail, which must leave empty meshes and still an empty pool.  Exit code 0 = all checks held (the sanitizer adds its own).
 #include "../../include/NativeUtils.h"
 
+#include <cstddef>
+extern "C" int hipMalloc(void **, size_t);   // the runtime double's (fake_hip.cpp); hipSuccess = 0
+extern "C" int hipFree(void *);
+static int fakeDevMalloc(void **p, size_t n) { return hipMalloc(p, n); }
+static int fakeDevFree(void *p) { return hipFree(p); }
+
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -214,6 +220,48 @@ void null_sweep()
     lsnFusionDestroy(nullptr);
     CHECK(lsnFusionRun(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == -1, "lsnFusionRun(null)");
     CHECK(lsnFusionRunMesh(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == -1, "lsnFusionRunMesh(null)");
+    // (device memory for the device-resident call below comes straight from the runtime double: this file includes no HIP header)
+    // the chained tick as one call: NULL handles and arguments, then a real two-half pipeline on the double (two plans, side stream, fork / join):
+    // what it allocates and enqueues is checked by the sanitizers and by the double's device discipline
+    CHECK(lsnTickCreate(0, 0, 0, nullptr, nullptr) == nullptr, "lsnTickCreate(0)");
+    lsnTickDestroy(nullptr);
+    CHECK(lsnTickRun(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == -1, "lsnTickRun(null)");
+    CHECK(lsnTickSetParams(nullptr, nullptr, nullptr, nullptr, nullptr) == -1, "lsnTickSetParams(null)");
+    CHECK(lsnTickCapacity(nullptr) == 0 && lsnTickTriangleCapacity(nullptr) == 0 && lsnTickParts(nullptr) == 0, "lsnTick getters(null)");
+    {
+        const int T = 9, n = 2, w[2] = {64, 24}, h[2] = {48, 16};
+        LsnTick *tk = lsnTickCreate(0, T, n, w, h);
+        CHECK(g_faults || (tk != nullptr && lsnTickParts(tk) == 2), "lsnTickCreate");   // (a fault hook may hit any of its allocations: then it returns NULL)
+        if (tk) {
+            const long long cap = lsnTickCapacity(tk), tcap = lsnTickTriangleCapacity(tk);
+            CHECK(cap == 64 * 48 + 24 * 16 && tcap == 2 * cap, "lsnTick capacities");
+            float intr[14], wt[24], bounds[6] = {-2, -2, -2, 2, 2, 2};
+            for (int i = 0; i < n; i++) {
+                const float k[7] = {w[i] / 2.0f, h[i] / 2.0f, 365.0f * w[i] / 512.0f, 365.0f * w[i] / 512.0f, 0.09f, -0.05f, 0.01f};
+                memcpy(intr + 7 * i, k, sizeof(k));
+                const float p[12] = {0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+                memcpy(wt + 12 * i, p, sizeof(p));
+            }
+            void *d_in = nullptr, *c_in = nullptr, *d_co = nullptr, *c_co = nullptr, *v = nullptr, *tr = nullptr;
+            int *o = nullptr, *to = nullptr;
+            CHECK(lsnTickRun(tk, &d_in, &c_in, &d_co, &c_co, &v, o, &tr, to, nullptr) == -1, "lsnTickRun before lsnTickSetParams / with null tables");
+            const bool set = lsnTickSetParams(tk, intr, wt, bounds, nullptr) == 0;
+            CHECK(g_faults || set, "lsnTickSetParams");
+            bool ok = fakeDevMalloc(&d_in, 2 * cap * T)== 0 && fakeDevMalloc(&c_in, 3 * cap * T)== 0 && fakeDevMalloc(&d_co, 2 * cap * T)== 0 &&
+                      fakeDevMalloc(&c_co, 3 * cap * T)== 0 && fakeDevMalloc(&v, 16 * cap * T)== 0 && fakeDevMalloc(&tr, 12 * tcap * T)== 0 &&
+                      fakeDevMalloc((void **)&o, sizeof(int) * (n + 1) * T)== 0 && fakeDevMalloc((void **)&to, sizeof(int) * (n + 1) * T)== 0;
+            CHECK(g_faults || ok, "device buffers for lsnTickRun");
+            if (ok && set)
+                for (int rep = 0; rep < 2; rep++) {
+                    char why[256] = "";
+                    const int rc = lsnTickRun(tk, d_in, c_in, d_co, c_co, v, o, tr, to, nullptr);
+                    if (rc) (void)lsnGetLastError(why, sizeof(why));
+                    CHECK(g_faults || rc == 0, "lsnTickRun: %s", why);
+                }
+            for (void *q : {d_in, c_in, d_co, c_co, v, tr, (void *)o, (void *)to}) (void)fakeDevFree(q);
+            lsnTickDestroy(tk);
+        }
+    }
     Mesh *heap = createMesh();
     CHECK(heap && heap->nVertices == 0 && heap->vertices == nullptr, "createMesh");
     deleteMesh(heap);
