@@ -16,6 +16,11 @@
 //     exceeds every query's bound, so the result is the exact NN at any distance.  Distances are evaluated exactly like
 //     PointCloud::kdtree_distance (include/NativeUtils/icp.h:40-47): (d0*d0 + d1*d1) + d2*d2, no FMA.
 //     Equal distances resolve to the lowest target index (nanoflann's tie order is traversal dependent).
+//     In front of the group search sits the NEAR PATH (round 6): a query that knows a real target point near it -- its previous
+//     neighbour, or what a probe of the 27 cells around it found -- walks the grid cells the ball of that distance touches by itself
+//     and is settled; only the rest forms the groups' search.  Same bits either way (see the NEAR PATH section).
+//     The grid is built with one atomic per RUN of equal cells among a wave's lanes (consecutive points are raster neighbours), whose
+//     return value ranks the run's points: the scatter needs no atomics.
 //   * one-to-one matching -- a 64-bit atomicMin per target on (dist_bits << 32 | ~i): minimum distance wins, the
 //     LATER source index wins ties, which is what the sequential scan at icp.cpp:95-126 ends with; a workgroup first
 //     combines its claims in LDS (scene clouds pile thousands of claims onto a few rim targets).
