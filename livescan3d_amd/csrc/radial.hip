@@ -1248,12 +1248,10 @@ static int radial_correct_on(LsnFusion *p, const float *intr_params, const void 
     // 256 x 4 426, 256 x 7 432, 256 x 5 470, 256 x 8 489, 256 x 12 551, 128 x 4 496, 1024 x 12 718 -- the same 24 waves per CU, but six
     // groups marching through their phases (gather: memory; closing: VALU + LDS) on their own fill each other's waits better than three
     // (eight pixels in flight per thread: the 8 x 512 pixels of such a band are two full trips for 256 threads -- 378-391 us; six in flight:
-    // 416-419, 16: 468.)  Wider frames keep the 52 KB budget of rounds 3-5: no measurement says otherwise.
+    // 416-419, 16: 468.)  Wider frames: fewer rows, down to two, to stay near that footprint -- 16 x 1024x1024 x 8 scene ticks, whole
+    // correction: 5 rows (the 52 KB budget of rounds 3-5) 1.31 ms, 2 / 3 / 4 rows 1.22-1.25, 6 rows 1.26, 8 rows 1.46.
     int rows = 6;
-    if (band_lds_bytes(rows, max_w) > 28 * 1024) {
-        rows = 12;
-        while (rows > 1 && band_lds_bytes(rows, max_w) > 52 * 1024) rows--;
-    }
+    while (rows > 2 && band_lds_bytes(rows, max_w) > 32 * 1024) rows--;
     if (const char *env = getenv("LSN_RADIAL_BAND_ROWS")) {  // tuning
         const int v = atoi(env);
         if (v >= 1 && band_lds_bytes(v, max_w) <= 160 * 1024) rows = v;

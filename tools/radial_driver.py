@@ -1,4 +1,4 @@
-"""Minimal radial-correction run for rocprofv3: python3 tools/radial_driver.py [noise|scene] [ticks] [reps]: in place, then out of place."""
+"""Minimal radial-correction run for rocprofv3: python3 tools/radial_driver.py [noise|scene] [ticks] [reps] [sensors width height]: in place, then out of place."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,7 +7,7 @@ from livescan3d_amd.fusion import DeviceFusion
 kind = sys.argv[1] if len(sys.argv) > 1 else "noise"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-S, w, h = 8, 512, 424
+S, w, h = [int(x) for x in sys.argv[4:7]] if len(sys.argv) >= 7 else (8, 512, 424)
 dev = torch.device("cuda", 0)
 if kind == "noise":
     depth, rgb = synth.noise_frames_torch(dev, 1, T, S, w, h)
