@@ -1649,12 +1649,20 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(float4 *src, float *ver
 }
 
 // What lsnIcpRun clears before its first iteration.
-__global__ __launch_bounds__(kThreads) void run_init_kernel(unsigned long long *keys, int n_keys, int *counters, int n_counters, IcpState *st)
+// seeds (nullable): neighbours handed in from outside, by the queries' ORIGINAL index (lsnRefine: the previous Gauss-Seidel pass's) -- they go
+// to the sorted order the first NN step reads; that step then is a seeded one with no motion to apply (mk = 0).
+__global__ __launch_bounds__(kThreads) void run_init_kernel(unsigned long long *keys, int n_keys, int *counters, int n_counters, IcpState *st,
+                                                            const int *__restrict__ seeds, const float4 *__restrict__ src, int n2, int *idx_sorted)
 {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i < n_keys) keys[i] = ~0ull;
     if (i < n_counters) counters[i] = 0;
-    if (i == 0) st->v_valid = 0;
+    if (i == 0) {
+        st->v_valid = 0;
+        st->mk = 0;
+        if (seeds) st->near_next = 1;   // (the first step has no statistics of a previous one: seeds from a converged pass are near)
+    }
+    if (seeds && i < n2) idx_sorted[i] = seeds[__float_as_int(src[i].w)];
 }
 
 }  // namespace
@@ -1998,8 +2006,10 @@ extern "C" int lsnIcpNearest(LsnIcp *w, const float *d_verts1, int n1, const flo
     return lsn::guarded<int>("lsnIcpNearest", static_cast<int>(-1), [&]() { return lsnIcpNearest_impl(w, d_verts1, n1, d_verts2, n2, d_idx, d_dist2, nn_mode, stream); });
 }
 
+// d_seeds (nullable, lsnRefine): n2 target indices by the queries' original index -- any index < n1 is a valid seed (a real point bounds the
+// search; the result never depends on it), good ones make the first step as cheap as the later ones.
 static int lsnIcpRun_impl(LsnIcp *w, const float *d_verts1, int n1, float *d_verts2, int n2, float *d_R, float *d_t, int maxIter,
-                         int nn_mode, void *stream)
+                         int nn_mode, void *stream, const int *d_seeds = nullptr)
 {
     lsn::clear_error();
     if (check_sizes(w, n1, n2, "lsnIcpRun")) return -1;
@@ -2024,12 +2034,13 @@ static int lsnIcpRun_impl(LsnIcp *w, const float *d_verts1, int n1, float *d_ver
     IcpState *st = w->state.as<IcpState>();
     // one launch instead of three fills (each a kernel of its own, ~4.5 us): the match keys, the NN step's list counters, and
     // v_valid -- the first iteration's SVD starts cold
-    hipLaunchKernelGGL(run_init_kernel, dim3(blocks_for(n1 > 2 * kBankInts ? n1 : 2 * kBankInts)), dim3(kThreads), 0, s, keys, n1, w->counters.as<int>(),
-                       2 * kBankInts, st);
+    const bool seeded0 = d_seeds && w->seed_nn && nn_mode != 0;
+    hipLaunchKernelGGL(run_init_kernel, dim3(blocks_for(std::max(std::max(n1, n2), 2 * kBankInts))), dim3(kThreads), 0, s, keys, n1, w->counters.as<int>(),
+                       2 * kBankInts, st, seeded0 ? d_seeds : (const int *)nullptr, (const float4 *)w->src.sorted.as<float4>(), n2, w->idx_sorted.as<int>());
     for (int iter = 0; iter < maxIter; iter++) {
         // from the second iteration on idx[] still holds every query's previous neighbour: the search is seeded with it, and
         // its first launch also carries out the previous iteration's motion and clears the match keys
-        const bool fused = iter > 0 && w->seed_nn && nn_mode != 0;
+        const bool fused = (iter > 0 || seeded0) && w->seed_nn && nn_mode != 0;
         if (iter > 0 && !fused)
             hipLaunchKernelGGL(apply_kernel, dim3(blocks_for(n2 > n1 ? n2 : n1)), dim3(kThreads), 0, s, w->src.sorted.as<float4>(), d_verts2, n2,
                                (const IcpState *)st, keys, n1);
@@ -2111,7 +2122,7 @@ struct RefineState {   // what a refine pass keeps on the device between calls
     int device = -1;
     LsnIcp *ws = nullptr;
     hipStream_t s = nullptr;
-    lsn::DevBuf d_all, d_others, d_Rt;
+    lsn::DevBuf d_all, d_others, d_Rt, d_seeds;
     void drop()
     {
         if (device >= 0) (void)hipSetDevice(device);
@@ -2119,7 +2130,7 @@ struct RefineState {   // what a refine pass keeps on the device between calls
         ws = nullptr;
         if (s) (void)hipStreamDestroy(s);
         s = nullptr;
-        d_all.release(); d_others.release(); d_Rt.release();
+        d_all.release(); d_others.release(); d_Rt.release(); d_seeds.release();
     }
     ~RefineState() { drop(); }
 };
@@ -2171,9 +2182,10 @@ static int lsnRefine_impl(int device, int n_sensors, float *const *clouds, const
         if (!rc && !rs->s) rc = hipStreamCreateWithFlags(&rs->s, hipStreamNonBlocking) != hipSuccess;
         hipStream_t s = rs->s;
         LsnIcp *ws = rs->ws;
-        lsn::DevBuf &d_all = rs->d_all, &d_others = rs->d_others, &d_Rt = rs->d_Rt;
+        lsn::DevBuf &d_all = rs->d_all, &d_others = rs->d_others, &d_Rt = rs->d_Rt, &d_seeds = rs->d_seeds;
         if (!rc) rc = d_all.reserve(sizeof(float) * 3 * (size_t)total) || d_others.reserve(sizeof(float) * 3 * (size_t)(total - min_n)) ||
-                      d_Rt.reserve(sizeof(float) * Rt.size());
+                      d_Rt.reserve(sizeof(float) * Rt.size()) || d_seeds.reserve(sizeof(int) * (size_t)total);
+        static const bool carry_seeds = !(getenv("LSN_REFINE_SEEDS") && atoi(getenv("LSN_REFINE_SEEDS")) == 0);   // A/B
         std::vector<long long> off(n_sensors + 1, 0);
         for (int i = 0; i < n_sensors; i++) off[i + 1] = off[i] + counts[i];
         for (int i = 0; i < n_sensors && !rc; i++)
@@ -2188,9 +2200,17 @@ static int lsnRefine_impl(int device, int n_sensors, float *const *clouds, const
                                         hipMemcpyDeviceToDevice, s) != hipSuccess;
                     pos += counts[j];
                 }
+                // From the second pass on the first NN step of a call is seeded with the neighbours the sensor's call of the previous pass ended
+                // with ("all other sensors" is the same concatenation in every pass, so the indices still name real points; the others have moved a
+                // little, which only makes the seeds a little less tight): ~65 us instead of ~150 for that step, same result.
                 if (!rc)
-                    rc = lsnIcpRun(ws, d_others.as<float>(), (int)pos, d_all.as<float>() + 3 * off[i], counts[i], d_Rt.as<float>() + 12 * i,
-                                   d_Rt.as<float>() + 12 * i + 9, n_icp_iters, 1, s);     // :370
+                    rc = lsn::guarded<int>("lsnRefine", -1, [&]() {
+                        return lsnIcpRun_impl(ws, d_others.as<float>(), (int)pos, d_all.as<float>() + 3 * off[i], counts[i], d_Rt.as<float>() + 12 * i,
+                                              d_Rt.as<float>() + 12 * i + 9, n_icp_iters, 1, s,
+                                              carry_seeds && it > 0 ? d_seeds.as<int>() + off[i] : (const int *)nullptr);     // :370
+                    });
+                if (!rc && carry_seeds && it + 1 < n_refine_iters)
+                    rc = hipMemcpyAsync(d_seeds.as<int>() + off[i], ws->idx.p, sizeof(int) * (size_t)counts[i], hipMemcpyDeviceToDevice, s) != hipSuccess;
             }
         }
         // results land in scratch first: the caller's arrays are only touched when everything worked
