@@ -2193,13 +2193,13 @@ static int lsnRefine_impl(int device, int n_sensors, float *const *clouds, const
         if (!rc) rc = hipMemcpyAsync(d_Rt.p, Rt.data(), sizeof(float) * Rt.size(), hipMemcpyHostToDevice, s) != hipSuccess;
         for (int it = 0; it < n_refine_iters && !rc; it++) {                  // :347
             for (int i = 0; i < n_sensors && !rc; i++) {                      // :349
-                long long pos = 0;                                             // :352-357 all other sensors' current clouds
-                for (int j = 0; j < n_sensors && !rc; j++) {
-                    if (j == i) continue;
-                    rc = hipMemcpyAsync(d_others.as<float>() + 3 * pos, d_all.as<float>() + 3 * off[j], sizeof(float) * 3 * (size_t)counts[j],
+                // :352-357 all other sensors' current clouds, in sensor order = everything before sensor i's block and everything behind it: two copies
+                const long long pos = total - counts[i];
+                if (off[i] > 0)
+                    rc = hipMemcpyAsync(d_others.as<float>(), d_all.as<float>(), sizeof(float) * 3 * (size_t)off[i], hipMemcpyDeviceToDevice, s) != hipSuccess;
+                if (!rc && off[i + 1] < total)
+                    rc = hipMemcpyAsync(d_others.as<float>() + 3 * off[i], d_all.as<float>() + 3 * off[i + 1], sizeof(float) * 3 * (size_t)(total - off[i + 1]),
                                         hipMemcpyDeviceToDevice, s) != hipSuccess;
-                    pos += counts[j];
-                }
                 // From the second pass on the first NN step of a call is seeded with the neighbours the sensor's call of the previous pass ended
                 // with ("all other sensors" is the same concatenation in every pass, so the indices still name real points; the others have moved a
                 // little, which only makes the seeds a little less tight): ~65 us instead of ~150 for that step, same result.
